@@ -1,0 +1,122 @@
+"""Known-answer tests for the CPU oracle, derived analytically from the cited reference
+code.  These are the only pins the oracle has: the reference cannot
+run here (no TensorFlow) and ships no golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import kfnet_oracle as O
+from oracle import kfnet_oracle_torch as OT
+
+
+def test_kalman_equal_noise():  # KFNet/KFNet.py:154-160
+    x = np.array([[[[1.0, 2.0, 3.0]]]]); z = np.array([[[[3.0, 4.0, 5.0]]]])
+    s = np.array([[[[0.5]]]])
+    kx, ks = O.build_kf_coord(x, s, z, s)
+    assert np.allclose(kx, (x + z) / 2)
+    assert np.allclose(ks, 0.5 / np.sqrt(2))
+
+
+def test_kalman_limits():
+    x = np.zeros((1, 1, 1, 3)); z = np.ones((1, 1, 1, 3))
+    kx, ks = O.build_kf_coord(x, np.full((1, 1, 1, 1), 1.0), z, np.full((1, 1, 1, 1), 1e-8))
+    assert np.allclose(kx, z, atol=1e-12) and ks[0, 0, 0, 0] < 1e-7
+    kx, ks = O.build_kf_coord(x, np.full((1, 1, 1, 1), 1e-3), z, np.full((1, 1, 1, 1), 1e3))
+    assert np.allclose(kx, x, atol=1e-9) and np.isclose(ks[0, 0, 0, 0], 1e-3, rtol=1e-9)
+
+
+def test_predict_clamp():  # KFNet/KFNet.py:393-401
+    h, w = 4, 5
+    prob = np.full((h * w, 64), 1 / 64.0)
+    offs = O.coord_volume(np.zeros((1, h, w, 2)), np.zeros((1, h, w, 2)))[1]
+    tx, ts, flow = O.process_model(prob, np.zeros((h * w, 1)), offs, np.zeros((1, h, w, 3)),
+                                   np.zeros((1, h, w, 1)))
+    assert np.allclose(ts, np.sqrt(2e-10))
+    assert np.allclose(flow, -0.5)  # App. E.7 soft-argmax bias of the -4..3 window
+
+
+def test_sampler():  # tools/util.py:36-93, App. A6
+    W = 8
+    img = np.tile(np.arange(1, W + 1, dtype=np.float64)[None, None, :, None], (1, 3, 1, 1))
+    def s(x, y=1.0):
+        return O.bilinear_sampler(img, np.array([[[[x, y]]]]))[0, 0, 0, 0]
+    assert s(3.0) == 4.0
+    assert np.isclose(s(6.75), 7.75)
+    assert s(7.0) == 0.0          # x == W-1 exactly -> weights cancel
+    assert s(-0.25) == 0.0
+    assert s(3.0, 2.0) == 0.0     # y == H-1
+    assert s(3.0, -1.0) == 0.0
+    # fp32 torch restatement agrees
+    c = np.array([[[[6.75, 1.0], [7.0, 1.0], [2.5, 0.5]]]], dtype=np.float32)
+    assert np.allclose(OT.bilinear_sampler(img.astype(np.float32), c), O.bilinear_sampler(img, c.astype(np.float64)))
+
+
+def test_cost_volume_identity_and_direction():  # KFNet/KFNet.py:343-359
+    rng = np.random.default_rng(0)
+    f = rng.normal(size=(1, 6, 7, 4))
+    V, offs = O.coord_volume(f, f, 8)
+    V = V.reshape(6, 7, 8, 8, 4)
+    assert np.all(V[:, :, 4, 4, :] == 0)
+    assert offs.shape == (64, 2) and tuple(offs[0]) == (-4, -4) and tuple(offs[63]) == (3, 3)
+    assert tuple(offs[1]) == (-3, -4)  # (x, y): j fastest
+    # border: shifted f1 out of range -> V == f2
+    assert np.all(V[0, 0, 0, 0, :] == f[0, 0, 0, :])
+    # delta at (x0,y0): block (i,j) of V is -delta at (x0-(j-4), y0-(i-4))
+    d = np.zeros((1, 6, 7, 1)); d[0, 3, 4, 0] = 1.0
+    Vd, _ = O.coord_volume(d, np.zeros_like(d), 8)
+    Vd = Vd.reshape(6, 7, 8, 8)
+    i, j = 2, 7
+    ys, xs = np.nonzero(Vd[:, :, i, j])
+    assert list(zip(ys, xs)) == [(3 - (i - 4), 4 - (j - 4))] and Vd[5, 1, i, j] == -1.0
+    Vt, _ = OT.coord_volume(f.astype(np.float32), (f * 2).astype(np.float32), 8)
+    Vn, _ = O.coord_volume(f.astype(np.float32), (f * 2).astype(np.float32), 8)
+    assert np.array_equal(Vt, Vn)
+
+
+def test_stride2_same():  # App. E.8
+    x = np.ones((1, 6, 8, 1)); w = np.ones((3, 3, 1, 1))
+    y = O.conv2d_same(x, w, None, 2, False)[0, :, :, 0]
+    assert y.shape == (3, 4)
+    assert y[0, 0] == 9 and y[-1, 0] == 6 and y[0, -1] == 6 and y[-1, -1] == 4
+    # odd size: pad (1,1)
+    y = O.conv2d_same(np.ones((1, 5, 5, 1)), w, None, 2, False)[0, :, :, 0]
+    assert y.shape == (3, 3) and y[0, 0] == 4 and y[1, 1] == 9
+    assert O.same_pad(540, 3, 2) == (270, 0, 1) and O.same_pad(135, 3, 2) == (68, 1, 1)
+
+
+def test_deconv():  # App. E.9 / A2
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(2, 1, 1, 5)); w = rng.normal(size=(3, 3, 4, 5)); b = rng.normal(size=4)
+    y = O.conv2d_transpose_same(x, w, b, 2, False)
+    ref = np.einsum('bc,ijoc->bijo', x[:, 0, 0], w[0:2, 0:2]) + b
+    assert np.allclose(y, ref)
+    # gradient-of-conv definition on a 2x3 input
+    x = rng.normal(size=(1, 2, 3, 2)); w = rng.normal(size=(3, 3, 3, 2))
+    y = O.conv2d_transpose_same(x, w, None, 2, False)
+    g = rng.normal(size=y.shape)
+    # <deconv(x), g> == <x, conv_s2(g, w')> where w' [kh,kw,Cin=3,Cout=2] = w
+    c = O.conv2d_same(g, w, None, 2, False)
+    assert np.isclose((y * g).sum(), (x * c).sum())
+    yt = OT.deconv_same(OT._t(x.astype(np.float32)).permute(0, 3, 1, 2), w.astype(np.float32), None, 2, False)
+    assert np.allclose(yt.permute(0, 2, 3, 1).numpy(), y, atol=1e-5)
+
+
+def test_l2norm_and_transform():
+    assert np.all(O.l2_normalize(np.zeros((1, 1, 1, 4))) == 0)
+    v = np.array([[[[0.6, 0.8]]]])
+    assert np.allclose(O.l2_normalize(v), v)
+    c = np.random.default_rng(2).normal(size=(1, 2, 2, 3))
+    assert np.allclose(O.apply_transform(c, np.eye(4)), c)
+    T = np.eye(4); T[:3, 3] = [1, 2, 3]
+    assert np.allclose(O.apply_transform(c, T), c + np.array([1, 2, 3]))
+
+
+def test_conv_vs_torch_random():
+    rng = np.random.default_rng(3)
+    for (H, W, ci, co, k, s) in [(7, 9, 3, 5, 3, 1), (8, 10, 4, 6, 3, 2), (9, 7, 4, 2, 3, 2), (5, 5, 8, 3, 1, 1)]:
+        x = rng.normal(size=(2, H, W, ci)).astype(np.float32)
+        w = rng.normal(size=(k, k, ci, co)).astype(np.float32)
+        b = rng.normal(size=co).astype(np.float32)
+        y = O.conv2d_same(x.astype(np.float64), w, b, s, True)
+        yt = OT.conv_same(OT._t(x).permute(0, 3, 1, 2), w, b, s, True).permute(0, 2, 3, 1).numpy()
+        assert y.shape == yt.shape
+        assert np.allclose(y, yt, atol=1e-4)
