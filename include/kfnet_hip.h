@@ -1,0 +1,170 @@
+/* libkfnet_hip.so -- C ABI of the MI355X-native (gfx950) KFNet prediction path.
+ *
+ * The reference (zlthinker/KFNet) has no native/FFI boundary: its hot path is a TF-1.x
+ * graph built by the Python `cnn_wrapper.Network` DSL and executed by `sess.run`
+ * (KFNet/eval.py:78-83).  Each entry point below replaces the TensorFlow op(s) that one
+ * reference call site dispatches to; the Python host in kfnet_amd/ keeps the reference's
+ * class/method surface and calls these through ctypes.
+ *
+ * Conventions
+ *   - extern "C"; every function returns KFN_OK (0) or a negative KFN_ERR_*; the text
+ *     of the last error on the calling thread is kfn_last_error().  No exceptions cross.
+ *   - All tensors are device pointers to fp32, NHWC, unless the name says otherwise.
+ *     The caller owns every buffer; the library never allocates or frees tensor memory
+ *     behind the caller's back and keeps no per-call state (re-entrant; any number of
+ *     host threads may call with distinct streams).
+ *   - `stream` is a hipStream_t (NULL = the default stream).  All work is asynchronous
+ *     on that stream and is hipGraph-capturable (no allocation / sync inside a launch).
+ *   - A "pixel stride" (ldx / ldy) is the distance in floats between consecutive
+ *     pixels; it lets a layer read or write a channel slice of a wider buffer, which is
+ *     how `Network.concat` (cnn_wrapper/network.py:316-318) is realised without copies.
+ */
+#ifndef KFNET_HIP_H_
+#define KFNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KFN_OK 0
+#define KFN_ERR_ARG (-1)
+#define KFN_ERR_HIP (-2)
+#define KFN_ERR_UNSUPPORTED (-3)
+
+#define KFN_ABI_VERSION 1
+
+const char* kfn_last_error(void);
+int kfn_abi_version(void);
+/* Device facts used by the host-side tile heuristics.  arch receives e.g. "gfx950". */
+int kfn_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- plumbing for hosts that do not bring their own allocator/streams (PyTorch does) -- */
+int kfn_malloc(void** dptr, size_t bytes);
+int kfn_free(void* dptr);
+int kfn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int kfn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int kfn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int kfn_memset(void* dst, int value, size_t bytes, void* stream);
+int kfn_stream_create(void** stream);
+int kfn_stream_destroy(void* stream);
+int kfn_stream_sync(void* stream);
+int kfn_event_create(void** event);
+int kfn_event_destroy(void* event);
+int kfn_event_record(void* event, void* stream);
+int kfn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+
+/* ---- convolution: replaces tf.layers.conv2d / tf.layers.conv2d_transpose -------------
+ * Network.conv   cnn_wrapper/network.py:116-135  (SCoordNet.py:21-32, OFlowNet.py:19-41,
+ *                KFNet/KFNet.py:318-338 call tf.layers.conv2d directly)
+ * Network.deconv cnn_wrapper/network.py:418-437  (OFlowNet.py:26,31,36)
+ * tf.layers.dense (OFlowNet.py:50-55) is the 1x1 case on a [P,1,1,C] tensor.
+ *
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, fp32 accumulate):
+ *   M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin (requires Cin % 16 == 0).
+ * Weights are PRE-PACKED by the host into w_packed[cout_pad][kh*kw*Cin] (K contiguous;
+ * row co holds w[kh][kw][ci][co] in (kh,kw,ci) order; for transposed convs the TF
+ * [kh,kw,Cout,Cin] kernel is packed in the same (kh,kw,ci) order); cout_pad is Cout
+ * rounded up to a multiple of 32 with zero rows.  Padding is TF 'SAME'.
+ */
+typedef struct kfn_conv_desc {
+  int32_t N, H, W, Cin; /* logical input shape */
+  int32_t ldx;          /* input pixel stride (floats), >= Cin, multiple of 4 */
+  int32_t Cout;         /* logical output channels */
+  int32_t cout_pad;     /* rows of w_packed (multiple of 32) */
+  int32_t ldy;          /* output pixel stride (floats), >= Cout */
+  int32_t kh, kw;       /* kernel size (kh*kw <= 32) */
+  int32_t stride;       /* 1 or 2 */
+  int32_t transposed;   /* 0 = conv2d SAME, 1 = conv2d_transpose SAME (stride 2) */
+  int32_t relu;         /* fuse tf.nn.relu */
+  int32_t epilogue;     /* KFN_EPI_* applied after bias(+relu) */
+  int32_t config;       /* 0 = auto tile choice, else KFN_CFG_* */
+} kfn_conv_desc;
+
+#define KFN_EPI_NONE 0
+#define KFN_EPI_L2NORM 1   /* tf.nn.l2_normalize(axis=-1), KFNet/KFNet.py:340; needs Cout == 32 */
+#define KFN_EPI_EXP_CH3 2  /* SCoordNet.GetOutput: uncertainty = exp(ch 3), SCoordNet.py:39-44 */
+#define KFN_EPI_EXP_1E2 3  /* OFlowNet.GetOutput: exp(.) * 1e-2, OFlowNet.py:56 */
+
+#define KFN_CFG_AUTO 0
+#define KFN_CFG_160x128 1  /* 4 waves, wave tile 160x32 */
+#define KFN_CFG_128x128 2  /* 4 waves, wave tile 64x64 */
+#define KFN_CFG_128x64 3   /* 4 waves, wave tile 64x32 */
+#define KFN_CFG_128x32 4   /* 4 waves, wave tile 32x32 */
+#define KFN_CFG_64x64 5    /* 4 waves, wave tile 32x32 */
+
+int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
+                    const float* bias /* [Cout] or NULL */, float* y, void* stream);
+/* Output spatial size for a descriptor (TF SAME rule); host-side shape inference. */
+int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
+
+/* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
+ * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature
+ * tower's preprocess + feat1 (KFNet/KFNet.py:317-320) in ONE pass over the image.
+ * w1 [27][C1], w2 [27][C2] = the TF HWIO kernels flattened (kh,kw,ci major, co minor).
+ * C1, C2 multiples of 16; C2 may be 0 (then w2/b2/y2 are ignored).  ReLU is fused. */
+int kfn_first_conv_u8(const uint8_t* img, int N, int H, int W,
+                      const float* w1, const float* b1, float* y1, int C1,
+                      const float* w2, const float* b2, float* y2, int C2, void* stream);
+
+/* ---- KFNet.BuildCoordVolume + reshape (KFNet/KFNet.py:343-359, :372) -----------------
+ * vol[n, y, x, i, j, c] = f2[n,y,x,c] - f1[n, y+i-w/2, x+j-w/2, c]  (0 outside).
+ * f1, f2: [N,H,W,C] (C % 4 == 0); vol: [N*H*W, window, window, C]. */
+int kfn_cost_volume(const float* f1, const float* f2, float* vol, int N, int H, int W, int C,
+                    int window, void* stream);
+
+/* ---- softmax over the window cells + soft-argmax flow ---------------------------------
+ * OFlowNet.GetOutput softmax (OFlowNet.py:45-47) + KFNet.BuildOFlowNet flow
+ * (KFNet/KFNet.py:381-385): flow[p] = sum_k softmax(logits[p])_k * (j-w/2, i-w/2).
+ * logits [P, window*window] (row-major i,j); flow_xy [P,2]; prob [P,window^2] or NULL. */
+int kfn_flow_softargmax(const float* logits, float* flow_xy, float* prob, int P, int window,
+                        void* stream);
+
+/* ---- the recurrent part: warp + Kalman predict/update + NIS + transform/emit ----------
+ * One launch scans T frames of S independent sequences (one workgroup per sequence,
+ * state resident in LDS when it fits).  Per frame and pixel, in this order:
+ *   KFNet.BuildOFlowNet tail (KFNet/KFNet.py:386-401): pixel_map = (x,y)+flow;
+ *     x^- = bilinear(last_coord), s_l = bilinear(last_unc) (tools/util.py:36-93,
+ *     clamped corners AND clamped-corner weights); P^- = max(s_l^2,eps^2)+max(s_t^2,eps^2)
+ *   KFNet.BuildKFCoord (KFNet/KFNet.py:148-162): K = P^-/(P^-+R), x = max(1-K,0) x^- + K z
+ *   KFNet.GetNIS (KFNet/KFNet.py:164-184)
+ *   eval.py:87-126: reset when (t0+t) % reset_period == 0 (state := measurement),
+ *     optional NIS gate on the OUTPUT only, record = (T.x, 1/sigma) via ApplyTransform
+ *     (KFNet/util.py:12-40).
+ */
+typedef struct kfn_kalman_desc {
+  int32_t S, T, H, W;
+  int32_t t0;            /* global index of frame 0 of this call (reset phase) */
+  int32_t reset_period;  /* eval.py: spec.sequence_length (500); <=0 = never reset */
+  float min_uncertainty; /* KFNet.min_uncertainty = 1e-5 */
+  float nis_gate;        /* 0 = off; eval.py --NIS uses 7.815 */
+  int32_t has_transform; /* 0 = identity */
+  float transform[12];   /* first 3 rows of inv(transform.txt), row-major */
+} kfn_kalman_desc;
+
+int kfn_kalman_scan(const kfn_kalman_desc* desc,
+                    const float* flow_xy,     /* [S,T,H*W,2] */
+                    const float* sigma_trans, /* [S,T,H*W]   */
+                    const float* meas,        /* [S,T,H*W,4] = (z, sigma_z) */
+                    float* state,             /* [S,H*W,4] in/out = (x, sigma) raw KF state */
+                    float* records,           /* [S,T,H*W,4] = (T.x, 1/sigma) */
+                    float* opt_temp,          /* [S,T,H*W,4] = (x^-, sigma^-) or NULL */
+                    float* opt_nis,           /* [S,T,H*W,3] or NULL */
+                    void* stream);
+
+/* KFNet.BuildKFCoord on its own (KFNet/KFNet.py:148-162) + optional KFNet.GetNIS
+ * (:164-184): pred = (x^-, sigma^-), meas = (z, sigma_z), out = (x, sigma), all [P,4];
+ * opt_nis [P,3] or NULL.  48 B/pixel of HBM traffic (32 read + 16 written). */
+int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis, long P,
+                    void* stream);
+
+/* ---- Network.concat fallback (cnn_wrapper/network.py:316-318): strided channel copy -- */
+int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int P, int C,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFNET_HIP_H_ */

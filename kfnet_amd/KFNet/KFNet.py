@@ -1,0 +1,244 @@
+"""Model assembly with the reference's `KFNet/KFNet.py` class surface (KFNetDataSpec,
+KFNet and its Build*/Get* methods), re-designed for a frame-batched MI355X pipeline.
+
+Differences from the reference's graph, all result-preserving:
+  * `images` is a uint8 [B,H,W,3] batch of B CONSECUTIVE frames, not a (t-1, t) pair.
+    Both towers run once per frame; the previous batch's last feature map is kept in
+    slot 0 of a [B+1,h,w,32] ring so frame pairs are (slot b, slot b+1).  No layer couples
+    batch elements, so this equals the reference's batch-2 evaluation of every pair.
+  * The recurrent state is one packed [1,h,w,4] tensor (x,y,z,sigma); `last_coord` /
+    `last_uncertainty` are channel views of it.
+  * warp + Kalman fuse + NIS + transform/emit is one persistent scan launch over the B
+    frames (kfn_kalman_scan) instead of ~35 TF elementwise/gather ops per frame.
+"""
+import numpy as np
+
+from .. import _lib
+from ..cnn_wrapper.network import Network
+from ..cnn_wrapper.OFlowNet import OFlowNet
+from ..cnn_wrapper.SCoordNet import SCoordNet
+from ..graph import (CostVolumeOp, Graph, KalmanScanOp, MemcpyOp, Tensor, variable_scope)
+
+
+class KFNetDataSpec():
+    """KFNet/KFNet.py:6-50 (the scene table only feeds training-schedule fields)."""
+
+    def __init__(self,
+                 batch_size=4,
+                 image_size=(480, 640),
+                 channels=3,
+                 crop_size=(480, 640),
+                 focal_x=525.,
+                 focal_y=525.,
+                 u=320.,
+                 v=240.,
+                 scene='stairs'):
+        self.batch_size = batch_size
+        self.image_size = image_size
+        self.channels = channels
+        self.crop_size = crop_size
+        self.focal_x = focal_x
+        self.focal_y = focal_y
+        self.u = u
+        self.v = v
+        self.scene = scene
+        self.image_num = 2000
+        self.sequence_length = 500
+        self.num_sequence = 4
+        table = {'chess': (4000, 1000, 4), 'fire': (2000, 1000, 2), 'heads': (1000, 1000, 1),
+                 'office': (6000, None, None), 'pumpkin': (4000, None, None),
+                 'redkitchen': (7000, None, None), 'stairs': (2000, 500, 4)}
+        if scene in table:
+            n, sl, ns = table[scene]
+            self.image_num = n
+            if sl is not None:
+                self.sequence_length = sl
+                self.num_sequence = ns
+        self.stepvalue = self.image_num * 75 // self.batch_size
+        self.max_steps = self.stepvalue * 5
+
+
+class _FeatTower(Network):
+    """KFNet.BuildOFlowFeat's 7 convs (KFNet/KFNet.py:318-338) expressed with the DSL."""
+
+    def setup(self):
+        from ..cnn_wrapper.network import PreprocessedImage
+        img = self.layers['input']
+        self.layers['preprocess'] = PreprocessedImage(img, 'preprocess')
+        (self.feed('preprocess')
+         .conv(3, 16, 1, name='feat1')    # 640x480
+         .conv(3, 32, 2, name='feat2')    # 320x240
+         .conv(3, 32, 1, name='feat3')    # 320x240
+         .conv(3, 64, 2, name='feat4')    # 160x120
+         .conv(3, 64, 1, name='feat5')    # 160x120
+         .conv(3, 128, 2, name='feat6')   # 80x60
+         .conv(3, 32, 1, relu=False, name='feat7'))  # 80x60
+
+
+class KFNet():
+    def __init__(self, images, spec, train_scoordnet=False, train_oflownet=False, dropout_rate=0.5,
+                 seed=None, reuse=True):
+        if train_scoordnet or train_oflownet:
+            raise NotImplementedError('training is out of scope of the MI355X prediction path')
+        self.focal_x = spec.focal_x
+        self.focal_y = spec.focal_y
+        self.u = spec.u
+        self.v = spec.v
+
+        self.reuse = reuse
+        self.train_scoordnet = train_scoordnet
+        self.train_oflownet = train_oflownet
+        self.seed = seed
+        self.dropout_rate = dropout_rate
+
+        self.graph = images.graph
+        shape = images.get_shape().as_list()
+        self.batch_size = shape[0]
+        self.height = shape[1]
+        self.width = shape[2]
+        self.flow_sample_rate = 8
+        self.min_uncertainty = 1e-5
+
+        self.images = images
+        self.frame_ops = []   # image-only stage (towers)
+        self.pair_ops = []    # image-pair stage (cost volume, OFlowNet, flow)
+        self.scan_ops = []    # recurrent stage
+        self.scoordnet = self.BuildSCoordNet()
+        self.temp_feat_maps = self.BuildOFlowFeat()
+        self._kalman = None
+
+    ####################### I/O #######################
+    def GetInputImages(self):
+        return self.images
+
+    def GetMeasureCoord(self):
+        return self.scoordnet.GetOutput()
+
+    def GetMeasureCoord2(self):
+        """KFNet/KFNet.py:470-474 picks batch index 1 of the pair; here every batch element
+        is a frame whose measurement is used, so this is GetMeasureCoord."""
+        return self.GetMeasureCoord()
+
+    def GetKFCoordRecursive(self, last_coord, last_uncertainty, transform=None, reset_period=0,
+                            nis_gate=0.0, emit_temp=False, emit_nis=False):
+        """KFNet/KFNet.py:85-100 for all B frames of the batch, in order.
+
+        last_coord / last_uncertainty must be the channel views (0:3, 3:4) of ONE packed
+        [1,h,w,4] state tensor; the state is updated in place (this is eval.py's
+        SetVariableByName feedback, KFNet/eval.py:96-104).  Returns
+        (temp_coord, temp_uncertainty, KF_coord, KF_uncertainty): temp_* are views of the
+        optional [B,h,w,4] prediction buffer (None unless emit_temp), KF_* are views of the
+        state (the raw KF estimate of the batch's LAST frame).  The per-frame output
+        records (T.x, 1/sigma) are `self.records` [B,h,w,4].
+        """
+        state = last_coord.base
+        if state is None or last_uncertainty.base is not state or state.shape[3] != 4:
+            raise ValueError('last_coord/last_uncertainty must be channel views of one packed [1,h,w,4] state')
+        measure_coord, measure_uncertainty = self.GetMeasureCoord2()
+        meas = measure_coord.base  # packed [B,h,w,4]
+        B = self.batch_size
+        feats = self.temp_feat_maps
+        feat_map1 = feats.batch(0, B, name='feat_map1')
+        feat_map2 = feats.batch(1, B, name='feat_map2')
+        n_ops = len(self.graph.ops)
+        flow, transition_uncertainty = self.BuildOFlowNet(feat_map1, feat_map2, last_coord, last_uncertainty)
+        self.pair_ops = self.graph.ops[n_ops:]
+        _, h, w, _ = meas.shape
+        g = self.graph
+        self.records = g.tensor((B, h, w, 4), name='records')
+        self.temp = g.tensor((B, h, w, 4), name='temp') if emit_temp else None
+        self.nis = g.tensor((B, h, w, 3), name='NIS') if emit_nis else None
+        op = KalmanScanOp(flow, transition_uncertainty, meas, state, self.records, self.temp, self.nis,
+                          S=1, T=B, H=h, W=w, reset_period=reset_period, min_uncertainty=self.min_uncertainty,
+                          nis_gate=nis_gate, transform=transform)
+        g.add(op)
+        self._kalman = op
+        # hand the last feature map over to slot 0 for the next batch
+        cp = MemcpyOp(feats.batch(B, 1), feats.batch(0, 1))
+        g.add(cp)
+        self.scan_ops = [op, cp]
+        temp_coord = self.temp.channels(0, 3) if emit_temp else None
+        temp_unc = self.temp.channels(3, 1) if emit_temp else None
+        return temp_coord, temp_unc, state.channels(0, 3), state.channels(3, 1)
+
+    def BuildKFCoord(self, last_coord, last_uncertainty, measure_coord, measure_uncertainty):
+        """KFNet/KFNet.py:148-162 as a stand-alone launch (kfn_kalman_fuse) on packed
+        [.,.,.,4] tensors; inside GetKFCoordRecursive it is fused into the scan kernel."""
+        from ..graph import KalmanFuseOp
+        pred, meas = last_coord.base, measure_coord.base
+        if pred is None or meas is None or last_uncertainty.base is not pred or measure_uncertainty.base is not meas:
+            raise ValueError('BuildKFCoord wants channel views of packed (coord, sigma) tensors')
+        out = self.graph.tensor(pred.shape, name='KF')
+        self.graph.add(KalmanFuseOp(pred, meas, out))
+        return out.channels(0, 3), out.channels(3, 1)
+
+    def GetNIS(self, measure_coord_map, measure_uncertainty_map, temp_coord_map, temp_uncertainty_map):
+        """KFNet/KFNet.py:164-184; produced by the scan kernel when emit_nis is set."""
+        if getattr(self, 'nis', None) is None:
+            raise ValueError('build GetKFCoordRecursive(..., emit_nis=True) first')
+        return self.nis
+    ####################### eof I/O #######################
+
+    def BuildSCoordNet(self):
+        n0 = len(self.graph.ops)
+        with variable_scope('ScoreNet'):
+            net = SCoordNet({'input': self.images},
+                            is_training=self.train_scoordnet,
+                            focal_x=self.focal_x,
+                            focal_y=self.focal_y,
+                            u=self.u,
+                            v=self.v,
+                            dropout_rate=self.dropout_rate,
+                            seed=self.seed,
+                            reuse=self.reuse)
+        self.frame_ops += self.graph.ops[n0:]
+        return net
+
+    def BuildOFlowFeat(self):
+        """KFNet/KFNet.py:315-341.  Returns the [B+1,h,w,32] feature ring; slots 1..B are
+        written by feat7 (+ fused l2_normalize), slot 0 is the previous batch's last map."""
+        g = self.graph
+        n0 = len(g.ops)
+        with variable_scope('Temporal'):
+            tower = _FeatTower({'input': self.images}, is_training=False)
+        feat7 = tower.get_output_by_name('feat7')
+        B, h, w, c = feat7.shape
+        ring = g.tensor((B + 1, h, w, c), name='feat_ring')
+        # re-home feat7's output into slots 1..B of the ring and fuse the L2 normalisation
+        g.storages.remove(feat7.storage)
+        feat7.base = ring
+        feat7.rel_off = 0
+        feat7.rel_batch = 1
+        for op in tower.ops:
+            if op.name == 'feat7':
+                op.epilogue = _lib.EPI_L2NORM
+        self.feat_tower = tower
+        self.frame_ops += [op for op in g.ops[n0:] if op not in self.frame_ops]
+        return ring
+
+    def BuildCoordVolume(self, feat_map1, feat_map2, window_size):
+        """KFNet/KFNet.py:343-359 (+ the reshape of :372): returns the [BHW,w,w,C] volume
+        tensor and the [w*w,2] (x,y) offsets (host ndarray)."""
+        n, h, w, c = feat_map2.shape
+        vol = self.graph.tensor((n * h * w, window_size, window_size, c), name='diff_feat')
+        self.graph.add(CostVolumeOp(feat_map1, feat_map2, vol, window_size))
+        half = window_size // 2
+        offs = np.array([(j - half, i - half) for i in range(window_size) for j in range(window_size)],
+                        dtype=np.float32)
+        return vol, offs
+
+    def BuildOFlowNet(self, feat_map1, feat_map2, coord_map1, uncertainty1):
+        """KFNet/KFNet.py:361-403, image-pair half: cost volume -> OFlowNet -> soft-argmax
+        flow and transition sigma.  The state-dependent half (bilinear warp of
+        coord_map1/uncertainty1 and variance propagation, :386-401) runs inside the scan
+        kernel, so this returns (flow [BHW,1,1,2], transition_uncertainty [BHW,1,1,1])."""
+        window_size = 64 // self.flow_sample_rate  # ensure a flow field 96x96 of original resolution
+        window_area = window_size * window_size
+        diff_feats, shift_offsets = self.BuildCoordVolume(feat_map1, feat_map2, window_size)
+        with variable_scope('Temporal'):
+            coord_flow_net = OFlowNet({'input': diff_feats}, window_area, is_training=self.train_oflownet,
+                                      reuse=self.reuse)
+            prob, transition_uncertainty = coord_flow_net.GetOutput()
+        self.oflownet = coord_flow_net
+        self.prob = prob
+        return prob.flow, transition_uncertainty

@@ -1,0 +1,88 @@
+"""ctypes binding of libkfnet_hip.so (include/kfnet_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or an entry point
+returns an error, a KfnError is raised.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
+
+KFN_OK = 0
+EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
+CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64 = 0, 1, 2, 3, 4, 5
+
+
+class KfnError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
+        'transposed', 'relu', 'epilogue', 'config')]
+
+
+class KalmanDesc(C.Structure):
+    _fields_ = [('S', C.c_int32), ('T', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('t0', C.c_int32), ('reset_period', C.c_int32),
+                ('min_uncertainty', C.c_float), ('nis_gate', C.c_float),
+                ('has_transform', C.c_int32), ('transform', C.c_float * 12)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/kfnet_hip.h
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    'kfn_last_error': (C.c_char_p, []),
+    'kfn_abi_version': (_i, []),
+    'kfn_device_info': (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    'kfn_malloc': (_i, [C.POINTER(_vp), _sz]),
+    'kfn_free': (_i, [_vp]),
+    'kfn_memcpy_h2d': (_i, [_vp, _vp, _sz, _vp]),
+    'kfn_memcpy_d2h': (_i, [_vp, _vp, _sz, _vp]),
+    'kfn_memcpy_d2d': (_i, [_vp, _vp, _sz, _vp]),
+    'kfn_memset': (_i, [_vp, _i, _sz, _vp]),
+    'kfn_stream_create': (_i, [C.POINTER(_vp)]),
+    'kfn_stream_destroy': (_i, [_vp]),
+    'kfn_stream_sync': (_i, [_vp]),
+    'kfn_event_create': (_i, [C.POINTER(_vp)]),
+    'kfn_event_destroy': (_i, [_vp]),
+    'kfn_event_record': (_i, [_vp, _vp]),
+    'kfn_event_elapsed_ms': (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    'kfn_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    'kfn_conv2d_out_shape': (_i, [C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i)]),
+    'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
+    'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KfnError('%s not found -- run `python -m kfnet_amd.build` (hipcc, gfx950); '
+                       'kfnet_amd has no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kfn_abi_version() != 1:
+        raise KfnError('libkfnet_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != KFN_OK:
+        msg = load().kfn_last_error()
+        raise KfnError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))

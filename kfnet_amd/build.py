@@ -1,0 +1,79 @@
+"""Builds kfnet_amd/libkfnet_hip.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python -m kfnet_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects are cached under kfnet_amd/csrc/build/ and
+rebuilt when a source or header is newer.  The built .so is git-ignored but travels to
+the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'libkfnet_hip.so')
+HEADERS = [os.path.join(CSRC, 'kfn_common.h'),
+           os.path.join(os.path.dirname(HERE), 'include', 'kfnet_hip.h')]
+
+ARCH = 'gfx950'
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# per-file extra flags
+EXTRA = {
+    # the Kalman/warp kernel reproduces the reference's unfused elementwise arithmetic
+    'kfn_kalman.hip': ['-ffp-contract=off'],
+}
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (need ROCm with gfx950 support)')
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    objs = []
+    for src in sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append([hipcc] + COMMON + EXTRA.get(src, []) + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stdout))
+        if verbose and r.stdout.strip():
+            print(r.stdout)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

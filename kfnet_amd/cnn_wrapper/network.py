@@ -1,0 +1,240 @@
+"""Chainable layer DSL with the reference's `cnn_wrapper.network.Network` surface
+(cnn_wrapper/network.py:8-31, 34-437), re-targeted from "add a TF op to the graph" to
+"append a libkfnet_hip.so launch to a kfnet_amd.graph.Graph".
+
+Same mechanics: the `@layer` decorator pops `self.terminals`, calls the op, stores the
+result in `self.layers[name]`, re-feeds it and returns `self`; `feed` resolves layer
+names; `get_unique_name` auto-numbers.  Hot-path layers (`conv`, `deconv`, `concat`) are
+backed by HIP kernels.  The reference's other 27 layer methods are never called by
+SCoordNet / OFlowNet / KFNet; they keep their names and signatures and raise
+NotImplementedError (there is deliberately no CPU/eager fallback in the product path).
+"""
+import numpy as np
+
+from .. import _lib
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, pack_bias,
+                     pack_conv_kernel, pack_deconv_kernel, pack_first_kernel)
+
+# Zero padding in default. 'VALID' gives no padding.
+DEFAULT_PADDING = 'SAME'
+
+try:
+    string_types = (basestring,)  # noqa: F821  (py2 spelling used by the reference)
+except NameError:
+    string_types = (str,)
+
+
+def layer(op):
+    """Decorator for composable network layers (cnn_wrapper/network.py:8-31)."""
+
+    def layer_decorated(self, *args, **kwargs):
+        name = kwargs.setdefault('name', self.get_unique_name(op.__name__))
+        if not self.terminals:
+            raise RuntimeError('No input variables found for layer %s.' % name)
+        elif len(self.terminals) == 1:
+            layer_input = self.terminals[0]
+        else:
+            layer_input = list(self.terminals)
+        layer_output = op(self, layer_input, *args, **kwargs)
+        self.layers[name] = layer_output
+        self.feed(layer_output)
+        return self
+
+    layer_decorated.__name__ = op.__name__
+    layer_decorated.__doc__ = op.__doc__
+    return layer_decorated
+
+
+class PreprocessedImage(object):
+    """Result of `(uint8 image - 128) * 0.00625` that has not been materialised: the
+    first convolution consumes it fused (kfn_first_conv_u8)."""
+
+    def __init__(self, source, name):
+        self.source = source
+        self.name = name
+        self.shape = source.shape
+        self.graph = source.graph
+
+    def get_shape(self):
+        return self.source.get_shape()
+
+
+def _same_out(n, s):
+    return -(-n // s)
+
+
+def _off_path(name):
+    def fn(self, *a, **k):
+        raise NotImplementedError(
+            "Network.%s is not on the KFNet prediction path (SURVEY.md §2.1) and has no HIP "
+            "kernel; only conv / deconv / concat (+ SCoordNet.preprocess) are implemented" % name)
+    fn.__name__ = name
+    return layer(fn)
+
+
+class Network(object):
+    """Class NetWork"""
+
+    def __init__(self, inputs, is_training, dropout_rate=0.5, seed=None, reuse=False):
+        self.inputs = inputs
+        self.terminals = []
+        self.layers = dict(inputs)
+        self.trainable = is_training
+        self.reuse = reuse
+        self.training = is_training
+        self.seed = seed
+        self.dropout_rate = dropout_rate
+        self.ops = []  # launches appended by this network, in order
+        self.setup()
+
+    def setup(self):
+        '''Construct the network. '''
+        raise NotImplementedError('Must be implemented by the subclass.')
+
+    # ------------------------------------------------------------------------------
+    @property
+    def graph(self):
+        for v in self.inputs.values():
+            return v.graph
+        raise RuntimeError('network has no inputs')
+
+    def load(self, data_path, session=None, ignore_missing=False):
+        '''Load network weights from the reference's numpy dict format
+        {op_name: {param_name: array}} (cnn_wrapper/network.py:60-75).  `session` is
+        accepted for signature compatibility; weights go to the graph's device buffers.'''
+        from ..weights import from_network_load_dict
+        from ..graph import current_scope
+        data_dict = np.load(data_path, allow_pickle=True).item()
+        flat = from_network_load_dict(data_dict, current_scope() or self._scope)
+        self.graph.load_weights(flat, strict=not ignore_missing)
+
+    def feed(self, *args):
+        '''Set the input(s) for the next operation by replacing the terminal nodes.
+        The arguments can be either layer names or the actual layers.'''
+        assert args
+        self.terminals = []
+        for fed_layer in args:
+            if isinstance(fed_layer, string_types):
+                try:
+                    fed_layer = self.layers[fed_layer]
+                except KeyError:
+                    raise KeyError('Unknown layer name fed: %s' % fed_layer)
+            self.terminals.append(fed_layer)
+        return self
+
+    def get_output(self):
+        '''Returns the current network output.'''
+        return self.terminals[-1]
+
+    def get_output_by_name(self, layer_name):
+        return self.layers[layer_name]
+
+    def get_unique_name(self, prefix):
+        ident = sum(t.startswith(prefix) for t, _ in self.layers.items()) + 1
+        return '%s_%d' % (prefix, ident)
+
+    def change_inputs(self, inputs):
+        assert len(inputs) == 1
+        for key in inputs:
+            self.layers[key] = inputs[key]
+
+    def _emit(self, op):
+        self.graph.add(op)
+        self.ops.append(op)
+        return op
+
+    # ---- hot-path layers -----------------------------------------------------------
+    @layer
+    def conv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING,
+             biased=True):
+        """tf.layers.conv2d (cnn_wrapper/network.py:116-135) -> kfn_conv2d_nhwc, or the
+        fused uint8 first layer when fed by `preprocess`."""
+        if padding != 'SAME':
+            raise NotImplementedError("only padding='SAME' is used by the KFNet path")
+        g = self.graph
+        k = int(kernel_size)
+        if isinstance(input, PreprocessedImage):
+            img = input.source
+            n, h, w, cin = img.shape
+            if not (k == 3 and strides == 1 and relu and cin == 3 and filters % 16 == 0):
+                raise NotImplementedError('fused first layer supports 3x3 stride-1 ReLU convs on 3 channels')
+            y = g.tensor((n, h, w, filters), name=name)
+            kern = g.variable(name + '/kernel', (3, 3, 3, filters), pack_first_kernel)
+            bias = g.variable(name + '/bias', (filters,), pack_bias)
+            op = g.first_conv.get(id(img))
+            if op is None or len(op.heads) >= 2:
+                op = FirstConvOp(img)
+                g.first_conv[id(img)] = op
+                self._emit(op)
+            else:
+                self.ops.append(op)
+            op.add_head(name, y, kern, bias)
+            return y
+        n, h, w, cin = input.shape
+        y = g.tensor((n, _same_out(h, strides), _same_out(w, strides), filters), name=name)
+        kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_conv_kernel)
+        bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
+        self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu))
+        return y
+
+    @layer
+    def deconv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING,
+               biased=True):
+        """tf.layers.conv2d_transpose (cnn_wrapper/network.py:418-437)."""
+        if padding != 'SAME' or strides != 2:
+            raise NotImplementedError("only stride-2 'SAME' transposed convs are used by the KFNet path")
+        g = self.graph
+        k = int(kernel_size)
+        n, h, w, cin = input.shape
+        y = g.tensor((n, h * strides, w * strides, filters), name=name)
+        kern = g.variable(name + '/kernel', (k, k, filters, cin), pack_deconv_kernel)
+        bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
+        self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, transposed=True))
+        return y
+
+    @layer
+    def concat(self, inputs, axis, name):
+        """tf.concat on the channel axis (cnn_wrapper/network.py:316-318).  Producers that
+        still own a private buffer are re-bound to write straight into their channel
+        window of the concat buffer (no copy); anything else is copied."""
+        if axis not in (-1, 3):
+            raise NotImplementedError('concat is only used on the channel axis')
+        g = self.graph
+        n, h, w, _ = inputs[0].shape
+        ctot = sum(t.shape[3] for t in inputs)
+        out = g.tensor((n, h, w, ctot), name=name)
+        off = 0
+        for t in inputs:
+            assert t.shape[:3] == (n, h, w)
+            c = t.shape[3]
+            if isinstance(t, Tensor) and t.is_whole() and not t.external and c % 4 == 0 and off % 4 == 0:
+                t.rebind(out.storage, off, ctot)
+            else:
+                self._emit(CopyChannelsOp(t, out.channels(off, c)))
+            off += c
+        return out
+
+    # ---- off-path layers: names/signatures kept, no kernels ------------------------
+    conv_bn = _off_path('conv_bn')
+    conv3d = _off_path('conv3d')
+    conv3d_bn = _off_path('conv3d_bn')
+    deconv3d = _off_path('deconv3d')
+    deconv3d_bn = _off_path('deconv3d_bn')
+    relu = _off_path('relu')
+    max_pool = _off_path('max_pool')
+    avg_pool = _off_path('avg_pool')
+    l2_pool = _off_path('l2_pool')
+    lrn = _off_path('lrn')
+    add = _off_path('add')
+    fc = _off_path('fc')
+    softmax = _off_path('softmax')
+    batch_normalization = _off_path('batch_normalization')
+    dropout = _off_path('dropout')
+    l2norm = _off_path('l2norm')
+    squeeze = _off_path('squeeze')
+    maximum = _off_path('maximum')
+    tanh = _off_path('tanh')
+    reshape = _off_path('reshape')
+    slice = _off_path('slice')
+    add_n = _off_path('add_n')
+    conv_tanh = _off_path('conv_tanh')

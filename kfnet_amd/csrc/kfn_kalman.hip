@@ -1,0 +1,264 @@
+// kfn_kalman.hip -- the recurrent part of KFNet as one persistent scan kernel.
+//
+// Replaces, per frame and pixel (compiled with -ffp-contract=off so every product/sum is
+// rounded exactly like the reference's unfused TF elementwise ops):
+//   KFNet.BuildOFlowNet tail   KFNet/KFNet.py:386-401  (pixel_map, 2x bilinear_sampler,
+//                                                       variance clamp + propagate)
+//   tools.util.bilinear_sampler tools/util.py:36-93    (clamped corners + clamped weights)
+//   KFNet.BuildKFCoord         KFNet/KFNet.py:148-162
+//   KFNet.GetNIS               KFNet/KFNet.py:164-184
+//   eval.py loop body          KFNet/eval.py:87-126    (reset, NIS output gate, state
+//                                                       feedback, ApplyTransform, 1/sigma)
+//
+// One workgroup (1024 threads = 16 wavefronts) per sequence.  The [H*W] x (x,y,z,sigma)
+// state lives in LDS as float4 (76.8 KB at 60x80) for the whole scan, so the 4-tap warp
+// gather never touches HBM; per frame the kernel streams 28 B/px of inputs (flow 8,
+// sigma_trans 4, measurement 16) and 16 B/px of records from/to HBM, and the inputs of
+// frame t+1 are already in flight while frame t is being fused (register prefetch).
+// The state is single-buffered: all threads gather + fuse into registers, barrier,
+// write back, barrier.
+#include "kfn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 1024;  // threads per sequence
+
+struct KalmanArgs {
+  const f32x2* flow;
+  const float* sigma_t;
+  const f32x4* meas;
+  f32x4* state;
+  f32x4* rec;
+  f32x4* opt_temp;
+  float* opt_nis;
+  kfn_kalman_desc d;
+};
+
+struct PixIn {
+  f32x2 flow;
+  float st;
+  f32x4 z;
+};
+
+template <int PPT>
+__global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_k[];
+  f32x4* st = reinterpret_cast<f32x4*>(smem_k);
+  const int tid = threadIdx.x;
+  const int s = blockIdx.x;
+  const int H = a.d.H, W = a.d.W, HW = H * W, T = a.d.T;
+  const float eps2 = a.d.min_uncertainty * a.d.min_uncertainty;
+  const float xmax = (float)(W - 1), ymax = (float)(H - 1);
+
+  // state -> LDS
+  for (int p = tid; p < HW; p += KT) st[p] = a.state[(size_t)s * HW + p];
+
+  const size_t seq_off = (size_t)s * T * HW;
+  PixIn cur[PPT], nxt[PPT];
+  auto load_inputs = [&](int t, PixIn* dst) {
+    const size_t off = seq_off + (size_t)t * HW;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      int p = tid + k * KT;
+      if (p < HW) {
+        dst[k].flow = a.flow[off + p];
+        dst[k].st = a.sigma_t[off + p];
+        dst[k].z = a.meas[off + p];
+      }
+    }
+  };
+  load_inputs(0, cur);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) load_inputs(t + 1, nxt);
+    const int gi = a.d.t0 + t;
+    const bool reset = a.d.reset_period > 0 && (gi % a.d.reset_period) == 0;
+    const size_t off = seq_off + (size_t)t * HW;
+    f32x4 newst[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      int p = tid + k * KT;
+      if (p >= HW) continue;
+      const f32x4 z = cur[k].z;  // (zx, zy, zz, sigma_z)
+      f32x4 outv;                // record before transform: (x, y, z, sigma)
+      if (reset) {
+        // eval.py:94-101: state := measurement, outputs := measurement
+        newst[k] = z;
+        outv = z;
+        if (a.opt_temp) a.opt_temp[off + p] = z;
+        if (a.opt_nis) {
+          a.opt_nis[(off + p) * 3 + 0] = 0.f;
+          a.opt_nis[(off + p) * 3 + 1] = 0.f;
+          a.opt_nis[(off + p) * 3 + 2] = 0.f;
+        }
+      } else {
+        const int y = p / W, x = p - y * W;
+        // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
+        const float px = (float)x + cur[k].flow.x;
+        const float py = (float)y + cur[k].flow.y;
+        // bilinear_sampler (tools/util.py:36-93)
+        const float x0 = floorf(px), x1 = x0 + 1.0f;
+        const float y0 = floorf(py), y1 = y0 + 1.0f;
+        const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+        const float y0s = fminf(fmaxf(y0, 0.f), ymax), y1s = fminf(fmaxf(y1, 0.f), ymax);
+        const float wx0 = x1s - px, wx1 = px - x0s;
+        const float wy0 = y1s - py, wy1 = py - y0s;
+        const int ix0 = (int)x0s, ix1 = (int)x1s, iy0 = (int)y0s, iy1 = (int)y1s;
+        const f32x4 im00 = st[iy0 * W + ix0];
+        const f32x4 im01 = st[iy1 * W + ix0];
+        const f32x4 im10 = st[iy0 * W + ix1];
+        const f32x4 im11 = st[iy1 * W + ix1];
+        const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
+        f32x4 g = ((w00 * im00 + w01 * im01) + w10 * im10) + w11 * im11;  // add_n order
+        // variance propagation (KFNet.py:393-401)
+        const float last_var = fmaxf(g.w * g.w, eps2);
+        const float trans_var = fmaxf(cur[k].st * cur[k].st, eps2);
+        const float temp_unc = sqrtf(trans_var + last_var);
+        // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
+        const float lv = temp_unc * temp_unc;
+        const float mv = z.w * z.w;
+        const float K = lv / (lv + mv);
+        const float om = fmaxf(1.0f - K, 0.0f);
+        f32x4 kf;
+        kf.x = om * g.x + K * z.x;
+        kf.y = om * g.y + K * z.y;
+        kf.z = om * g.z + K * z.z;
+        kf.w = sqrtf(om * lv);
+        newst[k] = kf;  // eval.py:103-104: raw KF state is fed back
+        outv = kf;
+        // GetNIS (KFNet.py:164-184)
+        const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
+        const float iv = iu * iu;
+        const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
+        const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
+        if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
+          // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
+          outv.x = z.x; outv.y = z.y; outv.z = z.z;
+        }
+        if (a.opt_temp) {
+          f32x4 tv = {g.x, g.y, g.z, temp_unc};
+          a.opt_temp[off + p] = tv;
+        }
+        if (a.opt_nis) {
+          a.opt_nis[(off + p) * 3 + 0] = n0;
+          a.opt_nis[(off + p) * 3 + 1] = n1;
+          a.opt_nis[(off + p) * 3 + 2] = n2;
+        }
+      }
+      // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
+      f32x4 r;
+      if (a.d.has_transform) {
+        const float* M = a.d.transform;
+        r.x = ((M[0] * outv.x + M[1] * outv.y) + M[2] * outv.z) + M[3];
+        r.y = ((M[4] * outv.x + M[5] * outv.y) + M[6] * outv.z) + M[7];
+        r.z = ((M[8] * outv.x + M[9] * outv.y) + M[10] * outv.z) + M[11];
+      } else {
+        r.x = outv.x; r.y = outv.y; r.z = outv.z;
+      }
+      r.w = 1.0f / outv.w;
+      a.rec[off + p] = r;
+    }
+    __syncthreads();  // every gather of frame t done
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      int p = tid + k * KT;
+      if (p < HW) st[p] = newst[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) cur[k] = nxt[k];
+    __syncthreads();  // new state visible
+  }
+  for (int p = tid; p < HW; p += KT) a.state[(size_t)s * HW + p] = st[p];
+}
+
+// KFNet.BuildKFCoord alone (KFNet/KFNet.py:148-162), optional GetNIS (:164-184):
+// 32 B read + 16 B written per pixel, pure HBM streaming.
+__global__ __launch_bounds__(256) void kalman_fuse_kernel(const f32x4* __restrict__ pred,
+                                                          const f32x4* __restrict__ meas,
+                                                          f32x4* __restrict__ out,
+                                                          float* __restrict__ nis, long P) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const f32x4 l = pred[p], z = meas[p];
+    const float lv = l.w * l.w;
+    const float mv = z.w * z.w;
+    const float K = lv / (lv + mv);
+    const float om = fmaxf(1.0f - K, 0.0f);
+    f32x4 kf;
+    kf.x = om * l.x + K * z.x;
+    kf.y = om * l.y + K * z.y;
+    kf.z = om * l.z + K * z.z;
+    kf.w = sqrtf(om * lv);
+    out[p] = kf;
+    if (nis) {
+      const float iu = sqrtf(l.w * l.w + z.w * z.w);
+      const float iv = iu * iu;
+      const float d0 = z.x - l.x, d1 = z.y - l.y, d2 = z.z - l.z;
+      nis[p * 3 + 0] = (d0 * d0) / iv;
+      nis[p * 3 + 1] = (d1 * d1) / iv;
+      nis[p * 3 + 2] = (d2 * d2) / iv;
+    }
+  }
+}
+
+template <int PPT>
+int launch_scan(const KalmanArgs& a, hipStream_t stream) {
+  const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4);
+  auto kern = kalman_scan_kernel<PPT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.d.S), dim3(KT), smem, stream, a);
+  KFN_LAUNCH_CHECK("kalman_scan_kernel");
+  return KFN_OK;
+}
+
+}  // namespace
+
+extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
+                               const float* sigma_trans, const float* meas, float* state,
+                               float* records, float* opt_temp, float* opt_nis, void* stream) {
+  KFN_REQUIRE(d && flow_xy && sigma_trans && meas && state && records, "kfn_kalman_scan: null argument");
+  KFN_REQUIRE(d->S > 0 && d->T > 0 && d->H > 1 && d->W > 1, "kfn_kalman_scan: bad shape S=%d T=%d H=%d W=%d",
+              d->S, d->T, d->H, d->W);
+  const int HW = d->H * d->W;
+  KFN_REQUIRE((size_t)HW * 16 <= 160 * 1024, "kfn_kalman_scan: %dx%d state does not fit the 160 KB LDS", d->H, d->W);
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(flow_xy) & 7) | (reinterpret_cast<uintptr_t>(meas) & 15) |
+               (reinterpret_cast<uintptr_t>(state) & 15) | (reinterpret_cast<uintptr_t>(records) & 15) |
+               (reinterpret_cast<uintptr_t>(opt_temp) & 15)) == 0,
+              "kfn_kalman_scan: misaligned buffer");
+  KalmanArgs a;
+  a.flow = reinterpret_cast<const f32x2*>(flow_xy);
+  a.sigma_t = sigma_trans;
+  a.meas = reinterpret_cast<const f32x4*>(meas);
+  a.state = reinterpret_cast<f32x4*>(state);
+  a.rec = reinterpret_cast<f32x4*>(records);
+  a.opt_temp = reinterpret_cast<f32x4*>(opt_temp);
+  a.opt_nis = opt_nis;
+  a.d = *d;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int ppt = kfn::ceil_div(HW, KT);
+  if (ppt <= 5) return launch_scan<5>(a, s);
+  if (ppt <= 8) return launch_scan<8>(a, s);
+  return launch_scan<10>(a, s);
+}
+
+extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis,
+                               long P, void* stream) {
+  KFN_REQUIRE(pred && meas && out && P > 0, "kfn_kalman_fuse: bad argument");
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(meas) |
+                reinterpret_cast<uintptr_t>(out)) & 15) == 0, "kfn_kalman_fuse: misaligned buffer");
+  long blocks = (P + 255) / 256;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  hipLaunchKernelGGL(kalman_fuse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(pred), reinterpret_cast<const f32x4*>(meas),
+                     reinterpret_cast<f32x4*>(out), opt_nis, P);
+  KFN_LAUNCH_CHECK("kalman_fuse_kernel");
+  return KFN_OK;
+}

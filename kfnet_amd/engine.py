@@ -1,0 +1,164 @@
+"""Sequence engine: drives the KFNet graph over a stream of frames.
+
+This is the native replacement of the per-frame `sess.run` loop of KFNet/eval.py:77-126.
+A chunk of T frames is processed in two phases:
+
+  heavy (state-independent, frame-parallel): for every batch of B frames run both towers,
+      the cost volume, OFlowNet and the flow head; the per-frame scan inputs
+      (flow 8 B/px, sigma_trans 4 B/px, measurement 16 B/px) are appended to chunk buffers;
+  scan  (the only sequential part): ONE kfn_kalman_scan launch walks the T frames with
+      the recurrent state in LDS and emits the [T,h,w,4] records.
+
+In a multi-GPU run every rank does `heavy` for its own contiguous chunk immediately and
+only the scan waits for the 76.8 KB state of the previous rank (kfnet_amd/dist.py).
+"""
+import numpy as np
+
+from . import _lib
+from .graph import Graph, KalmanScanOp
+from .KFNet.KFNet import KFNet, KFNetDataSpec
+
+
+def grid_size(image_hw):
+    """Label-grid size = three stride-2 SAME convs = ceil(./8) (not eval.py's `//8`,
+    which is wrong for 540 rows -- SURVEY.md F11)."""
+    h, w = image_hw
+    for _ in range(3):
+        h, w = -(-h // 2), -(-w // 2)
+    return h, w
+
+
+class KFNetEngine(object):
+    def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
+                 nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False):
+        import torch
+        self.torch = torch
+        self.B = int(batch)
+        self.H, self.W = image_size
+        self.h, self.w = grid_size(image_size)
+        self.reset_period = int(reset_period)
+        self.nis_gate = float(nis_gate)
+        self.transform = None if transform is None else np.asarray(transform, dtype=np.float32)
+        self.max_chunk = int(max_chunk)
+        self.emit_debug = emit_debug
+
+        g = self.graph = Graph()
+        spec = KFNetDataSpec(batch_size=self.B, image_size=image_size)
+        self.images = g.placeholder((self.B, self.H, self.W, 3), 'u8', name='images')
+        self.state = g.placeholder((1, self.h, self.w, 4), name='last_state')
+        last_coord = self.state.channels(0, 3, name='last_coord')
+        last_unc = self.state.channels(3, 1, name='last_uncertainty')
+        self.net = KFNet(self.images, spec)
+        self.net.GetKFCoordRecursive(last_coord, last_unc, transform=self.transform,
+                                     reset_period=self.reset_period, nis_gate=self.nis_gate,
+                                     emit_temp=emit_debug, emit_nis=emit_debug)
+        self.meas = self.net.GetMeasureCoord()[0].base          # [B,h,w,4]
+        self.flow = self.net.prob.flow                           # [B*hw,1,1,2]
+        self.sigma_t = self.net.oflownet.get_output_by_name('uncertainty')  # [B*hw,1,1,1]
+        # chunk-level scan buffers
+        hw = self.h * self.w
+        T = self.max_chunk
+        self.c_flow = g.tensor((T, self.h, self.w, 2), name='chunk_flow')
+        self.c_sigma = g.tensor((T, self.h, self.w, 1), name='chunk_sigma_trans')
+        self.c_meas = g.tensor((T, self.h, self.w, 4), name='chunk_meas')
+        self.c_rec = g.tensor((T, self.h, self.w, 4), name='chunk_records')
+        self.c_temp = g.tensor((T, self.h, self.w, 4), name='chunk_temp') if emit_debug else None
+        self.c_nis = g.tensor((T, self.h, self.w, 3), name='chunk_nis') if emit_debug else None
+        self.chunk_scan = KalmanScanOp(self.c_flow, self.c_sigma, self.c_meas, self.state, self.c_rec,
+                                       self.c_temp, self.c_nis, S=1, T=1, H=self.h, W=self.w,
+                                       reset_period=self.reset_period, min_uncertainty=self.net.min_uncertainty,
+                                       nis_gate=self.nis_gate, transform=self.transform)
+        g.finalize(device)
+        g.load_weights(weights)
+        self.lib = _lib.load()
+        self.device = g.device
+        self.hw = hw
+        self.heavy_ops = self.net.frame_ops + self.net.pair_ops
+        self.handover = self.net.scan_ops[1]
+        self._staging = None
+
+    # ------------------------------------------------------------------------------
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def upload_frames(self, frames):
+        """uint8 [T,H,W,3] host array -> device tensor (H2D once; the timed region of
+        bench.py starts with frames resident in HBM)."""
+        frames = np.ascontiguousarray(frames)
+        assert frames.dtype == np.uint8 and frames.shape[1:] == (self.H, self.W, 3)
+        return self.torch.from_numpy(frames).to(self.device)
+
+    def _set_batch_images(self, dev_frames, start, count, stream):
+        """Copy `count` frames starting at `start` into the batch input (pad with the last)."""
+        fb = self.H * self.W * 3
+        dst = self.images.ptr
+        src = dev_frames.data_ptr() + start * fb
+        _lib.check(self.lib.kfn_memcpy_d2d(dst, src, count * fb, stream), 'memcpy images')
+        for k in range(count, self.B):  # pad: repeat the last valid frame (results discarded)
+            _lib.check(self.lib.kfn_memcpy_d2d(dst + k * fb, src + (count - 1) * fb, fb, stream), 'memcpy pad')
+
+    def prime(self, dev_prev_frame):
+        """Compute the flow features of the frame preceding this chunk and park them in
+        ring slot 0 (multi-GPU: rank r recomputes them from the image -- 5.6 GFLOP --
+        instead of receiving 614 KB from rank r-1)."""
+        stream = self._stream()
+        fb = self.H * self.W * 3
+        for k in range(self.B):
+            _lib.check(self.lib.kfn_memcpy_d2d(self.images.ptr + k * fb, dev_prev_frame.data_ptr(), fb, stream), 'prime')
+        tower_ops = [op for op in self.net.frame_ops if op in self.net.feat_tower.ops]
+        self.graph.run(stream, tower_ops)
+        ring = self.net.temp_feat_maps
+        self.handover.src = ring.batch(self.B, 1)
+        self.handover.launch(self.lib, stream)
+
+    def heavy(self, dev_frames, T=None):
+        """State-independent phase for frames [0,T) of `dev_frames` -> chunk scan buffers."""
+        T = dev_frames.shape[0] if T is None else T
+        if T > self.max_chunk:
+            raise ValueError('chunk of %d frames exceeds max_chunk=%d' % (T, self.max_chunk))
+        stream = self._stream()
+        ring = self.net.temp_feat_maps
+        hw = self.hw
+        for s0 in range(0, T, self.B):
+            cnt = min(self.B, T - s0)
+            self._set_batch_images(dev_frames, s0, cnt, stream)
+            self.graph.run(stream, self.heavy_ops)
+            lib = self.lib
+            _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + s0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
+            _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + s0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')
+            _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + s0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
+            self.handover.src = ring.batch(cnt, 1)
+            self.handover.launch(lib, stream)
+
+    def scan(self, T, t0=0):
+        """Sequential phase: one launch over the T frames staged by `heavy`."""
+        self.chunk_scan.T = int(T)
+        self.chunk_scan.t0 = int(t0)
+        self.chunk_scan.launch(self.lib, self._stream())
+
+    def process(self, dev_frames, t0=0):
+        """heavy + scan; returns the device records tensor view [T,h,w,4] (torch)."""
+        T = dev_frames.shape[0]
+        self.heavy(dev_frames, T)
+        self.scan(T, t0)
+        return self.records(T)
+
+    def records(self, T):
+        buf = self.c_rec.root_storage.buf
+        return buf[:T * self.hw * 4].view(T, self.h, self.w, 4)
+
+    def debug(self, T):
+        out = {}
+        if self.c_temp is not None:
+            out['temp'] = self.c_temp.root_storage.buf[:T * self.hw * 4].view(T, self.h, self.w, 4).cpu().numpy()
+            out['nis'] = self.c_nis.root_storage.buf[:T * self.hw * 3].view(T, self.h, self.w, 3).cpu().numpy()
+        out['flow'] = self.c_flow.root_storage.buf[:T * self.hw * 2].view(T, self.h, self.w, 2).cpu().numpy()
+        out['sigma_trans'] = self.c_sigma.root_storage.buf[:T * self.hw].view(T, self.h, self.w, 1).cpu().numpy()
+        out['meas'] = self.c_meas.root_storage.buf[:T * self.hw * 4].view(T, self.h, self.w, 4).cpu().numpy()
+        return out
+
+    def get_state(self):
+        return self.state.root_storage.buf  # torch [hw*4] (x,y,z,sigma), the message rank->rank
+
+    def flops_per_frame(self):
+        return sum(op.flops() for op in self.heavy_ops if hasattr(op, 'flops')) / self.B

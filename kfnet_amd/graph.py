@@ -1,0 +1,460 @@
+"""Deferred op graph that stands in for the TF-1.x graph + session of the reference.
+
+The reference's `Network` layer methods add TF ops to a global graph that `sess.run`
+executes (cnn_wrapper/network.py:8-31, KFNet/eval.py:78-83).  Here the same layer
+methods append launch records for libkfnet_hip.so entry points to a `Graph`; `Graph.run`
+replays them on a HIP stream.  Tensors are NHWC fp32 device buffers with an explicit
+pixel stride so that `concat` is a re-binding of producer outputs, not a copy.
+
+PyTorch is used only as the device allocator / stream provider.  Shape inference and
+graph construction work without a GPU (device=None); running does not.
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_scope_stack = []
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    """tf.variable_scope analogue (KFNet/KFNet.py:304,316,374): prefixes variable names."""
+    _scope_stack.append(name)
+    try:
+        yield
+    finally:
+        _scope_stack.pop()
+
+
+def current_scope():
+    return '/'.join(_scope_stack)
+
+
+class _Shape(list):
+    def as_list(self):
+        return list(self)
+
+
+class Storage(object):
+    """A flat device buffer of `numel` elements of `dtype` ('f32' | 'u8')."""
+
+    def __init__(self, numel, dtype='f32'):
+        self.numel = int(numel)
+        self.dtype = dtype
+        self.buf = None  # torch tensor once allocated
+
+    def allocate(self, device):
+        import torch
+        if self.buf is None:
+            dt = torch.float32 if self.dtype == 'f32' else torch.uint8
+            self.buf = torch.zeros(self.numel, dtype=dt, device=device)
+        return self.buf
+
+    @property
+    def ptr(self):
+        if self.buf is None:
+            raise _lib.KfnError('graph buffers are not allocated: call Graph.finalize(device) '
+                                '(needs a GPU; kfnet_amd has no CPU execution path)')
+        return self.buf.data_ptr()
+
+
+class Tensor(object):
+    """NHWC tensor handle: a channel window [ch_off, ch_off+C) of a buffer whose pixel
+    stride is `ld` elements.  `base` makes this a view that follows its parent when the
+    parent is re-bound into a concat buffer."""
+
+    def __init__(self, graph, shape, dtype='f32', name=None, base=None, rel_off=0, rel_batch=0):
+        self.graph = graph
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = dtype
+        self.name = name
+        self.base = base
+        self.rel_off = rel_off      # channel offset inside the parent
+        self.rel_batch = rel_batch  # batch (outermost axis) offset inside the parent
+        self.external = False
+        if base is None:
+            n, h, w, c = self.shape
+            self.storage = Storage(n * h * w * c, dtype)
+            self._ld = c
+            self._off = 0
+            graph.storages.append(self.storage)
+
+    # -- TF-flavoured introspection ----------------------------------------------------
+    def get_shape(self):
+        return _Shape(self.shape)
+
+    @property
+    def pixels(self):
+        return self.shape[0] * self.shape[1] * self.shape[2]
+
+    @property
+    def C(self):
+        return self.shape[3]
+
+    @property
+    def ld(self):
+        return self.base.ld if self.base is not None else self._ld
+
+    @property
+    def ch_off(self):
+        return (self.base.ch_off + self.rel_off) if self.base is not None else self._off
+
+    @property
+    def root_storage(self):
+        return self.base.root_storage if self.base is not None else self.storage
+
+    @property
+    def elem_off(self):
+        """Element offset of this view's batch window from the start of the root buffer."""
+        if self.base is None:
+            return 0
+        _, h, w, _ = self.base.shape
+        return self.base.elem_off + self.rel_batch * h * w * self.base.ld
+
+    @property
+    def ptr(self):
+        esz = 4 if self.dtype == 'f32' else 1
+        return self.root_storage.ptr + (self.elem_off + self.ch_off) * esz
+
+    def is_whole(self):
+        return self.base is None and self._off == 0 and self._ld == self.shape[3]
+
+    def rebind(self, storage, ch_off, ld):
+        """Move this tensor's data into a window of a wider buffer (concat)."""
+        assert self.base is None
+        if self.storage in self.graph.storages:
+            self.graph.storages.remove(self.storage)
+        self.storage = storage
+        self._off = ch_off
+        self._ld = ld
+
+    def channels(self, start, count, name=None):
+        """tf.slice on the channel axis as a zero-copy view."""
+        n, h, w, c = self.shape
+        assert 0 <= start and start + count <= c
+        return Tensor(self.graph, (n, h, w, count), self.dtype, name, base=self, rel_off=start)
+
+    def batch(self, start, count, name=None):
+        """Zero-copy window [start, start+count) of the batch axis."""
+        n, h, w, c = self.shape
+        assert 0 <= start and start + count <= n
+        return Tensor(self.graph, (count, h, w, c), self.dtype, name, base=self, rel_batch=start)
+
+    # -- host <-> device ---------------------------------------------------------------
+    def numpy(self):
+        import torch
+        n, h, w, c = self.shape
+        buf = self.root_storage.buf
+        if buf is None:
+            raise _lib.KfnError('tensor %r is not allocated' % self.name)
+        torch.cuda.synchronize()
+        flat = buf.cpu().numpy()
+        off, ld = self.ch_off + self.elem_off, self.ld
+        idx = off + np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :]
+        return flat[idx].reshape(n, h, w, c)
+
+    def upload(self, arr):
+        import torch
+        n, h, w, c = self.shape
+        arr = np.ascontiguousarray(arr).reshape(n, h, w, c)
+        want = np.float32 if self.dtype == 'f32' else np.uint8
+        if arr.dtype != want:
+            raise TypeError('tensor %r wants %s, got %s' % (self.name, want, arr.dtype))
+        assert self.ld == c and self.ch_off == 0, 'upload needs a channel-dense tensor'
+        dst = self.root_storage.buf[self.elem_off:self.elem_off + arr.size]
+        dst.copy_(torch.from_numpy(arr.reshape(-1)), non_blocking=False)
+
+
+class Param(object):
+    """A weight variable: TF name + logical shape; `pack` turns the TF-layout ndarray
+    into the device layout the kernels read."""
+
+    def __init__(self, graph, name, shape, pack):
+        self.name = name
+        self.shape = tuple(shape)
+        self.pack = pack
+        self.storage = None
+        self.packed_shape = None
+        graph.params[name] = self
+
+    @property
+    def ptr(self):
+        if self.storage is None:
+            raise _lib.KfnError('weights not loaded: variable %s (call Graph.load_weights)' % self.name)
+        return self.storage.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------
+# ops
+# ---------------------------------------------------------------------------------------
+class Op(object):
+    name = '?'
+
+    def launch(self, lib, stream):
+        raise NotImplementedError
+
+
+def pack_conv_kernel(w):
+    """TF HWIO [kh,kw,Cin,Cout] -> [cout_pad][kh*kw*Cin] (K contiguous), zero rows pad."""
+    kh, kw, ci, co = w.shape
+    cp = -(-co // 32) * 32
+    out = np.zeros((cp, kh * kw * ci), dtype=np.float32)
+    out[:co] = np.transpose(w, (3, 0, 1, 2)).reshape(co, -1)
+    return out
+
+
+def pack_deconv_kernel(w):
+    """TF conv2d_transpose [kh,kw,Cout,Cin] -> [cout_pad][kh*kw*Cin]."""
+    kh, kw, co, ci = w.shape
+    cp = -(-co // 32) * 32
+    out = np.zeros((cp, kh * kw * ci), dtype=np.float32)
+    out[:co] = np.transpose(w, (2, 0, 1, 3)).reshape(co, -1)
+    return out
+
+
+def pack_dense_kernel(w):
+    """tf.layers.dense [in,out] == a 1x1 conv kernel [1,1,in,out]."""
+    return pack_conv_kernel(w.reshape(1, 1, w.shape[0], w.shape[1]))
+
+
+def pack_first_kernel(w):
+    """TF HWIO [3,3,3,C] -> [27][C] (kh,kw,ci major)."""
+    return np.ascontiguousarray(w.reshape(27, w.shape[3]).astype(np.float32))
+
+
+def pack_bias(b):
+    return np.ascontiguousarray(b.astype(np.float32))
+
+
+class ConvOp(Op):
+    def __init__(self, name, x, y, kernel, bias, kh, kw, stride, relu, transposed=False,
+                 epilogue=_lib.EPI_NONE, config=_lib.CFG_AUTO):
+        self.name = name
+        self.x, self.y, self.kernel, self.bias = x, y, kernel, bias
+        self.kh, self.kw, self.stride, self.relu = kh, kw, stride, relu
+        self.transposed = transposed
+        self.epilogue = epilogue
+        self.config = config
+        self._desc = None
+
+    def desc(self):
+        n, h, w, cin = self.x.shape
+        cout = self.y.shape[3]
+        d = _lib.ConvDesc(N=n, H=h, W=w, Cin=cin, ldx=self.x.ld, Cout=cout,
+                          cout_pad=-(-cout // 32) * 32, ldy=self.y.ld, kh=self.kh, kw=self.kw,
+                          stride=self.stride, transposed=int(self.transposed), relu=int(self.relu),
+                          epilogue=self.epilogue, config=self.config)
+        return d
+
+    def flops(self):
+        """Nominal dense FLOPs (zero-padding taps counted)."""
+        if self.transposed:
+            n, hi, wi, _ = self.x.shape
+            return 2.0 * n * hi * wi * self.y.shape[3] * self.kh * self.kw * self.x.shape[3]
+        n, ho, wo, cout = self.y.shape
+        return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
+
+    def launch(self, lib, stream):
+        d = self.desc()
+        rc = lib.kfn_conv2d_nhwc(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                 self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        _lib.check(rc, 'kfn_conv2d_nhwc[%s]' % self.name)
+
+
+class FirstConvOp(Op):
+    """uint8 image -> preprocess -> conv (Cin=3), up to two heads sharing one image read."""
+
+    def __init__(self, img):
+        self.name = 'first_conv'
+        self.img = img
+        self.heads = []  # (name, y, kernel, bias)
+
+    def add_head(self, name, y, kernel, bias):
+        assert len(self.heads) < 2
+        self.heads.append((name, y, kernel, bias))
+        self.name = 'first_conv[' + '+'.join(h[0] for h in self.heads) + ']'
+
+    def flops(self):
+        n, h, w, _ = self.img.shape
+        return sum(2.0 * n * h * w * 27 * hd[1].shape[3] for hd in self.heads)
+
+    def launch(self, lib, stream):
+        n, h, w, _ = self.img.shape
+        h1 = self.heads[0]
+        for hd in self.heads:
+            assert hd[1].is_whole(), 'first-layer outputs must be whole buffers'
+        if len(self.heads) == 2:
+            h2 = self.heads[1]
+            rc = lib.kfn_first_conv_u8(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3],
+                                       h2[2].ptr, h2[3].ptr, h2[1].ptr, h2[1].shape[3], stream)
+        else:
+            rc = lib.kfn_first_conv_u8(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3],
+                                       None, None, None, 0, stream)
+        _lib.check(rc, 'kfn_first_conv_u8')
+
+
+class CostVolumeOp(Op):
+    def __init__(self, f1, f2, vol, window):
+        self.name = 'cost_volume'
+        self.f1, self.f2, self.vol, self.window = f1, f2, vol, window
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.f2.shape
+        assert self.f1.ld == c and self.f2.ld == c
+        rc = lib.kfn_cost_volume(self.f1.ptr, self.f2.ptr, self.vol.ptr, n, h, w, c, self.window, stream)
+        _lib.check(rc, 'kfn_cost_volume')
+
+
+class FlowOp(Op):
+    def __init__(self, logits, flow, prob, window):
+        self.name = 'flow_softargmax'
+        self.logits, self.flow, self.prob, self.window = logits, flow, prob, window
+
+    def launch(self, lib, stream):
+        P = self.flow.pixels
+        rc = lib.kfn_flow_softargmax(self.logits.ptr, self.flow.ptr,
+                                     self.prob.ptr if self.prob is not None else None, P, self.window, stream)
+        _lib.check(rc, 'kfn_flow_softargmax')
+
+
+class CopyChannelsOp(Op):
+    def __init__(self, src, dst):
+        self.name = 'copy_channels'
+        self.src, self.dst = src, dst
+
+    def launch(self, lib, stream):
+        rc = lib.kfn_copy_channels(self.src.ptr, self.src.ld, self.dst.ptr, self.dst.ld, self.src.pixels,
+                                   self.src.C, stream)
+        _lib.check(rc, 'kfn_copy_channels')
+
+
+class MemcpyOp(Op):
+    """Device-to-device copy of a channel-dense tensor (feature ring hand-over)."""
+
+    def __init__(self, src, dst):
+        self.name = 'memcpy_d2d'
+        self.src, self.dst = src, dst
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.src.shape
+        assert self.src.ld == c and self.dst.ld == c and self.dst.shape == self.src.shape
+        rc = lib.kfn_memcpy_d2d(self.dst.ptr, self.src.ptr, n * h * w * c * 4, stream)
+        _lib.check(rc, 'kfn_memcpy_d2d')
+
+
+class KalmanScanOp(Op):
+    """S sequences x T frames of warp + Kalman fuse (+NIS, transform, emit)."""
+
+    def __init__(self, flow, sigma_t, meas, state, records, temp=None, nis=None, S=1, T=1, H=0, W=0,
+                 reset_period=500, min_uncertainty=1e-5, nis_gate=0.0, transform=None):
+        self.name = 'kalman_scan'
+        self.flow, self.sigma_t, self.meas, self.state = flow, sigma_t, meas, state
+        self.records, self.temp, self.nis = records, temp, nis
+        self.S, self.T, self.H, self.W = S, T, H, W
+        self.reset_period = reset_period
+        self.min_uncertainty = min_uncertainty
+        self.nis_gate = nis_gate
+        self.transform = transform
+        self.t0 = 0
+
+    def launch(self, lib, stream):
+        d = _lib.KalmanDesc(S=self.S, T=self.T, H=self.H, W=self.W, t0=int(self.t0),
+                            reset_period=int(self.reset_period), min_uncertainty=self.min_uncertainty,
+                            nis_gate=float(self.nis_gate), has_transform=int(self.transform is not None))
+        if self.transform is not None:
+            t = np.asarray(self.transform, dtype=np.float32)[:3, :4].reshape(-1)
+            for i in range(12):
+                d.transform[i] = float(t[i])
+        rc = lib.kfn_kalman_scan(C.byref(d), self.flow.ptr, self.sigma_t.ptr, self.meas.ptr, self.state.ptr,
+                                 self.records.ptr, self.temp.ptr if self.temp is not None else None,
+                                 self.nis.ptr if self.nis is not None else None, stream)
+        _lib.check(rc, 'kfn_kalman_scan')
+
+
+class KalmanFuseOp(Op):
+    """Stand-alone KFNet.BuildKFCoord (+ optional NIS) on packed [.,.,.,4] tensors."""
+
+    def __init__(self, pred, meas, out, nis=None):
+        self.name = 'kalman_fuse'
+        self.pred, self.meas, self.out, self.nis = pred, meas, out, nis
+
+    def launch(self, lib, stream):
+        for t in (self.pred, self.meas, self.out):
+            assert t.ld == 4 and t.C == 4
+        rc = lib.kfn_kalman_fuse(self.pred.ptr, self.meas.ptr, self.out.ptr,
+                                 self.nis.ptr if self.nis is not None else None, self.out.pixels, stream)
+        _lib.check(rc, 'kfn_kalman_fuse')
+
+
+# ---------------------------------------------------------------------------------------
+class Graph(object):
+    def __init__(self):
+        self.ops = []
+        self.storages = []
+        self.params = {}
+        self.first_conv = {}  # id(img tensor) -> FirstConvOp
+        self.device = None
+        self.debug_prob = False
+
+    # -- construction -------------------------------------------------------------------
+    def placeholder(self, shape, dtype='f32', name=None):
+        t = Tensor(self, shape, dtype, name)
+        t.external = True
+        return t
+
+    def tensor(self, shape, dtype='f32', name=None):
+        return Tensor(self, shape, dtype, name)
+
+    def add(self, op):
+        self.ops.append(op)
+        return op
+
+    def variable(self, name, shape, pack):
+        full = (current_scope() + '/' + name) if current_scope() else name
+        if full in self.params:  # tf.AUTO_REUSE
+            return self.params[full]
+        return Param(self, full, shape, pack)
+
+    # -- execution ----------------------------------------------------------------------
+    def finalize(self, device='cuda:0'):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.KfnError('no GPU visible: kfnet_amd executes only through libkfnet_hip.so on a '
+                                'gfx950 device (there is no CPU fallback)')
+        _lib.load()
+        self.device = torch.device(device)
+        for s in self.storages:
+            s.allocate(self.device)
+        return self
+
+    def load_weights(self, W, strict=True):
+        """RestoreFromScope analogue (KFNet/train.py:317-321): W is {tf_name: ndarray}."""
+        import torch
+        if self.device is None:
+            raise _lib.KfnError('call Graph.finalize(device) before load_weights')
+        for name, p in self.params.items():
+            if name not in W:
+                if strict:
+                    raise KeyError('weight %s missing from the container' % name)
+                continue
+            arr = np.asarray(W[name], dtype=np.float32)
+            if tuple(arr.shape) != p.shape:
+                raise ValueError('weight %s has shape %s, graph wants %s' % (name, arr.shape, p.shape))
+            packed = p.pack(arr)
+            p.packed_shape = packed.shape
+            p.storage = torch.from_numpy(np.ascontiguousarray(packed)).to(self.device)
+        return self
+
+    def run(self, stream=None, ops=None):
+        import torch
+        lib = _lib.load()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        for op in (ops if ops is not None else self.ops):
+            op.launch(lib, stream)
+
+    def total_flops(self):
+        return sum(op.flops() for op in self.ops if hasattr(op, 'flops'))

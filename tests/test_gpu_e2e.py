@@ -1,0 +1,100 @@
+"""-m gpu end-to-end parity: the full KFNet sequence engine (HIP) against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): max-abs <= 1e-4 on the scene-coordinate channels;
+the confidence channel 1/sigma is O(1..1e3), so its tolerance is RELATIVE 1e-4
+(SURVEY.md §7 'Tolerance on channel 3')."""
+import numpy as np
+import pytest
+
+from oracle import kfnet_oracle as O
+from oracle import kfnet_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+
+COORD_TOL = 1e-4
+CONF_RTOL = 1e-4
+
+
+def _check(rec, ref):
+    assert rec.shape == ref.shape
+    dc = np.abs(rec[..., 0:3] - ref[..., 0:3]).max()
+    dr = (np.abs(rec[..., 3] - ref[..., 3]) / np.abs(ref[..., 3])).max()
+    assert dc <= COORD_TOL, 'coord max-abs %g' % dc
+    assert dr <= CONF_RTOL, 'confidence max-rel %g' % dr
+    return dc, dr
+
+
+@pytest.mark.parametrize('batch', [1, 2, 4])
+def test_small_sequence_vs_fp64_oracle(batch):
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    imgs = synthetic_sequence(7, 64, 96, seed=1)
+    T4 = O.get_transform(synthetic_transform())
+    ref, dbg = O.eval_sequence(imgs, W, T4, reset_period=5, dtype=np.float64, return_debug=True)
+    eng = KFNetEngine(W, image_size=(64, 96), batch=batch, transform=T4, reset_period=5, max_chunk=16,
+                      emit_debug=True)
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    d = eng.debug(7)
+    # stage-level diagnostics first (clearer failures than the final record)
+    z = np.concatenate([np.concatenate([x['z'][0], x['sz'][0]], -1)[None] for x in dbg])
+    assert np.abs(d['meas'] - z).max() < 5e-5
+    for t in (1, 2, 3, 4, 6):
+        assert np.abs(d['flow'][t] - dbg[t]['flow'][0]).max() < 5e-5
+        assert np.abs(d['sigma_trans'][t].reshape(-1) - dbg[t]['sigma_trans'].reshape(-1)).max() < 1e-6
+    _check(rec, ref)
+
+
+def test_nis_gate_and_odd_grid():
+    """540x960-style odd intermediate sizes (SAME pad (1,1) on odd rows) at reduced scale:
+    68x120 image -> 34x60 -> 17x30 -> 9x15 grid; plus the --NIS output gate."""
+    from kfnet_amd.engine import KFNetEngine, grid_size
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    assert grid_size((540, 960)) == (68, 120) and grid_size((68, 120)) == (9, 15)
+    W = synthetic_weights(99)
+    imgs = synthetic_sequence(4, 68, 120, seed=5)
+    T4 = np.eye(4, dtype=np.float32)
+    ref = O.eval_sequence(imgs, W, T4, reset_period=500, nis_gate=True, dtype=np.float64)
+    eng = KFNetEngine(W, image_size=(68, 120), batch=2, transform=T4, reset_period=500, nis_gate=7.815,
+                      max_chunk=8)
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    _check(rec, ref)
+
+
+def test_full_size_vs_torch_oracle():
+    """BASELINE config: 480x640 frames -> 60x80x4 maps, 3 frames, against the fp32 torch
+    restatement (the fp64 numpy gold takes minutes at this size)."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    imgs = synthetic_sequence(3, 480, 640, seed=1)
+    T4 = O.get_transform(synthetic_transform())
+    ref = OT.eval_sequence(imgs, W, T4, reset_period=500)
+    eng = KFNetEngine(W, image_size=(480, 640), batch=2, transform=T4, reset_period=500, max_chunk=4)
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    assert rec.shape == (3, 60, 80, 4)
+    _check(rec, ref)
+
+
+def test_chunked_equals_single_pass():
+    """Processing a sequence as two chunks with state/feature hand-over (what two ranks do)
+    is bit-identical to one pass."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(7)
+    imgs = synthetic_sequence(8, 64, 96, seed=2)
+    eng = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=500, max_chunk=8)
+    dev = eng.upload_frames(imgs)
+    one = eng.process(dev).cpu().numpy().copy()
+    eng2 = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=500, max_chunk=8)
+    a = eng2.process(dev[:3], t0=0).cpu().numpy().copy()
+    state = eng2.get_state().clone()
+    eng3 = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=500, max_chunk=8)
+    eng3.prime(dev[2])
+    eng3.get_state().copy_(state)
+    b = eng3.process(dev[3:], t0=3).cpu().numpy().copy()
+    assert np.array_equal(np.concatenate([a, b]), one)

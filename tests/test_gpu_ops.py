@@ -1,0 +1,281 @@
+"""-m gpu parity tests: every C-ABI entry point of libkfnet_hip.so against the CPU oracle
+on identical seeded inputs.  fp32 tolerance: the conv kernels accumulate in fp32 in a
+different order than the fp64 oracle, so |err| <= 2e-5 * sum_k|a_k b_k| is the bound used
+(fp32 round-off class; measured errors are ~1e-6 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import kfnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_tol(x, w, transposed=False):
+    # crude per-tensor bound on sum|a*b|
+    k = w.shape[0] * w.shape[1] * (w.shape[3] if transposed else w.shape[2])
+    return 2e-5 * k * float(np.abs(x).max()) * float(np.abs(w).max()) / 8 + 1e-6
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, relu
+    (1, 8, 8, 32, 32, 3, 1, True),
+    (2, 13, 17, 16, 48, 3, 1, False),
+    (1, 12, 20, 64, 64, 3, 2, True),       # even size stride 2: pad (0,1)
+    (1, 15, 9, 32, 100, 3, 2, True),       # odd size stride 2: pad (1,1)
+    (3, 8, 8, 48, 16, 3, 1, True),         # OFlowNet conv6 shape class
+    (5, 8, 8, 16, 1, 3, 1, False),         # OFlowNet prediction: Cout = 1
+    (2, 6, 10, 256, 128, 1, 1, True),      # 1x1
+    (1, 20, 24, 128, 320, 3, 1, True),     # multiple N tiles
+    (7, 1, 1, 128, 128, 3, 1, True),       # 1x1 spatial: only the centre tap is live
+    (6, 2, 2, 64, 64, 3, 1, True),
+    (1, 60, 80, 64, 160, 3, 1, True),      # M = 4800 = 30 x 160
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5])
+def test_conv_vs_oracle(case, config):
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co, k, s, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
+    wt = (rng.normal(size=(k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, s, relu, config=config)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, s, relu)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= _conv_tol(x, wt)
+
+
+def test_conv_strided_views():
+    from tests.gpu_util import run_conv
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(2, 8, 8, 32)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, 32, 16)) / 17).astype(np.float32)
+    b = rng.normal(size=16).astype(np.float32)
+    y = run_conv(x, wt, b, 1, True, ldx=96, x_off=64, ldy=48, y_off=16)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    assert np.abs(y - ref).max() <= _conv_tol(x, wt)
+
+
+@pytest.mark.parametrize('shape', [(3, 1, 1, 128, 64), (2, 2, 2, 64, 32), (2, 4, 4, 32, 16), (1, 5, 7, 16, 40)])
+def test_deconv_vs_oracle(shape):
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, co, ci)) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, 2, True, transposed=True)
+    ref = O.conv2d_transpose_same(x.astype(np.float64), wt, b, 2, True)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= _conv_tol(x, wt, True)
+
+
+def test_conv_epilogues():
+    from tests.gpu_util import run_conv
+    from kfnet_amd import _lib
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(2, 6, 7, 128)).astype(np.float32)
+    w32 = (rng.normal(size=(3, 3, 128, 32)) / 34).astype(np.float32)
+    b32 = rng.normal(size=32).astype(np.float32)
+    y = run_conv(x, w32, b32, 1, False, epilogue=_lib.EPI_L2NORM)
+    ref = O.l2_normalize(O.conv2d_same(x.astype(np.float64), w32, b32, 1, False))
+    assert np.abs(y - ref).max() < 2e-6
+    w4 = (rng.normal(size=(1, 1, 128, 4)) / 11).astype(np.float32)
+    b4 = rng.normal(size=4).astype(np.float32)
+    y = run_conv(x, w4, b4, 1, False, epilogue=_lib.EPI_EXP_CH3)
+    ref = O.conv2d_same(x.astype(np.float64), w4, b4, 1, False)
+    ref[..., 3] = np.exp(ref[..., 3])
+    assert np.abs(y - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    w1 = (rng.normal(size=(1, 1, 128, 1)) / 11).astype(np.float32)
+    y = run_conv(x, w1, None, 1, False, epilogue=_lib.EPI_EXP_1E2)
+    ref = np.exp(O.conv2d_same(x.astype(np.float64), w1, None, 1, False)) * 1e-2
+    assert np.abs(y - ref).max() < 1e-6
+
+
+def test_conv_bad_args_fail_loudly():
+    from tests.gpu_util import dev, stream
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    x = dev(np.zeros((1, 4, 4, 8), np.float32))
+    d = _lib.ConvDesc(N=1, H=4, W=4, Cin=8, ldx=8, Cout=8, cout_pad=32, ldy=8, kh=3, kw=3, stride=1)
+    rc = lib.kfn_conv2d_nhwc(C.byref(d), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), stream())
+    assert rc == -1 and b'Cin' in lib.kfn_last_error()
+
+
+@pytest.mark.parametrize('hw', [(8, 64), (9, 70), (48, 96)])
+def test_first_conv_u8(hw):
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    H, W = hw
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    w1 = (rng.normal(size=(3, 3, 3, 64)) / 5).astype(np.float32)
+    b1 = rng.normal(size=64).astype(np.float32)
+    w2 = (rng.normal(size=(3, 3, 3, 16)) / 5).astype(np.float32)
+    b2 = rng.normal(size=16).astype(np.float32)
+    y1 = torch.zeros(2 * H * W * 64, device='cuda')
+    y2 = torch.zeros(2 * H * W * 16, device='cuda')
+    di, dw1, db1, dw2, db2 = dev(img), dev(w1.reshape(27, 64)), dev(b1), dev(w2.reshape(27, 16)), dev(b2)
+    _lib.check(lib.kfn_first_conv_u8(di.data_ptr(), 2, H, W, dw1.data_ptr(), db1.data_ptr(), y1.data_ptr(), 64,
+                                     dw2.data_ptr(), db2.data_ptr(), y2.data_ptr(), 16, stream()), 'first')
+    sync()
+    xp = O.preprocess(img, np.float64)
+    r1 = O.conv2d_same(xp, w1, b1, 1, True)
+    r2 = O.conv2d_same(xp, w2, b2, 1, True)
+    assert np.abs(y1.cpu().numpy().reshape(r1.shape) - r1).max() < 2e-5
+    assert np.abs(y2.cpu().numpy().reshape(r2.shape) - r2).max() < 2e-5
+
+
+def test_cost_volume_bit_exact():
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    N, H, W, Cc = 3, 7, 9, 32
+    f = rng.normal(size=(N + 1, H, W, Cc)).astype(np.float32)
+    fd = dev(f)
+    vol = torch.zeros(N * H * W * 64 * Cc, device='cuda')
+    _lib.check(lib.kfn_cost_volume(fd.data_ptr(), fd.data_ptr() + H * W * Cc * 4, vol.data_ptr(), N, H, W, Cc, 8,
+                                   stream()), 'cv')
+    sync()
+    got = vol.cpu().numpy().reshape(N, H * W, 8, 8, Cc)
+    for n in range(N):
+        ref, _ = O.coord_volume(f[n:n + 1], f[n + 1:n + 2], 8)
+        assert np.array_equal(got[n], ref)   # subtraction only: bit exact
+
+
+def test_flow_softargmax():
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    P = 1003
+    logits = (rng.normal(size=(P, 64)) * 4).astype(np.float32)
+    flow = torch.zeros(P * 2, device='cuda')
+    prob = torch.zeros(P * 64, device='cuda')
+    dl = dev(logits)
+    _lib.check(lib.kfn_flow_softargmax(dl.data_ptr(), flow.data_ptr(), prob.data_ptr(), P, 8, stream()), 'flow')
+    sync()
+    pr = O.softmax(logits.astype(np.float64))
+    offs = O.coord_volume(np.zeros((1, 2, 2, 1)), np.zeros((1, 2, 2, 1)), 8)[1]
+    assert np.abs(prob.cpu().numpy().reshape(P, 64) - pr).max() < 1e-6
+    assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 5e-6
+    # uniform logits -> (-0.5, -0.5) exactly
+    dl = dev(np.zeros((4, 64), np.float32))
+    _lib.check(lib.kfn_flow_softargmax(dl.data_ptr(), flow.data_ptr(), None, 4, 8, stream()), 'flow')
+    sync()
+    assert np.all(flow.cpu().numpy()[:8] == -0.5)
+
+
+def _scan_ref(flow, sig, meas, state0, T4, t0, reset_period, nis_gate):
+    """fp32 numpy oracle of the scan, frame by frame."""
+    S, T, H, W, _ = flow.shape
+    offs = None
+    rec = np.zeros((S, T, H, W, 4), np.float32)
+    temp = np.zeros((S, T, H, W, 4), np.float32)
+    nis = np.zeros((S, T, H, W, 3), np.float32)
+    state = state0.copy()
+    for s in range(S):
+        sx, ss = state[s:s + 1, ..., 0:3], state[s:s + 1, ..., 3:4]
+        for t in range(T):
+            z, sz = meas[s, t][None, ..., 0:3], meas[s, t][None, ..., 3:4]
+            if reset_period > 0 and (t0 + t) % reset_period == 0:
+                ox, os_ = z, sz
+                sx, ss = z, sz
+                temp[s, t] = meas[s, t]
+            else:
+                pm = O.get_pixel_map(H, W, np.float32) + flow[s, t][None]
+                tx = O.bilinear_sampler(sx, pm)
+                lu = O.bilinear_sampler(ss, pm)
+                eps2 = np.float32(1e-5) * np.float32(1e-5)
+                ts = np.sqrt(np.maximum(sig[s, t][None] ** 2, eps2) + np.maximum(lu * lu, eps2))
+                kx, ks = O.build_kf_coord(tx, ts, z, sz)
+                nn = O.get_nis(z, sz, tx, ts)
+                ox, os_ = kx, ks
+                if nis_gate > 0:
+                    m = ((nn[..., 0:1] + nn[..., 1:2]) + nn[..., 2:3]) > nis_gate
+                    ox = np.where(m, z, kx)
+                sx, ss = kx, ks
+                temp[s, t] = np.concatenate([tx[0], ts[0]], -1)
+                nis[s, t] = nn[0]
+            if T4 is not None:
+                ox = O.apply_transform(ox, T4)
+            rec[s, t] = np.concatenate([ox[0], 1.0 / os_[0]], -1)
+        state[s] = np.concatenate([sx[0], ss[0]], -1)
+    return rec, temp, nis, state
+
+
+@pytest.mark.parametrize('cfg', [(1, 3, 60, 80, 0, 500, 0.0, True), (3, 5, 17, 23, 498, 500, 7.815, True),
+                                 (2, 4, 68, 120, 1, 0, 0.0, False)])
+def test_kalman_scan_vs_oracle(cfg):
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.synth import synthetic_transform
+    import torch
+    lib = _lib.load()
+    S, T, H, W, t0, rp, gate, use_T = cfg
+    rng = np.random.default_rng(S * 100 + T)
+    flow = (rng.normal(size=(S, T, H, W, 2)) * 2.0).astype(np.float32)
+    flow[:, :, 0, :, :] = -3.0  # push a row out of range
+    sig = np.abs(rng.normal(size=(S, T, H, W, 1)) * 0.05).astype(np.float32)
+    meas = rng.normal(size=(S, T, H, W, 4)).astype(np.float32)
+    meas[..., 3] = np.abs(meas[..., 3]) * 0.3 + 0.05
+    state0 = rng.normal(size=(S, H, W, 4)).astype(np.float32)
+    state0[..., 3] = np.abs(state0[..., 3]) * 0.3 + 0.05
+    T4 = O.get_transform(synthetic_transform()) if use_T else None
+    d = _lib.KalmanDesc(S=S, T=T, H=H, W=W, t0=t0, reset_period=rp, min_uncertainty=1e-5, nis_gate=gate,
+                        has_transform=int(use_T))
+    if use_T:
+        for i, v in enumerate(T4[:3].reshape(-1)):
+            d.transform[i] = float(v)
+    dfl, dsg, dme, dst = dev(flow), dev(sig), dev(meas), dev(state0)
+    rec = torch.zeros(S * T * H * W * 4, device='cuda')
+    tmp = torch.zeros(S * T * H * W * 4, device='cuda')
+    nis = torch.zeros(S * T * H * W * 3, device='cuda')
+    _lib.check(lib.kfn_kalman_scan(C.byref(d), dfl.data_ptr(), dsg.data_ptr(), dme.data_ptr(), dst.data_ptr(),
+                                   rec.data_ptr(), tmp.data_ptr(), nis.data_ptr(), stream()), 'scan')
+    sync()
+    r_rec, r_tmp, r_nis, r_state = _scan_ref(flow, sig, meas, state0, T4, t0, rp, gate)
+    g_rec = rec.cpu().numpy().reshape(r_rec.shape)
+    g_state = dst.cpu().numpy().reshape(r_state.shape)
+    # elementwise fp32 with the same op order: a few ulps (transform matmul order aside)
+    assert np.allclose(tmp.cpu().numpy().reshape(r_tmp.shape), r_tmp, rtol=2e-6, atol=2e-6)
+    assert np.allclose(g_state, r_state, rtol=4e-6, atol=4e-6)
+    assert np.allclose(g_rec[..., 0:3], r_rec[..., 0:3], rtol=1e-5, atol=1e-5)
+    assert np.allclose(g_rec[..., 3], r_rec[..., 3], rtol=1e-5)
+    if gate == 0.0:
+        assert np.allclose(nis.cpu().numpy().reshape(r_nis.shape), r_nis, rtol=1e-4, atol=1e-6)
+
+
+def test_kalman_fuse_kat():
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    P = 5000
+    pred = rng.normal(size=(P, 4)).astype(np.float32); pred[:, 3] = np.abs(pred[:, 3]) + 0.01
+    meas = rng.normal(size=(P, 4)).astype(np.float32); meas[:, 3] = np.abs(meas[:, 3]) + 0.01
+    meas[0, 3] = pred[0, 3]  # equal-noise KAT: K = 1/2
+    out = torch.zeros(P * 4, device='cuda'); nis = torch.zeros(P * 3, device='cuda')
+    dp, dm = dev(pred), dev(meas)
+    _lib.check(lib.kfn_kalman_fuse(dp.data_ptr(), dm.data_ptr(), out.data_ptr(), nis.data_ptr(), P, stream()), 'fuse')
+    sync()
+    o = out.cpu().numpy().reshape(P, 4)
+    kx, ks = O.build_kf_coord(pred[:, 0:3], pred[:, 3:4], meas[:, 0:3], meas[:, 3:4])
+    assert np.array_equal(o[:, 0:3], kx) and np.array_equal(o[:, 3:4], ks)   # bit exact vs fp32 numpy
+    assert np.allclose(o[0, 0:3], (pred[0, 0:3] + meas[0, 0:3]) / 2, rtol=1e-6)
+    assert np.isclose(o[0, 3], pred[0, 3] / np.sqrt(2), rtol=1e-6)
+    # property: min(s)/sqrt2 <= s_kf <= min(s)
+    mn = np.minimum(pred[:, 3], meas[:, 3])
+    assert np.all(o[:, 3] <= mn * (1 + 1e-6)) and np.all(o[:, 3] >= mn / np.sqrt(2) * (1 - 1e-6))
+    rn = O.get_nis(meas[:, 0:3], meas[:, 3:4], pred[:, 0:3], pred[:, 3:4])
+    assert np.allclose(nis.cpu().numpy().reshape(P, 3), rn, rtol=1e-6)
