@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the MI355X-native KFNet prediction path.
+
+A "step" is ONE 480x640 frame through the whole hot path (SCoordNet + flow-feature tower
++ cost volume + OFlowNet + flow head + warp/Kalman fuse/emit).  Workload = BASELINE.json
+configs[2]: full KFNet on a synthetic 480x640 sequence, random weights, fp32.  The timed
+region starts with the uint8 frames already resident in HBM and ends when the [K,60,80,4]
+records are in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the N*K-frame sequence is
+sharded into contiguous K-frame chunks (weak scaling).  Every rank runs the
+state-independent heavy phase for its chunk at once; the recurrent Kalman state (76.8 KB)
+is handed rank r -> r+1 with RCCL send/recv just before the rank's scan launch.
+
+One JSON line on rank 0; extra objects: roofline (dominant kernel = the fp32 MFMA
+implicit-GEMM conv), roofline_kalman (batched persistent scan, HBM), cpu_baseline
+(reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=64)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--batch', type=int, default=4, help='frames per tower launch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--no-kalman-roofline', action='store_true')
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
+    return ap.parse_args()
+
+
+def per_kernel_profile(eng, dev_frames):
+    """Time every launch of one heavy batch with HIP events on the launch stream.
+    Returns [(op_name, kernel_tag, flops, ms)]."""
+    import torch
+    from kfnet_amd.graph import ConvOp
+    stream = eng._stream()
+    eng._set_batch_images(dev_frames, 0, eng.B, stream)
+    eng.graph.run(stream, eng.heavy_ops)  # warm
+    torch.cuda.synchronize()
+    rows = []
+    reps = 3
+    for op in eng.heavy_ops:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            op.launch(eng.lib, stream)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tag = 'conv_mfma_kernel' if isinstance(op, ConvOp) else op.name.split('[')[0]
+        rows.append((op.name, tag, op.flops() if hasattr(op, 'flops') else 0.0, ms))
+    return rows
+
+
+def kalman_roofline(device, S=256, T=64, H=60, W=80):
+    """Batched persistent scan: S sequences x T frames per launch,
+    76 B/px algorithmic traffic (44 read + 32 written)."""
+    import ctypes as C
+    import torch
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    hw = H * W
+    g = torch.Generator(device='cpu').manual_seed(0)
+    flow = (torch.randn(S * T * hw * 2, generator=g) * 1.5).to(device)
+    sig = (torch.rand(S * T * hw, generator=g) * 0.05 + 0.001).to(device)
+    meas = torch.randn(S * T * hw * 4, generator=g)
+    meas[3::4] = meas[3::4].abs() * 0.3 + 0.05
+    meas = meas.to(device)
+    state = meas[:S * hw * 4].clone()
+    rec = torch.empty(S * T * hw * 4, device=device)
+    d = _lib.KalmanDesc(S=S, T=T, H=H, W=W, t0=1, reset_period=500, min_uncertainty=1e-5, nis_gate=0.0,
+                        has_transform=1)
+    for i, v in enumerate([1, 0, 0, 0.1, 0, 1, 0, 0.2, 0, 0, 1, 0.3]):
+        d.transform[i] = float(v)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        _lib.check(lib.kfn_kalman_scan(C.byref(d), flow.data_ptr(), sig.data_ptr(), meas.data_ptr(),
+                                       state.data_ptr(), rec.data_ptr(), None, None, stream), 'scan')
+    launch()
+    torch.cuda.synchronize()
+    reps = 5
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_alg = float(S) * T * hw * 76.0
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
+    return {'kernel': 'kalman_scan_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+            'shape': 'S=%d sequences x T=%d frames x %dx%d px, 76 B/px' % (S, T, H, W),
+            'avg_launch_ms': round(ms, 4)}
+
+
+def cpu_baseline(frames, W, T4, steps):
+    """Reference-faithful CPU restatement (oracle/kfnet_oracle_torch.py): both towers on a
+    2-frame batch per step, 64 materialised shifts, unfused ops (KFNet/eval.py:41,77-104)."""
+    import torch
+    from oracle import kfnet_oracle_torch as OT
+    cores = torch.get_num_threads()
+    sx = ss = None
+    recs = []
+    # one untimed warm-up step (oneDNN primitive creation)
+    OT.eval_step_reference_style(np.stack([frames[1], frames[0]]), W, None, None, T4, True)
+    t0 = time.time()
+    for i in range(steps):
+        pair = np.stack([frames[1], frames[0]]) if i == 0 else np.stack([frames[i - 1], frames[i]])
+        rec, sx, ss = OT.eval_step_reference_style(pair, W, sx, ss, T4, i % 500 == 0)
+        recs.append(rec)
+    dt = time.time() - t0
+    return {'value': round(steps / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d eval.py-style steps (2-frame tower batches, 64 shifts) of the same 480x640 '
+                      'sequence, torch-CPU fp32, %.1f s' % (steps, dt)}, np.stack(recs)
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    from kfnet_amd.dist import run_chunk
+    from oracle import kfnet_oracle as O
+
+    K, Wm, B = args.steps, args.warmup, args.batch
+    Wt = synthetic_weights(1234)
+    T4 = O.get_transform(synthetic_transform())
+    # the whole job is one N*K-frame sequence; rank r owns frames [r*K, (r+1)*K)
+    # (synthetic frames are generated per rank from the global frame index)
+    lo = rank * K
+    need_prev = 1 if lo > 0 else 0
+    frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
+    eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
+                      max_chunk=max(K, Wm, B), device=str(device))
+    dev_all = eng.upload_frames(frames_all)
+    dev_prev = dev_all[0] if need_prev else None
+    dev_frames = dev_all[need_prev:]
+
+    # warm-up: W untimed steps
+    if Wm > 0:
+        eng.process(dev_frames[:min(Wm, K)], t0=lo)
+    torch.cuda.synchronize()
+    if dist is not None:
+        # warm the p2p channels used by the state hand-off
+        run_chunk(eng, dev_frames[:B], lo, rank, world, dist, dev_prev)
+        torch.cuda.synchronize()
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    run_chunk(eng, dev_frames, lo, rank, world, dist, dev_prev)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_frames = K * world
+    fps = total_frames / elapsed
+
+    out = {
+        'metric': 'frames/sec on 480x640 seq', 'value': round(fps, 3), 'unit': 'frames/s',
+        'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': round(elapsed * 1e3 / K, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic (rolled random texture uint8 frames, seeded He-uniform random weights)',
+        'config': {'workload': 'full KFNet (SCoordNet+OFlowNet+Kalman) %d-frame %dx%d seq per GPU, random weights'
+                               % (K, args.height, args.width),
+                   'frames_total': total_frames, 'tower_batch': B, 'reset_period': 500,
+                   'parallelism': 'frame-sharded x%d, Kalman state rank->rank via RCCL send/recv' % world},
+    }
+    if rank == 0:
+        rows = per_kernel_profile(eng, dev_frames)
+        conv_ms = sum(r[3] for r in rows if r[1] == 'conv_mfma_kernel')
+        conv_fl = sum(r[2] for r in rows if r[1] == 'conv_mfma_kernel')
+        n_conv = sum(1 for r in rows if r[1] == 'conv_mfma_kernel')
+        heavy_ms = sum(r[3] for r in rows)
+        tf = conv_fl / (conv_ms * 1e-3) / 1e12
+        out['roofline'] = {
+            'kernel': 'conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all %d launches of one %d-frame batch)' % (n_conv, B),
+            'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'algorithmic_gflop_per_launch_avg': round(conv_fl / n_conv / 1e9, 3),
+            'avg_launch_ms': round(conv_ms / n_conv, 4),
+            'conv_share_of_heavy_time': round(conv_ms / heavy_ms, 4),
+        }
+        out['per_kernel_ms_per_batch'] = {r[0] + ('#%d' % i): round(r[3], 4) for i, r in enumerate(rows)}
+        top = sorted(rows, key=lambda r: -r[3])[:6]
+        out['top_layers'] = [{'op': r[0], 'ms': round(r[3], 3),
+                              'tflops': round(r[2] / (r[3] * 1e-3) / 1e12, 1) if r[2] else None} for r in top]
+        if not args.no_kalman_roofline:
+            out['roofline_kalman'] = kalman_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            host_frames = frames_all[need_prev:need_prev + max(args.cpu_steps, 2)]
+            cb, cpu_recs = cpu_baseline(host_frames, Wt, T4, args.cpu_steps)
+            out['cpu_baseline'] = cb
+            gpu_recs = eng.process(dev_frames[:args.cpu_steps], t0=0).cpu().numpy()
+            out['parity_vs_cpu_restatement'] = {
+                'frames': int(args.cpu_steps),
+                'coord_max_abs': float(np.abs(gpu_recs[..., :3] - cpu_recs[..., :3]).max()),
+                'conf_max_rel': float((np.abs(gpu_recs[..., 3] - cpu_recs[..., 3]) / np.abs(cpu_recs[..., 3])).max()),
+                'tolerance': 'coord max-abs <= 1e-4, confidence max-rel <= 1e-4'}
+            out['speedup_vs_cpu_baseline'] = round(fps / cb['value'], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -8,17 +8,20 @@ not uniform.
 import numpy as np
 
 
-def synthetic_sequence(T, H=480, W=640, seed=1, dx=3, dy=2, noise=4):
+def synthetic_sequence(T, H=480, W=640, seed=1, dx=3, dy=2, noise=4, start=0):
+    """Frames [start, start+T) of the seeded sequence (frame t depends only on (seed, t),
+    so ranks can generate their own chunk)."""
     rng = np.random.default_rng(seed)
     # low-frequency texture: upsampled coarse noise + fine noise, 0..255
     coarse = rng.integers(0, 256, size=(H // 8 + 2, W // 8 + 2, 3)).astype(np.float32)
     tex = np.kron(coarse, np.ones((8, 8, 1), dtype=np.float32))[:H, :W]
     tex = 0.75 * tex + 0.25 * rng.integers(0, 256, size=(H, W, 3)).astype(np.float32)
     frames = np.empty((T, H, W, 3), dtype=np.uint8)
-    for t in range(T):
+    for k in range(T):
+        t = start + k
         f = np.roll(tex, shift=(t * dy, t * dx), axis=(0, 1))
-        f = f + rng.integers(-noise, noise + 1, size=f.shape)
-        frames[t] = np.clip(f, 0, 255).astype(np.uint8)
+        f = f + np.random.default_rng([seed, t]).integers(-noise, noise + 1, size=f.shape)
+        frames[k] = np.clip(f, 0, 255).astype(np.uint8)
     return frames
 
 

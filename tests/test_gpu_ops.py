@@ -274,8 +274,11 @@ def test_kalman_fuse_kat():
     assert np.array_equal(o[:, 0:3], kx) and np.array_equal(o[:, 3:4], ks)   # bit exact vs fp32 numpy
     assert np.allclose(o[0, 0:3], (pred[0, 0:3] + meas[0, 0:3]) / 2, rtol=1e-6)
     assert np.isclose(o[0, 3], pred[0, 3] / np.sqrt(2), rtol=1e-6)
-    # property: min(s)/sqrt2 <= s_kf <= min(s)
+    # property: min(s)/sqrt2 <= s_kf <= min(s).  The reference forms P = max(1-K,0)*P^- with
+    # K rounded to fp32, so 1-K cancels catastrophically when sigma_z << sigma^-; the property
+    # only holds to ~eps/(1-K) and is checked where 1-K is not tiny.
     mn = np.minimum(pred[:, 3], meas[:, 3])
-    assert np.all(o[:, 3] <= mn * (1 + 1e-6)) and np.all(o[:, 3] >= mn / np.sqrt(2) * (1 - 1e-6))
+    ok = (meas[:, 3] > 0.1 * pred[:, 3])
+    assert np.all(o[ok, 3] <= mn[ok] * (1 + 1e-4)) and np.all(o[ok, 3] >= mn[ok] / np.sqrt(2) * (1 - 1e-4))
     rn = O.get_nis(meas[:, 0:3], meas[:, 3:4], pred[:, 0:3], pred[:, 3:4])
     assert np.allclose(nis.cpu().numpy().reshape(P, 3), rn, rtol=1e-6)
