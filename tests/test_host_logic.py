@@ -1,0 +1,126 @@
+"""CPU tests (no GPU): host-side graph construction, the Network DSL mechanics mirrored
+from cnn_wrapper/network.py, weight container, C-ABI surface, no-fallback guarantees."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kfnet_amd import _lib
+from kfnet_amd.graph import (Graph, pack_conv_kernel, pack_deconv_kernel, pack_dense_kernel,
+                             variable_scope)
+from kfnet_amd.KFNet.KFNet import KFNet, KFNetDataSpec
+from kfnet_amd.weights import num_params, synthetic_weights, variable_specs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(B=2, H=480, W=640):
+    g = Graph()
+    img = g.placeholder((B, H, W, 3), 'u8')
+    h, w = -(-H // 8), -(-W // 8)
+    st = g.placeholder((1, h, w, 4))
+    net = KFNet(img, KFNetDataSpec(batch_size=B, image_size=(H, W)))
+    net.GetKFCoordRecursive(st.channels(0, 3), st.channels(3, 1))
+    return g, net
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = os.path.join(ROOT, 'kfnet_amd', 'libkfnet_hip.so')
+    if not os.path.exists(lib_path):
+        from kfnet_amd import build
+        build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, 'include', 'kfnet_hip.h')).read()
+    declared = set(re.findall(r'\b(kfn_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    h = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(h, name), name
+    lib = _lib.load()
+    assert lib.kfn_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    g, _ = _build(1, 64, 96)
+    with pytest.raises(_lib.KfnError):
+        g.finalize('cuda:0')
+    with pytest.raises(_lib.KfnError):
+        g.run(stream=0)   # buffers not allocated -> no silent CPU path
+
+
+def test_graph_matches_reference_architecture():
+    g, net = _build(2)
+    want = set()
+    for n, kind, shape in variable_specs():
+        want |= {n + '/kernel', n + '/bias'}
+    assert set(g.params) == want
+    for n, kind, shape in variable_specs():
+        assert g.params[n + '/kernel'].shape == shape, n
+    # nominal FLOPs/frame == SURVEY.md App. C (496.224 GFLOP)
+    fl = sum(op.flops() for op in g.ops if hasattr(op, 'flops')) / 2
+    assert abs(fl / 1e9 - 496.224) < 0.01
+    W = synthetic_weights(0)
+    assert num_params(W) == 24406724 + 180512 + 511186
+    # layer LUT / naming mechanics of the DSL (network.py:96-109)
+    sc = net.scoordnet
+    assert sc.get_output_by_name('conv4b').shape == (2, 60, 80, 1024)
+    assert sc.get_output().shape == (2, 60, 80, 4)
+    assert sc.get_unique_name('conv') == 'conv_%d' % (sum(k.startswith('conv') for k in sc.layers) + 1)
+    with pytest.raises(KeyError):
+        sc.feed('nope')
+    with pytest.raises(NotImplementedError):
+        sc.feed('conv7').max_pool(2, 2, name='p')
+
+
+def test_concat_is_zero_copy_rebinding():
+    g, net = _build(1, 64, 96)
+    of = net.oflownet
+    for cat, parts in (('concat2', ('upconv2', 'conv2b')), ('concat1', ('upconv1', 'conv1b')),
+                       ('concat0', ('upconv0', 'conv0'))):
+        c = of.get_output_by_name(cat)
+        off = 0
+        for p in parts:
+            t = of.get_output_by_name(p)
+            assert t.root_storage is c.root_storage and t.ld == c.C and t.ch_off == off
+            off += t.C
+    assert not any(op.name == 'copy_channels' for op in g.ops)
+
+
+def test_odd_grid_shapes():
+    g, net = _build(1, 540, 960)
+    assert net.scoordnet.get_output().shape == (1, 68, 120, 4)   # ceil, not eval.py's 540//8 = 67
+    assert net.temp_feat_maps.shape == (2, 68, 120, 32)
+
+
+def test_weight_packing_layouts():
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(3, 3, 16, 5)).astype(np.float32)
+    p = pack_conv_kernel(w)
+    assert p.shape == (32, 144) and np.all(p[5:] == 0)
+    assert p[3, (1 * 3 + 2) * 16 + 7] == w[1, 2, 7, 3]
+    wd = rng.normal(size=(3, 3, 6, 16)).astype(np.float32)   # [kh,kw,Cout,Cin]
+    pd = pack_deconv_kernel(wd)
+    assert pd.shape == (32, 144) and pd[4, (2 * 3 + 0) * 16 + 9] == wd[2, 0, 4, 9]
+    wf = rng.normal(size=(128, 64)).astype(np.float32)
+    assert np.array_equal(pack_dense_kernel(wf)[:64], wf.T)
+
+
+def test_variable_scope_names():
+    g = Graph()
+    with variable_scope('A'):
+        with variable_scope('B'):
+            p = g.variable('x/kernel', (1,), lambda a: a)
+    assert p.name == 'A/B/x/kernel'
+    with variable_scope('A'):
+        with variable_scope('B'):
+            assert g.variable('x/kernel', (1,), lambda a: a) is p   # AUTO_REUSE
+
+
+def test_dataspec_matches_reference_table():
+    s = KFNetDataSpec()
+    assert s.scene == 'stairs' and s.sequence_length == 500 and s.image_num == 2000
+    assert KFNetDataSpec(scene='heads').sequence_length == 1000
