@@ -99,6 +99,10 @@ int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_pa
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);
 /* Output spatial size for a descriptor (TF SAME rule); host-side shape inference. */
 int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
+/* Which kernel instantiation kfn_conv2d_nhwc will launch for `desc`: tile config
+ * (KFN_CFG_*), k-step (16|32) and workgroup count.  Used by bench.py to attribute
+ * measured launch times to kernel names. */
+int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles);
 
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
  * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature

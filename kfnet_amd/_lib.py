@@ -52,6 +52,7 @@ SYMBOLS = {
     'kfn_event_elapsed_ms': (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     'kfn_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_conv2d_out_shape': (_i, [C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i)]),
+    'kfn_conv2d_plan': (_i, [C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),

@@ -5,19 +5,27 @@
 // K = taps*Cin.  Both operands are staged through LDS "K-contiguous":
 //   A tile [BM][BK]  = im2col rows gathered on the fly from the NHWC activations
 //   B tile [BN][BK]  = rows of the pre-packed weight matrix w_packed[Cout][K]
-// with a 4-float row pad so that the ds_read_b128 fragment reads (lane (i,h) reads
-// row i, floats [8c+4h, 8c+4h+4)) are bank-conflict free (row stride 36 or 20 dwords:
-// 9 resp. 5 are odd, so 16 rows that are distinct mod 16 cover all 64 banks).
+// LDS rows are unpadded; the 16-byte quad q of row r is stored at quad q ^ sw(r)
+// (sw(r) = (r>>1)&7 for BK=32, (r>>2)&3 for BK=16), which makes both the ds_write_b128
+// staging stores and the ds_read_b128 fragment reads (lane (i,h) reads row i, floats
+// [8c+4h, 8c+4h+4)) bank-conflict free, and keeps a 160x128x32 double-buffered tile at
+// 72 KiB so TWO workgroups (2 waves per SIMD) fit in the 160 KiB LDS of a CU: one
+// wave's staging/barrier gaps are filled by the other wave's MFMAs.
 // Each 8-wide k-chunk feeds four 32x32x2 MFMAs per (mi,ni) tile: MFMA step t takes
 // k = 8c + 4h + t from lane half h -- A and B use the same assignment, so the k
-// permutation is harmless.  Global loads for stage s+1 are issued before the MFMAs of
-// stage s (register-staged double buffer, one barrier per stage).
+// permutation is harmless.  Global loads are raw buffer loads (hardware range check
+// gives the zero padding for free: invalid taps use an out-of-range offset); loads of
+// stage s+1 are issued before the MFMAs of stage s (register-staged double buffer, one
+// barrier per stage).
 #include "kfn_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0x80000000u;  // voffset that always fails the buffer range check
 
 struct ConvArgs {
   const float* x;
@@ -27,9 +35,10 @@ struct ConvArgs {
   int N, H, W, Cin, ldx;
   int Ho, Wo, Cout, cout_pad, ldy;
   int kh, kw, stride, pad_t, pad_l;
-  int transposed, relu, epilogue;
+  int relu, epilogue;
   int M, Ktot;
   int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -41,22 +50,31 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
-template <int TM, int TN, int WM, int WN, int BK>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs p) {
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+template <int BK>
+__device__ __forceinline__ int swz(int r) {
+  return BK == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3);
+}
+
+template <int TM, int TN, int WM, int WN, int BK, bool TRANSPOSED>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int NT = 64 * WM * WN;
-  constexpr int LDK = BK + 4;
   constexpr int QPR = BK / 4;       // float4 quads per tile row
   constexpr int RPP = NT / QPR;     // tile rows covered per pass of the whole block
   constexpr int AP = (BM + RPP - 1) / RPP;
   constexpr int BP = (BN + RPP - 1) / RPP;
-  constexpr int A_ELEMS = BM * LDK;
-  constexpr int B_ELEMS = BN * LDK;
+  constexpr int A_ELEMS = BM * BK;
+  constexpr int B_ELEMS = BN * BK;
+  constexpr int NCH = BK / 8;       // 8-wide k-chunks per stage
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][BM][LDK]
-  float* Bs = smem + 2 * A_ELEMS;   // [2][BN][LDK]
+  float* As = smem;                 // [2][BM][BK] swizzled
+  float* Bs = smem + 2 * A_ELEMS;   // [2][BN][BK] swizzled
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,67 +92,72 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs p) {
   const int q = tid % QPR;
   const int r0 = tid / QPR;
 
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
   // ---- per-thread im2col row state -------------------------------------------------
-  int a_pix0[AP];  // n_img*H*W
-  int a_iy0[AP];
-  int a_ix0[AP];
+  // conv:        a_off = byte offset of input pixel (iy0, ix0) (may be "negative" = wrapped;
+  //              adding the tap offset brings valid taps back in range), a_msk = valid taps
+  // transposed:  a_off = n_img*H*W, coordinates kept in a_y/a_x, offset computed per tap
+  unsigned a_off[AP];
+  unsigned a_msk[AP];
+  int a_y[AP], a_x[AP];
   const int HoWo = p.Ho * p.Wo;
+  const int ntaps = p.kh * p.kw;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    int r = r0 + i * RPP;
-    int m = m0 + r;
+    const int r = r0 + i * RPP;
+    const int m = m0 + r;
+    a_off[i] = 0;
+    a_msk[i] = 0;
+    a_y[i] = a_x[i] = 0;
     if (r < BM && m < p.M) {
-      int n_img = m / HoWo;
-      int rem = m - n_img * HoWo;
-      int oy = rem / p.Wo;
-      int ox = rem - oy * p.Wo;
-      a_pix0[i] = n_img * p.H * p.W;
-      if (p.transposed) {
-        a_iy0[i] = oy + p.pad_t;
-        a_ix0[i] = ox + p.pad_l;
+      const int n_img = m / HoWo;
+      const int rem = m - n_img * HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      unsigned msk = 0;
+      if (TRANSPOSED) {
+        const int by = oy + p.pad_t, bx = ox + p.pad_l;
+        a_y[i] = by;
+        a_x[i] = bx;
+        a_off[i] = (unsigned)(n_img * p.H * p.W);
+        for (int t = 0; t < ntaps; ++t) {
+          const int ky = t / p.kw, kx = t - ky * p.kw;
+          const int ty = by - ky, tx = bx - kx;
+          const bool ok = (ty >= 0) && (tx >= 0) && (((ty | tx) & 1) == 0) && ((ty >> 1) < p.H) &&
+                          ((tx >> 1) < p.W);
+          if (ok) msk |= 1u << t;
+        }
       } else {
-        a_iy0[i] = oy * p.stride - p.pad_t;
-        a_ix0[i] = ox * p.stride - p.pad_l;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * 4) * 4u;
+        for (int t = 0; t < ntaps; ++t) {
+          const int ky = t / p.kw, kx = t - ky * p.kw;
+          const int iy = iy0 + ky, ix = ix0 + kx;
+          if (((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W)) msk |= 1u << t;
+        }
       }
-    } else {
-      a_pix0[i] = 0;
-      a_iy0[i] = -(1 << 20);
-      a_ix0[i] = -(1 << 20);
+      a_msk[i] = msk;
     }
   }
-
-  auto tap_pixel = [&](int i, int ky, int kx, int& pix) -> bool {
-    if (p.transposed) {
-      int ty = a_iy0[i] - ky, tx = a_ix0[i] - kx;
-      bool ok = (ty >= 0) && (tx >= 0) && (((ty | tx) & 1) == 0) && ((ty >> 1) < p.H) &&
-                ((tx >> 1) < p.W);
-      pix = a_pix0[i] + (ty >> 1) * p.W + (tx >> 1);
-      return ok;
-    } else {
-      int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      bool ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-      pix = a_pix0[i] + iy * p.W + ix;
-      return ok;
-    }
-  };
+  unsigned b_off[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int r = r0 + i * RPP;
+    const int n = n0 + r;
+    b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * 4) * 4u : OOB;
+  }
 
   // ---- which taps touch at least one in-range input pixel of this tile? -----------
   // (zero-padding taps of whole tiles are skipped: exact, they only add +0.)
-  const int ntaps = p.kh * p.kw;
-  unsigned tapmask = 0;
+  unsigned tapmask;
   {
     unsigned mine = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      int ky = t / p.kw, kx = t - ky * p.kw;
-      bool any = false;
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        int pix;
-        any |= tap_pixel(i, ky, kx, pix);
-      }
-      if (any) mine |= (1u << t);
-    }
-    // block-wide OR through LDS (smem is free before the main loop)
+    for (int i = 0; i < AP; ++i) mine |= a_msk[i];
     unsigned* red = reinterpret_cast<unsigned*>(smem);
     if (tid == 0) red[0] = 0;
     __syncthreads();
@@ -155,54 +178,64 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs p) {
   f32x4 ga[AP], gb[BP];
 
   auto load_stage = [&](int tap, int c0) {
-    int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int ty = a_y[i] - ky, tx = a_x[i] - kx;
+        const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
+        const unsigned vo = ((a_msk[i] >> tap) & 1u) ? (pix * (unsigned)p.ldx + (unsigned)(c0 + q * 4)) * 4u : OOB;
+        ga[i] = buf_load(rsA, vo);
+      }
+    } else {
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + c0) * 4u;  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const unsigned vo = ((a_msk[i] >> tap) & 1u) ? a_off[i] + adelta : OOB;
+        ga[i] = buf_load(rsA, vo);
+      }
+    }
+    const unsigned bdelta = (unsigned)(tap * p.Cin + c0) * 4u;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < BP; ++i) gb[i] = buf_load(rsB, b_off[i] + bdelta);
+  };
+
+  // swizzled LDS store position of this thread's quad: sw(r) is the same for all passes
+  // because RPP is a multiple of 16 rows.
+  const int wr_off = r0 * BK + ((q ^ swz<BK>(r0)) * 4);
+  auto store_stage = [&](int buf) {
+    float* a = As + buf * A_ELEMS + wr_off;
+    float* b = Bs + buf * B_ELEMS + wr_off;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      int pix;
-      bool ok = tap_pixel(i, ky, kx, pix);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.ldx + c0 + q * 4);
-      ga[i] = v;
+      if (AP * RPP == BM || r0 + i * RPP < BM) *reinterpret_cast<f32x4*>(a + i * RPP * BK) = ga[i];
     }
-    const int kbase = tap * p.Cin + c0 + q * 4;
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      int r = r0 + i * RPP;
-      int n = n0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < BN && n < p.cout_pad)
-        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.Ktot + kbase);
-      gb[i] = v;
+      if (BP * RPP == BN || r0 + i * RPP < BN) *reinterpret_cast<f32x4*>(b + i * RPP * BK) = gb[i];
     }
   };
 
-  auto store_stage = [&](int buf) {
-    float* a = As + buf * A_ELEMS;
-    float* b = Bs + buf * B_ELEMS;
+  // fragment read positions: row (lane&31) of each 32-row sub-tile, logical quad 2c+h
+  const int li = lane & 31, lh = lane >> 5;
+  int rdq[NCH];
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int r = r0 + i * RPP;
-      if (AP * RPP == BM || r < BM) *reinterpret_cast<f32x4*>(a + r * LDK + q * 4) = ga[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      int r = r0 + i * RPP;
-      if (BP * RPP == BN || r < BN) *reinterpret_cast<f32x4*>(b + r * LDK + q * 4) = gb[i];
-    }
-  };
+  for (int c = 0; c < NCH; ++c) rdq[c] = (((2 * c + lh) ^ swz<BK>(li)) * 4);
+  const int a_rd = (wm * TM * 32 + li) * BK;
+  const int b_rd = (wn * TN * 32 + li) * BK;
 
   auto compute_stage = [&](int buf) {
-    const float* a = As + buf * A_ELEMS + (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const float* b = Bs + buf * B_ELEMS + (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const float* a = As + buf * A_ELEMS + a_rd;
+    const float* b = Bs + buf * B_ELEMS + b_rd;
 #pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
-        af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * LDK + c * 8);
+        af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * BK + rdq[c]);
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni)
-        bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDK + c * 8);
+        bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * BK + rdq[c]);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -246,11 +279,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs p) {
 
   // ---- epilogue: bias, ReLU, fused head ops, store ------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
-  const int col_l = lane & 31;
-  const int rowh = 4 * (lane >> 5);
+  const int rowh = 4 * lh;
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
-    const int n = n0 + (wn * TN + ni) * 32 + col_l;
+    const int n = n0 + (wn * TN + ni) * 32 + li;
     const bool n_ok = n < p.Cout;
     const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
@@ -279,15 +311,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs p) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int BK>
+struct TileCfg {
+  int cfg, bm, bn;
+};
+const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128}, {KFN_CFG_128x128, 128, 128},
+                         {KFN_CFG_128x64, 128, 64},   {KFN_CFG_128x32, 128, 32},
+                         {KFN_CFG_64x64, 64, 64}};
+
+const TileCfg* find_cfg(int cfg) {
+  for (const TileCfg& c : kCfgs)
+    if (c.cfg == cfg) return &c;
+  return nullptr;
+}
+
+template <int TM, int TN, int WM, int WN, int BK, bool TR>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-  constexpr int LDK = BK + 4;
-  constexpr size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
-  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK>;
+  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, TR>;
   static bool attr_done = false;  // benign race: idempotent attribute
   if (!attr_done) {
     KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -300,30 +344,26 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   return KFN_OK;
 }
 
-template <int BK>
+template <int BK, bool TR>
 int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
-    case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK>(a, s);
-    case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, BK>(a, s);
-    case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK>(a, s);
-    case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, BK>(a, s);
-    case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK>(a, s);
+    case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK, TR>(a, s);
+    case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, BK, TR>(a, s);
+    case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, TR>(a, s);
+    case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, BK, TR>(a, s);
+    case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK, TR>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }
 
-// Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) for 256 CUs.
-int auto_config(const ConvArgs& a, int num_cu) {
-  struct Cand { int cfg, bm, bn; };
-  const Cand cands[] = {{KFN_CFG_160x128, 160, 128}, {KFN_CFG_128x128, 128, 128},
-                        {KFN_CFG_128x64, 128, 64},   {KFN_CFG_128x32, 128, 32},
-                        {KFN_CFG_64x64, 64, 64}};
+// Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) over the CUs.
+int auto_config(int M, int Cout, int num_cu) {
   double best = -1.0;
   int best_cfg = KFN_CFG_128x32;
-  for (const Cand& c : cands) {
-    long tiles = (long)kfn::ceil_div(a.M, c.bm) * kfn::ceil_div(a.Cout, c.bn);
+  for (const TileCfg& c : kCfgs) {
+    long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn);
     long rounds = (tiles + num_cu - 1) / num_cu;
-    double eff = ((double)a.M * a.Cout) / ((double)rounds * num_cu * c.bm * c.bn);
+    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn);
     // larger tiles amortise LDS traffic / barriers better: small bonus
     eff *= (c.bm * c.bn >= 160 * 128) ? 1.00 : (c.bm * c.bn >= 128 * 128) ? 0.97
            : (c.bm * c.bn >= 128 * 64) ? 0.92 : 0.85;
@@ -337,24 +377,20 @@ int auto_config(const ConvArgs& a, int num_cu) {
 
 int g_num_cu = 0;
 
-}  // namespace
-
-extern "C" int kfn_conv2d_out_shape(const kfn_conv_desc* d, int* Ho, int* Wo) {
-  KFN_REQUIRE(d && Ho && Wo, "kfn_conv2d_out_shape: null argument");
-  if (d->transposed) {
-    *Ho = d->H * d->stride;
-    *Wo = d->W * d->stride;
-  } else {
-    int pb;
-    kfn::same_pad(d->H, d->kh, d->stride, Ho, &pb);
-    kfn::same_pad(d->W, d->kw, d->stride, Wo, &pb);
+int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      g_num_cu = prop.multiProcessorCount;
+    else
+      g_num_cu = 256;  // MI355X
   }
-  return KFN_OK;
+  return g_num_cu;
 }
 
-extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const float* w_packed,
-                               const float* bias, float* y, void* stream) {
-  KFN_REQUIRE(d && x && w_packed && y, "kfn_conv2d_nhwc: null argument");
+int validate(const kfn_conv_desc* d) {
   KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "kfn_conv2d_nhwc: bad shape %dx%dx%d", d->N, d->H, d->W);
   KFN_REQUIRE(d->Cin > 0 && d->Cin % 16 == 0, "kfn_conv2d_nhwc: Cin=%d must be a multiple of 16", d->Cin);
   KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0, "kfn_conv2d_nhwc: bad ldx=%d", d->ldx);
@@ -363,44 +399,89 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   KFN_REQUIRE(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 32, "kfn_conv2d_nhwc: bad kernel %dx%d", d->kh, d->kw);
   KFN_REQUIRE(d->stride == 1 || d->stride == 2, "kfn_conv2d_nhwc: stride %d unsupported", d->stride);
   KFN_REQUIRE(!d->transposed || d->stride == 2, "kfn_conv2d_nhwc: transposed conv needs stride 2");
+  KFN_REQUIRE(d->epilogue != KFN_EPI_L2NORM || d->Cout == 32, "kfn_conv2d_nhwc: L2NORM epilogue needs Cout == 32");
+  return KFN_OK;
+}
+
+void out_shape(const kfn_conv_desc* d, int* Ho, int* Wo, int* pad_t, int* pad_l) {
+  if (d->transposed) {
+    // padding of the forward SAME conv (s*H -> H) whose input-gradient this is
+    int o;
+    *Ho = d->H * d->stride;
+    *Wo = d->W * d->stride;
+    kfn::same_pad(*Ho, d->kh, d->stride, &o, pad_t);
+    kfn::same_pad(*Wo, d->kw, d->stride, &o, pad_l);
+  } else {
+    kfn::same_pad(d->H, d->kh, d->stride, Ho, pad_t);
+    kfn::same_pad(d->W, d->kw, d->stride, Wo, pad_l);
+  }
+}
+
+int pick_config(const kfn_conv_desc* d, int M) {
+  int cfg = d->config;
+  if (cfg == KFN_CFG_AUTO) cfg = auto_config(M, d->Cout, num_cu());
+  if (d->epilogue == KFN_EPI_L2NORM) cfg = KFN_CFG_128x32;  // one 32-lane half == all channels
+  return cfg;
+}
+
+}  // namespace
+
+extern "C" int kfn_conv2d_out_shape(const kfn_conv_desc* d, int* Ho, int* Wo) {
+  KFN_REQUIRE(d && Ho && Wo, "kfn_conv2d_out_shape: null argument");
+  int pt, pl;
+  out_shape(d, Ho, Wo, &pt, &pl);
+  return KFN_OK;
+}
+
+extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int* tiles) {
+  KFN_REQUIRE(d && config && bk && tiles, "kfn_conv2d_plan: null argument");
+  int rc = validate(d);
+  if (rc != KFN_OK) return rc;
+  int Ho, Wo, pt, pl;
+  out_shape(d, &Ho, &Wo, &pt, &pl);
+  const int M = d->N * Ho * Wo;
+  *config = pick_config(d, M);
+  const TileCfg* c = find_cfg(*config);
+  KFN_REQUIRE(c, "kfn_conv2d_plan: unknown config %d", *config);
+  *bk = (d->Cin % 32 == 0) ? 32 : 16;
+  *tiles = kfn::ceil_div(M, c->bm) * kfn::ceil_div(d->Cout, c->bn);
+  return KFN_OK;
+}
+
+extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const float* w_packed,
+                               const float* bias, float* y, void* stream) {
+  KFN_REQUIRE(d && x && w_packed && y, "kfn_conv2d_nhwc: null argument");
+  int rc = validate(d);
+  if (rc != KFN_OK) return rc;
   KFN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_packed) & 15) == 0,
               "kfn_conv2d_nhwc: x / w_packed must be 16-byte aligned");
-  KFN_REQUIRE(d->epilogue != KFN_EPI_L2NORM || d->Cout == 32, "kfn_conv2d_nhwc: L2NORM epilogue needs Cout == 32");
 
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
-  a.transposed = d->transposed; a.relu = d->relu; a.epilogue = d->epilogue;
-  if (d->transposed) {
-    // padding of the forward SAME conv (s*H -> H) whose input-gradient this is
-    int o;
-    a.Ho = d->H * d->stride;
-    a.Wo = d->W * d->stride;
-    kfn::same_pad(a.Ho, d->kh, d->stride, &o, &a.pad_t);
-    kfn::same_pad(a.Wo, d->kw, d->stride, &o, &a.pad_l);
-  } else {
-    kfn::same_pad(d->H, d->kh, d->stride, &a.Ho, &a.pad_t);
-    kfn::same_pad(d->W, d->kw, d->stride, &a.Wo, &a.pad_l);
-  }
-  long M = (long)d->N * a.Ho * a.Wo;
-  KFN_REQUIRE(M < (1L << 31) && (long)d->N * d->H * d->W < (1L << 31), "kfn_conv2d_nhwc: tensor too large");
-  a.M = (int)M;
+  a.relu = d->relu; a.epilogue = d->epilogue;
+  out_shape(d, &a.Ho, &a.Wo, &a.pad_t, &a.pad_l);
+  const long M = (long)d->N * a.Ho * a.Wo;
+  const long in_pix = (long)d->N * d->H * d->W;
+  const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
   a.Ktot = d->kh * d->kw * d->Cin;
+  const long w_bytes = (long)d->cout_pad * a.Ktot * 4L;
+  // 32-bit byte offsets + the OOB marker need every buffer below 1 GiB
+  KFN_REQUIRE(M < (1L << 30) && x_bytes < (1L << 30) && w_bytes < (1L << 30),
+              "kfn_conv2d_nhwc: tensor too large for 32-bit buffer addressing (x %ld B, w %ld B)", x_bytes, w_bytes);
+  a.M = (int)M;
+  a.x_bytes = (unsigned)x_bytes;
+  a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
 
-  if (g_num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    KFN_HIP(hipGetDevice(&dev));
-    KFN_HIP(hipGetDeviceProperties(&prop, dev));
-    g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  int cfg = d->config;
-  if (cfg == KFN_CFG_AUTO) cfg = auto_config(a, g_num_cu);
-  if (d->epilogue == KFN_EPI_L2NORM) cfg = KFN_CFG_128x32;  // one 32-lane half == all channels
+  const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->Cin % 32 == 0) return dispatch_cfg<32>(cfg, a, s);
-  return dispatch_cfg<16>(cfg, a, s);
+  if (d->transposed) {
+    if (d->Cin % 32 == 0) return dispatch_cfg<32, true>(cfg, a, s);
+    return dispatch_cfg<16, true>(cfg, a, s);
+  }
+  if (d->Cin % 32 == 0) return dispatch_cfg<32, false>(cfg, a, s);
+  return dispatch_cfg<16, false>(cfg, a, s);
 }

@@ -257,6 +257,16 @@ class ConvOp(Op):
         n, ho, wo, cout = self.y.shape
         return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
 
+    CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2)}
+
+    def kernel_name(self, lib):
+        """Template instantiation this op launches, spelled like rocprofv3 prints it."""
+        d = self.desc()
+        cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
+        t = self.CFG_TILE[cfg.value]
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %s>' % (t + (bk.value, 'true' if self.transposed else 'false'))
+
     def launch(self, lib, stream):
         d = self.desc()
         rc = lib.kfn_conv2d_nhwc(C.byref(d), self.x.ptr, self.kernel.ptr,
