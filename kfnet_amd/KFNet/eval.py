@@ -1,0 +1,115 @@
+"""Per-sequence prediction entry point with the reference's `KFNet/eval.py` command line
+and output contract (README.md:126-130, KFNet/eval.py:31-177):
+
+    python -m kfnet_amd.KFNet.eval --input_folder I --output_folder O --model_folder M --scene S [--NIS]
+
+I holds image_list.txt (+ optional label_list.txt) and transform.txt; for every image one
+`coord_<index>.npy` float32 [h,w,4] = concat(T.x_KF, 1/sigma_KF) is written to O.
+`--synthetic T` replaces the image list by a seeded synthetic sequence (no dataset is
+reachable from the build environment); `--random_weights` replaces the checkpoint.
+
+Host loop semantics kept from eval.py: sequence_length = 500 irrespective of --scene
+(KFNetDataSpec() is built with the default scene), reset at i % 500 == 0,
+raw (untransformed, ungated) KF state fed back, NIS gate on the output only.
+Not reproduced: loss/accuracy/median-distance log fields (they need label maps; SURVEY
+§8(f) rank 1) and --show plotting.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from ..tools.io import get_snapshot, read_lines
+from ..weights import load_npz, synthetic_weights
+
+SCENES = ('chess', 'fire', 'heads', 'office', 'pumpkin', 'redkitchen', 'stairs')
+
+
+def get_transform(transform_file=None):
+    """KFNet/train.py:49-58."""
+    if transform_file:
+        transform = np.loadtxt(transform_file, dtype=np.float32)
+        return np.linalg.inv(transform)
+    return np.eye(4, dtype=np.float32)
+
+
+def load_images(paths, image_size):
+    """tf.image.decode_png(channels=3) replacement (KFNet/train.py:213-217)."""
+    from PIL import Image
+    H, W = image_size
+    out = np.empty((len(paths), H, W, 3), dtype=np.uint8)
+    for i, p in enumerate(paths):
+        im = np.asarray(Image.open(p).convert('RGB'))
+        if im.shape[:2] != (H, W):
+            raise ValueError('%s is %s, expected %dx%d' % (p, im.shape, H, W))
+        out[i] = im
+    return out
+
+
+def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
+         frames=None, sequence_length=500, chunk=256, verbose=True):
+    """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records."""
+    from ..engine import KFNetEngine
+    T = len(image_paths) if frames is None else frames.shape[0]
+    eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
+                      reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk)
+    records = []
+    for lo in range(0, T, chunk):
+        hi = min(T, lo + chunk)
+        host = frames[lo:hi] if frames is not None else load_images(image_paths[lo:hi], image_size)
+        dev = eng.upload_frames(host)
+        rec = eng.process(dev, t0=lo).cpu().numpy()   # state and feature ring carry over
+        records.append(rec)
+        if output_folder and os.path.isdir(output_folder):
+            for k in range(hi - lo):
+                np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
+        if verbose:
+            print('frames %d~%d done' % (lo, hi - 1))
+    return np.concatenate(records)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--input_folder', default='')
+    ap.add_argument('--output_folder', default='')
+    ap.add_argument('--model_folder', default='')
+    ap.add_argument('--scene', default='')
+    ap.add_argument('--NIS', action='store_true')
+    ap.add_argument('--gpu', type=int, default=0)
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--synthetic', type=int, default=0, help='use a seeded synthetic sequence of this many frames')
+    ap.add_argument('--random_weights', action='store_true')
+    a = ap.parse_args(argv)
+    if a.scene not in SCENES:
+        print('Invalid scene:', a.scene)   # KFNet/train.py:142-144
+        return 1
+    if a.random_weights:
+        W = synthetic_weights(1234)
+    else:
+        snapshot, step = get_snapshot(a.model_folder)
+        if snapshot is None:
+            print('no kfnet_weights*.npz in', a.model_folder)
+            return 1
+        W = load_npz(snapshot)
+    import torch
+    torch.cuda.set_device(a.gpu)
+    if a.synthetic > 0:
+        from ..synth import synthetic_sequence, synthetic_transform
+        frames = synthetic_sequence(a.synthetic)
+        transform = np.linalg.inv(synthetic_transform())
+        eval(None, transform, W, a.output_folder, a.NIS, frames=frames, batch=a.batch)
+        return 0
+    image_list = os.path.join(a.input_folder, 'image_list.txt')
+    transform_file = os.path.join(a.input_folder, 'transform.txt')
+    image_paths = read_lines(image_list)
+    print('----------------------------------')
+    print('scene: ', a.scene)
+    print('image number: ', len(image_paths))
+    print('----------------------------------')
+    eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, batch=a.batch)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
