@@ -35,9 +35,10 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=64)
-    ap.add_argument('--warmup', type=int, default=8)
-    ap.add_argument('--batch', type=int, default=4, help='frames per tower launch')
+    ap.add_argument('--steps', type=int, default=136)
+    ap.add_argument('--warmup', type=int, default=17)
+    ap.add_argument('--batch', type=int, default=17,
+                    help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kalman-roofline', action='store_true')
@@ -53,7 +54,8 @@ def per_kernel_profile(eng, dev_frames):
     from kfnet_amd.graph import ConvOp
     stream = eng._stream()
     eng._set_batch_images(dev_frames, 0, eng.B, stream)
-    eng.graph.run(stream, eng.heavy_ops)  # warm
+    eng.graph.run(stream, eng.heavy_ops, active=(eng.B, eng.B))  # warm
+    eng.graph.active = (eng.B, eng.B)
     torch.cuda.synchronize()
     rows = []
     reps = 3
@@ -163,7 +165,8 @@ def main():
     from kfnet_amd.dist import run_chunk
     from oracle import kfnet_oracle as O
 
-    K, Wm, B = args.steps, args.warmup, args.batch
+    K, Wm = args.steps, args.warmup
+    B = max(1, min(args.batch, K))
     Wt = synthetic_weights(1234)
     T4 = O.get_transform(synthetic_transform())
     # the whole job is one N*K-frame sequence; rank r owns frames [r*K, (r+1)*K)

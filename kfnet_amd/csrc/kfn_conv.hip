@@ -38,7 +38,8 @@ struct ConvArgs {
   int relu, epilogue;
   int M, Ktot;
   int tiles_m, tiles_n;
-  unsigned x_bytes, w_bytes;
+  unsigned long long x_bytes;
+  unsigned w_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -92,8 +93,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int q = tid % QPR;
   const int r0 = tid / QPR;
 
-  const __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  // The A descriptor is re-based at the first image this tile touches, so 32-bit byte
+  // offsets only have to span the few images of ONE tile (activations may exceed 2 GiB).
+  const int HoWo = p.Ho * p.Wo;
+  const int n_first = m0 / HoWo;
+  const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_rest = p.x_bytes - a_base;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
+      (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
@@ -104,7 +112,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   unsigned a_off[AP];
   unsigned a_msk[AP];
   int a_y[AP], a_x[AP];
-  const int HoWo = p.Ho * p.Wo;
   const int ntaps = p.kh * p.kw;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
@@ -114,8 +121,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     a_msk[i] = 0;
     a_y[i] = a_x[i] = 0;
     if (r < BM && m < p.M) {
-      const int n_img = m / HoWo;
-      const int rem = m - n_img * HoWo;
+      const int n_abs = m / HoWo;
+      const int rem = m - n_abs * HoWo;
+      const int n_img = n_abs - n_first;
       const int oy = rem / p.Wo;
       const int ox = rem - oy * p.Wo;
       unsigned msk = 0;
@@ -177,42 +185,53 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   f32x4 ga[AP], gb[BP];
 
-  auto load_stage = [&](int tap, int c0) {
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
-    if (TRANSPOSED) {
-#pragma unroll
-      for (int i = 0; i < AP; ++i) {
+  // ---- stage iterator of the LOAD stream (compute only counts stages) ---------------
+  const int kchunks = p.Cin / BK;
+  const int n_stages = __builtin_popcount(tapmask) * kchunks;
+  int ld_tap = tapmask ? __builtin_ctz(tapmask) : 32;
+  int ld_c0 = 0;
+  auto advance = [&]() {
+    ld_c0 += BK;
+    if (ld_c0 >= p.Cin) {
+      ld_c0 = 0;
+      const unsigned rest = (ld_tap < 31) ? (tapmask & ~((2u << ld_tap) - 1u)) : 0u;
+      ld_tap = rest ? __builtin_ctz(rest) : 32;
+    }
+  };
+
+  // Issue the global loads of the stage the iterator points at (all-OOB = zeros once the
+  // iterator has run off the end: keeps the loop body branch-free).
+  auto load_one = [&](int k, bool live, unsigned adelta, unsigned bdelta, int ky, int kx, int tap) {
+    if (k < AP) {
+      const int i = k;
+      unsigned vo;
+      if (TRANSPOSED) {
         const int ty = a_y[i] - ky, tx = a_x[i] - kx;
         const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
-        const unsigned vo = ((a_msk[i] >> tap) & 1u) ? (pix * (unsigned)p.ldx + (unsigned)(c0 + q * 4)) * 4u : OOB;
-        ga[i] = buf_load(rsA, vo);
+        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * 4)) * 4u;
+      } else {
+        vo = a_off[i] + adelta;
       }
+      vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo : OOB;
+      ga[i] = buf_load(rsA, vo);
     } else {
-      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + c0) * 4u;  // wave-uniform
-#pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        const unsigned vo = ((a_msk[i] >> tap) & 1u) ? a_off[i] + adelta : OOB;
-        ga[i] = buf_load(rsA, vo);
-      }
+      const int i = k - AP;
+      gb[i] = buf_load(rsB, live ? b_off[i] + bdelta : OOB);
     }
-    const unsigned bdelta = (unsigned)(tap * p.Cin + c0) * 4u;  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < BP; ++i) gb[i] = buf_load(rsB, b_off[i] + bdelta);
   };
 
   // swizzled LDS store position of this thread's quad: sw(r) is the same for all passes
   // because RPP is a multiple of 16 rows.
   const int wr_off = r0 * BK + ((q ^ swz<BK>(r0)) * 4);
-  auto store_stage = [&](int buf) {
-    float* a = As + buf * A_ELEMS + wr_off;
-    float* b = Bs + buf * B_ELEMS + wr_off;
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      if (AP * RPP == BM || r0 + i * RPP < BM) *reinterpret_cast<f32x4*>(a + i * RPP * BK) = ga[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      if (BP * RPP == BN || r0 + i * RPP < BN) *reinterpret_cast<f32x4*>(b + i * RPP * BK) = gb[i];
+  auto store_one = [&](int k, int buf) {
+    if (k < AP) {
+      const int i = k;
+      if (AP * RPP == BM || r0 + i * RPP < BM)
+        *reinterpret_cast<f32x4*>(As + buf * A_ELEMS + wr_off + i * RPP * BK) = ga[i];
+    } else {
+      const int i = k - AP;
+      if (BP * RPP == BN || r0 + i * RPP < BN)
+        *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + wr_off + i * RPP * BK) = gb[i];
     }
   };
 
@@ -224,56 +243,93 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int a_rd = (wm * TM * 32 + li) * BK;
   const int b_rd = (wn * TN * 32 + li) * BK;
 
-  auto compute_stage = [&](int buf) {
-    const float* a = As + buf * A_ELEMS + a_rd;
-    const float* b = Bs + buf * B_ELEMS + b_rd;
+  f32x4 fr[2][TM + TN];  // double-buffered A (TM) + B (TN) fragments
+  auto read_one = [&](int k, int slot, int buf, int c) {
+    if (k < TM)
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + a_rd + k * 32 * BK + rdq[c]);
+    else
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + b_rd + (k - TM) * 32 * BK + rdq[c]);
+  };
+
+  constexpr int NLD = AP + BP;     // global loads == LDS stores per stage
+  constexpr int NFR = TM + TN;     // fragment reads per chunk
+  constexpr int J = 4 * TM * TN;   // MFMAs per chunk
+
+  if (n_stages > 0) {
+    // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers ----------------------
+    {
+      const int ky = ld_tap / p.kw, kx = ld_tap - ky * p.kw;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned bdelta = (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      f32x4 af[TM], bf[TN];
+      for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
+      advance();
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-        af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * BK + rdq[c]);
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni)
-        bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * BK + rdq[c]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
+      for (int k = 0; k < NLD; ++k) store_one(k, 0);
     }
-  };
-
-  auto next_tap = [&](int t) {
-    ++t;
-    while (t < ntaps && !((tapmask >> t) & 1u)) ++t;
-    return t;
-  };
-
-  int tap = next_tap(-1);
-  if (tap < ntaps) {
-    int c0 = 0;
-    load_stage(tap, c0);
-    store_stage(0);
+    {
+      const bool live = ld_tap < 32;
+      const int tp = live ? ld_tap : 0;
+      const int ky = tp / p.kw, kx = tp - ky * p.kw;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) load_one(k, live, adelta, bdelta, ky, kx, tp);
+      advance();
+    }
     __syncthreads();
-    int buf = 0;
-    while (true) {
-      int c1 = c0 + BK, tap1 = tap;
-      if (c1 >= p.Cin) {
-        c1 = 0;
-        tap1 = next_tap(tap);
+#pragma unroll
+    for (int k = 0; k < NFR; ++k) read_one(k, 0, 0, 0);
+
+    // ---- main loop: one iteration == one BK-deep stage ---------------------------------
+    // Program order inside an iteration (everything but the MFMAs is slotted BETWEEN
+    // MFMAs, which leave ~64 cycles of issue slack each):
+    //   chunk 0       : ds_write regs(stage s+1) -> buf^1,  fragment reads of chunk 1
+    //   chunk 1       : buffer loads of stage s+2 -> regs,  fragment reads of chunk 2
+    //   chunk 2..N-2  : fragment reads of the next chunk
+    //   chunk N-1     : first half of the MFMAs, lgkmcnt(0) + barrier, fragment reads of
+    //                   chunk 0 of stage s+1 from buf^1, second half of the MFMAs
+    // (BK = 16 has two chunks: stores in chunk 0, loads + barrier in chunk 1.)
+    for (int s = 0; s < n_stages; ++s) {
+      const int buf = s & 1;
+      const bool live = ld_tap < 32;
+      const int tp = live ? ld_tap : 0;
+      const int ky = tp / p.kw, kx = tp - ky * p.kw;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int slot = c & 1;
+        const bool last = (c == NCH - 1);
+        constexpr int LOADC = (NCH > 2) ? 1 : NCH - 1;  // chunk that carries the global loads
+        // side ops of this chunk, in issue order
+        const int n_rd = last ? 0 : NFR;
+        const int n_st = (c == 0) ? NLD : 0;
+        const int n_ld = (c == LOADC) ? NLD : 0;
+        const int n_side = n_rd + n_st + n_ld;
+        const int jspan = last ? J / 2 : J;  // in the last chunk side ops ride the first half
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
+          if (last && j == J / 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NFR; ++k) read_one(k, slot ^ 1, buf ^ 1, 0);
+          }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < NFR + NLD; ++k) {
+            if (k < n_side && (k * jspan) / n_side == j) {
+              if (k < n_rd) read_one(k, slot ^ 1, buf, c + 1);
+              else if (k < n_rd + n_st) store_one(k - n_rd, buf ^ 1);
+              else load_one(k - n_rd - n_st, live, adelta, bdelta, ky, kx, tp);
+            }
+          }
+        }
       }
-      const bool has_next = tap1 < ntaps;
-      if (has_next) load_stage(tap1, c1);
-      compute_stage(buf);
-      if (!has_next) break;
-      store_stage(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
-      tap = tap1;
-      c0 = c1;
+      advance();
     }
   }
 
@@ -468,11 +524,15 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
   a.Ktot = d->kh * d->kw * d->Cin;
   const long w_bytes = (long)d->cout_pad * a.Ktot * 4L;
-  // 32-bit byte offsets + the OOB marker need every buffer below 1 GiB
-  KFN_REQUIRE(M < (1L << 30) && x_bytes < (1L << 30) && w_bytes < (1L << 30),
-              "kfn_conv2d_nhwc: tensor too large for 32-bit buffer addressing (x %ld B, w %ld B)", x_bytes, w_bytes);
+  // 32-bit byte offsets (+ the OOB marker 2^31): weights below 2 GiB, and the images one
+  // 160-row tile can touch below 2 GiB (the A descriptor is re-based per tile).
+  const long img_bytes = (long)d->H * d->W * d->ldx * 4L;
+  const long imgs_per_tile = 160 / ((long)a.Ho * a.Wo) + 2;
+  KFN_REQUIRE(M < (1L << 31) && w_bytes < (1L << 31) && img_bytes * imgs_per_tile < (1L << 31),
+              "kfn_conv2d_nhwc: tensor too large for 32-bit buffer addressing (image %ld B, w %ld B)", img_bytes,
+              w_bytes);
   a.M = (int)M;
-  a.x_bytes = (unsigned)x_bytes;
+  a.x_bytes = (unsigned long long)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
 

@@ -94,8 +94,6 @@ class KFNetEngine(object):
         dst = self.images.ptr
         src = dev_frames.data_ptr() + start * fb
         _lib.check(self.lib.kfn_memcpy_d2d(dst, src, count * fb, stream), 'memcpy images')
-        for k in range(count, self.B):  # pad: repeat the last valid frame (results discarded)
-            _lib.check(self.lib.kfn_memcpy_d2d(dst + k * fb, src + (count - 1) * fb, fb, stream), 'memcpy pad')
 
     def prime(self, dev_prev_frame):
         """Compute the flow features of the frame preceding this chunk and park them in
@@ -103,12 +101,11 @@ class KFNetEngine(object):
         instead of receiving 614 KB from rank r-1)."""
         stream = self._stream()
         fb = self.H * self.W * 3
-        for k in range(self.B):
-            _lib.check(self.lib.kfn_memcpy_d2d(self.images.ptr + k * fb, dev_prev_frame.data_ptr(), fb, stream), 'prime')
+        _lib.check(self.lib.kfn_memcpy_d2d(self.images.ptr, dev_prev_frame.data_ptr(), fb, stream), 'prime')
         tower_ops = [op for op in self.net.frame_ops if op in self.net.feat_tower.ops]
-        self.graph.run(stream, tower_ops)
+        self.graph.run(stream, tower_ops, active=(1, self.B))   # one frame only
         ring = self.net.temp_feat_maps
-        self.handover.src = ring.batch(self.B, 1)
+        self.handover.src = ring.batch(1, 1)
         self.handover.launch(self.lib, stream)
 
     def heavy(self, dev_frames, T=None):
@@ -122,7 +119,7 @@ class KFNetEngine(object):
         for s0 in range(0, T, self.B):
             cnt = min(self.B, T - s0)
             self._set_batch_images(dev_frames, s0, cnt, stream)
-            self.graph.run(stream, self.heavy_ops)
+            self.graph.run(stream, self.heavy_ops, active=(cnt, self.B))   # partial batches cost their share
             lib = self.lib
             _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + s0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
             _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + s0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')

@@ -190,6 +190,13 @@ class Param(object):
 # ---------------------------------------------------------------------------------------
 # ops
 # ---------------------------------------------------------------------------------------
+def _scaled(n, graph):
+    """Leading (batch) extent actually launched: graphs are built for B frames but a
+    partial batch of nb <= B frames only runs its share (Graph.active = (nb, B))."""
+    nb, B = graph.active
+    return n if nb == B else (n * nb) // B
+
+
 class Op(object):
     name = '?'
 
@@ -243,7 +250,7 @@ class ConvOp(Op):
     def desc(self):
         n, h, w, cin = self.x.shape
         cout = self.y.shape[3]
-        d = _lib.ConvDesc(N=n, H=h, W=w, Cin=cin, ldx=self.x.ld, Cout=cout,
+        d = _lib.ConvDesc(N=_scaled(n, self.x.graph), H=h, W=w, Cin=cin, ldx=self.x.ld, Cout=cout,
                           cout_pad=-(-cout // 32) * 32, ldy=self.y.ld, kh=self.kh, kw=self.kw,
                           stride=self.stride, transposed=int(self.transposed), relu=int(self.relu),
                           epilogue=self.epilogue, config=self.config)
@@ -293,6 +300,7 @@ class FirstConvOp(Op):
 
     def launch(self, lib, stream):
         n, h, w, _ = self.img.shape
+        n = _scaled(n, self.img.graph)
         h1 = self.heads[0]
         for hd in self.heads:
             assert hd[1].is_whole(), 'first-layer outputs must be whole buffers'
@@ -313,6 +321,7 @@ class CostVolumeOp(Op):
 
     def launch(self, lib, stream):
         n, h, w, c = self.f2.shape
+        n = _scaled(n, self.f2.graph)
         assert self.f1.ld == c and self.f2.ld == c
         rc = lib.kfn_cost_volume(self.f1.ptr, self.f2.ptr, self.vol.ptr, n, h, w, c, self.window, stream)
         _lib.check(rc, 'kfn_cost_volume')
@@ -324,7 +333,7 @@ class FlowOp(Op):
         self.logits, self.flow, self.prob, self.window = logits, flow, prob, window
 
     def launch(self, lib, stream):
-        P = self.flow.pixels
+        P = _scaled(self.flow.pixels, self.flow.graph)
         rc = lib.kfn_flow_softargmax(self.logits.ptr, self.flow.ptr,
                                      self.prob.ptr if self.prob is not None else None, P, self.window, stream)
         _lib.check(rc, 'kfn_flow_softargmax')
@@ -408,6 +417,7 @@ class Graph(object):
         self.first_conv = {}  # id(img tensor) -> FirstConvOp
         self.device = None
         self.debug_prob = False
+        self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 
     # -- construction -------------------------------------------------------------------
     def placeholder(self, shape, dtype='f32', name=None):
@@ -458,13 +468,19 @@ class Graph(object):
             p.storage = torch.from_numpy(np.ascontiguousarray(packed)).to(self.device)
         return self
 
-    def run(self, stream=None, ops=None):
+    def run(self, stream=None, ops=None, active=None):
+        """Launch `ops` (default: all) in order.  active=(nb, B) runs only the first nb of
+        the B batch entries the graph was built for."""
         import torch
         lib = _lib.load()
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-        for op in (ops if ops is not None else self.ops):
-            op.launch(lib, stream)
+        self.active = active if active is not None else (1, 1)
+        try:
+            for op in (ops if ops is not None else self.ops):
+                op.launch(lib, stream)
+        finally:
+            self.active = (1, 1)
 
     def total_flops(self):
         return sum(op.flops() for op in self.ops if hasattr(op, 'flops'))

@@ -282,3 +282,27 @@ def test_kalman_fuse_kat():
     assert np.all(o[ok, 3] <= mn[ok] * (1 + 1e-4)) and np.all(o[ok, 3] >= mn[ok] / np.sqrt(2) * (1 - 1e-4))
     rn = O.get_nis(meas[:, 0:3], meas[:, 3:4], pred[:, 0:3], pred[:, 3:4])
     assert np.allclose(nis.cpu().numpy().reshape(P, 3), rn, rtol=1e-6)
+
+
+def test_conv_beyond_2gib_activations():
+    """Activations larger than 2 GiB (32-bit buffer offsets are re-based per tile): every
+    image of a batch of identical images must produce the bit-identical output."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_conv_kernel
+    lib = _lib.load()
+    N, H, W, ci, co = 30, 480, 640, 64, 32
+    g = torch.Generator(device='cpu').manual_seed(3)
+    img = torch.randn(H * W * ci, generator=g).cuda()
+    x = img.repeat(N)                               # 2.36 GB
+    assert x.numel() * 4 > 2 ** 31
+    w = (np.random.default_rng(0).normal(size=(3, 3, ci, co)) / 24).astype(np.float32)
+    wp = dev(pack_conv_kernel(w))
+    y = torch.empty(N * H * W * co, device='cuda')
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=32, ldy=co, kh=3, kw=3, stride=1, relu=1)
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(d), x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), stream()), 'conv')
+    sync()
+    y = y.view(N, -1)
+    assert float(y[0].abs().max()) > 0
+    assert bool((y == y[0:1]).all())
