@@ -94,6 +94,8 @@ typedef struct kfn_conv_desc {
 #define KFN_CFG_128x64 3   /* 4 waves, wave tile 64x32 */
 #define KFN_CFG_128x32 4   /* 4 waves, wave tile 32x32 */
 #define KFN_CFG_64x64 5    /* 4 waves, wave tile 32x32 */
+#define KFN_CFG_256x32 6   /* 4 waves, wave tile 64x32 (Cout <= 32 layers) */
+#define KFN_CFG_192x64 7   /* 4 waves, wave tile 96x32 (Cout == 64 layers) */
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);
@@ -125,6 +127,14 @@ int kfn_cost_volume(const float* f1, const float* f2, float* vol, int N, int H, 
  * logits [P, window*window] (row-major i,j); flow_xy [P,2]; prob [P,window^2] or NULL. */
 int kfn_flow_softargmax(const float* logits, float* flow_xy, float* prob, int P, int window,
                         void* stream);
+
+/* ---- fused flow head: OFlowNet 'prediction' conv + softmax + soft-argmax ----------------
+ * cnn_wrapper/OFlowNet.py:41 (3x3 conv C->1, SAME, no ReLU on the 8x8 window grid) +
+ * OFlowNet.py:45-47 + KFNet/KFNet.py:381-385 in one kernel; the 64 logits stay on chip.
+ * x [P,8,8,C] (C % 4 == 0, C <= 32); w [3,3,C] = the TF kernel [3,3,C,1] flattened;
+ * bias [1] or NULL; flow_xy [P,2]; opt_logits [P,64] or NULL (debug). */
+int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow_xy,
+                  float* opt_logits, int P, int C, void* stream);
 
 /* ---- the recurrent part: warp + Kalman predict/update + NIS + transform/emit ----------
  * One launch scans T frames of S independent sequences (one workgroup per sequence,

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
-CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64 = 0, 1, 2, 3, 4, 5
+CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class KfnError(RuntimeError):
@@ -56,6 +56,7 @@ SYMBOLS = {
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'kfn_flow_head': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),

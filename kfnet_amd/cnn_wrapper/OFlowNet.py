@@ -1,7 +1,7 @@
 """OFlowNet, the process-model head over the local cost volume -- same class surface as
 the reference's cnn_wrapper/OFlowNet.py:6-57."""
 from .. import _lib
-from ..graph import ConvOp, FlowOp, pack_bias, pack_dense_kernel
+from ..graph import ConvOp, FlowHeadOp, FlowOp, pack_bias, pack_dense_kernel, pack_flow_head_kernel
 from .network import Network
 
 
@@ -71,7 +71,19 @@ class OFlowNet(Network):
         assert output.shape[1] * output.shape[2] == self.window_area and output.is_whole()
         prob_map = g.tensor((n, 1, 1, self.window_area), name='prob')
         flow = g.tensor((n, 1, 1, 2), name='flow')
-        self._emit(FlowOp(output, flow, prob_map if g.debug_prob else None, window))
+        pred_op = [op for op in self.ops if op.name == 'prediction'][0]
+        x = pred_op.x
+        if (g.fuse_flow_head and not g.debug_prob and window == 8 and x.is_whole() and x.shape[3] % 4 == 0
+                and x.shape[3] <= 32):
+            # the 'prediction' conv is absorbed into the flow head: its 64 logits per pixel are
+            # produced and consumed on chip (the 'prediction' layer tensor is not written)
+            g.ops.remove(pred_op)
+            self.ops.remove(pred_op)
+            kern = g.params[pred_op.kernel.name]
+            kern.pack = pack_flow_head_kernel
+            self._emit(FlowHeadOp(x, kern, pred_op.bias, flow))
+        else:
+            self._emit(FlowOp(output, flow, prob_map if g.debug_prob else None, window))
         prob_map.flow = flow
         feat = self.get_output_by_name('conv3b')  # BHWx1x1x128
         fc1 = self._dense(feat, 64, 'fc1', True)

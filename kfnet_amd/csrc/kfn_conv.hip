@@ -18,6 +18,7 @@
 // stage s+1 are issued before the MFMAs of stage s (register-staged double buffer, one
 // barrier per stage).
 #include "kfn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,6 +54,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<0, N>(f);
 }
 
 template <int BK>
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // The A descriptor is re-based at the first image this tile touches, so 32-bit byte
   // offsets only have to span the few images of ONE tile (activations may exceed 2 GiB).
   const int HoWo = p.Ho * p.Wo;
-  const int n_first = m0 / HoWo;
+  const int n_first = TRANSPOSED ? 0 : m0 / HoWo;
   const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
   const unsigned long long a_rest = p.x_bytes - a_base;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -121,11 +135,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     a_msk[i] = 0;
     a_y[i] = a_x[i] = 0;
     if (r < BM && m < p.M) {
-      const int n_abs = m / HoWo;
-      const int rem = m - n_abs * HoWo;
-      const int n_img = n_abs - n_first;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
+      int n_img, oy, ox;
+      if (TRANSPOSED) {
+        // parity-class-major row order: m = cls*(N*H*W) + (n, i, j); output pixel
+        // (2i + (cls>>1), 2j + (cls&1)).  All rows of a tile (bar 3 seams) then share a
+        // parity class and hence the same 1/2/2/4 live taps -- the rest are skipped.
+        const int NHW = p.N * p.H * p.W;
+        const int cls = m / NHW;
+        const int idx = m - cls * NHW;
+        n_img = idx / (p.H * p.W);
+        const int rem = idx - n_img * (p.H * p.W);
+        const int ii = rem / p.W;
+        oy = 2 * ii + (cls >> 1);
+        ox = 2 * (rem - ii * p.W) + (cls & 1);
+      } else {
+        const int n_abs = m / HoWo;
+        const int rem = m - n_abs * HoWo;
+        n_img = n_abs - n_first;
+        oy = rem / p.Wo;
+        ox = rem - oy * p.Wo;
+      }
       unsigned msk = 0;
       if (TRANSPOSED) {
         const int by = oy + p.pad_t, bx = ox + p.pad_l;
@@ -297,40 +326,62 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const int ky = tp / p.kw, kx = tp - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
       const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int slot = c & 1;
-        const bool last = (c == NCH - 1);
+      static_for<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int slot = c & 1;
+        constexpr bool last = (c == NCH - 1);
         constexpr int LOADC = (NCH > 2) ? 1 : NCH - 1;  // chunk that carries the global loads
         // side ops of this chunk, in issue order
-        const int n_rd = last ? 0 : NFR;
-        const int n_st = (c == 0) ? NLD : 0;
-        const int n_ld = (c == LOADC) ? NLD : 0;
-        const int n_side = n_rd + n_st + n_ld;
-        const int jspan = last ? J / 2 : J;  // in the last chunk side ops ride the first half
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          const int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
-          if (last && j == J / 2) {
+        constexpr int n_rd = last ? 0 : NFR;
+        constexpr int n_st = (c == 0) ? NLD : 0;
+        constexpr int n_ld = (c == LOADC) ? NLD : 0;
+        constexpr int n_side = n_rd + n_st + n_ld;
+        constexpr int jspan = last ? J / 2 : J;  // in the last chunk side ops ride the first half
+        static_for<J>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
+          if constexpr (last && j == J / 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < NFR; ++k) read_one(k, slot ^ 1, buf ^ 1, 0);
+            static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0); });
           }
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-          for (int k = 0; k < NFR + NLD; ++k) {
-            if (k < n_side && (k * jspan) / n_side == j) {
-              if (k < n_rd) read_one(k, slot ^ 1, buf, c + 1);
-              else if (k < n_rd + n_st) store_one(k - n_rd, buf ^ 1);
-              else load_one(k - n_rd - n_st, live, adelta, bdelta, ky, kx, tp);
-            }
-          }
-        }
-      }
+          // side ops k with floor(k*jspan/n_side) == j ride behind MFMA j
+          constexpr int kb = n_side ? (j * n_side + jspan - 1) / jspan : 0;
+          constexpr int ke0 = n_side ? ((j + 1) * n_side + jspan - 1) / jspan : 0;
+          constexpr int ke = ke0 < n_side ? ke0 : n_side;
+          static_for<(ke > kb ? ke - kb : 0)>([&](auto kc) {
+            constexpr int k = kb + decltype(kc)::value;
+            if constexpr (k < n_rd) read_one(k, slot ^ 1, buf, c + 1);
+            else if constexpr (k < n_rd + n_st) store_one(k - n_rd, buf ^ 1);
+            else load_one(k - n_rd - n_st, live, adelta, bdelta, ky, kx, tp);
+          });
+        });
+      });
       advance();
     }
+  }
+
+  // transposed: rows are in parity-class order, translate to output pixel indices via LDS
+  int* out_pix = reinterpret_cast<int*>(smem);
+  if (TRANSPOSED) {
+    __syncthreads();  // everyone is done with the operand buffers
+    for (int r = tid; r < BM; r += NT) {
+      const int m = m0 + r;
+      int op = -1;
+      if (m < p.M) {
+        const int NHW = p.N * p.H * p.W;
+        const int cls = m / NHW;
+        const int idx = m - cls * NHW;
+        const int n_img = idx / (p.H * p.W);
+        const int rem = idx - n_img * (p.H * p.W);
+        const int ii = rem / p.W;
+        op = (n_img * p.Ho + 2 * ii + (cls >> 1)) * p.Wo + 2 * (rem - ii * p.W) + (cls & 1);
+      }
+      out_pix[r] = op;
+    }
+    __syncthreads();
   }
 
   // ---- epilogue: bias, ReLU, fused head ops, store ------------------------------------
@@ -361,7 +412,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         } else if (p.epilogue == KFN_EPI_EXP_1E2) {
           v = expf(v) * 1e-2f;
         }
-        if (n_ok && m < p.M) p.y[(size_t)m * p.ldy + n] = v;
+        if (TRANSPOSED) {
+          const int op = out_pix[m - m0];
+          if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
+        } else {
+          if (n_ok && m < p.M) p.y[(size_t)m * p.ldy + n] = v;
+        }
       }
     }
   }
@@ -369,10 +425,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
 struct TileCfg {
   int cfg, bm, bn;
+  double prior;  // measured MFMA utilisation of the instantiation on large problems
 };
-const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128}, {KFN_CFG_128x128, 128, 128},
-                         {KFN_CFG_128x64, 128, 64},   {KFN_CFG_128x32, 128, 32},
-                         {KFN_CFG_64x64, 64, 64}};
+const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87}, {KFN_CFG_128x128, 128, 128, 0.84},
+                         {KFN_CFG_192x64, 192, 64, 0.78},   {KFN_CFG_128x64, 128, 64, 0.72},
+                         {KFN_CFG_256x32, 256, 32, 0.70},   {KFN_CFG_128x32, 128, 32, 0.52},
+                         {KFN_CFG_64x64, 64, 64, 0.50}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -408,6 +466,8 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, TR>(a, s);
     case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, BK, TR>(a, s);
     case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK, TR>(a, s);
+    case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, BK, TR>(a, s);
+    case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }
@@ -419,10 +479,7 @@ int auto_config(int M, int Cout, int num_cu) {
   for (const TileCfg& c : kCfgs) {
     long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn);
     long rounds = (tiles + num_cu - 1) / num_cu;
-    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn);
-    // larger tiles amortise LDS traffic / barriers better: small bonus
-    eff *= (c.bm * c.bn >= 160 * 128) ? 1.00 : (c.bm * c.bn >= 128 * 128) ? 0.97
-           : (c.bm * c.bn >= 128 * 64) ? 0.92 : 0.85;
+    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn) * c.prior;
     if (eff > best) {
       best = eff;
       best_cfg = c.cfg;
@@ -476,7 +533,7 @@ void out_shape(const kfn_conv_desc* d, int* Ho, int* Wo, int* pad_t, int* pad_l)
 int pick_config(const kfn_conv_desc* d, int M) {
   int cfg = d->config;
   if (cfg == KFN_CFG_AUTO) cfg = auto_config(M, d->Cout, num_cu());
-  if (d->epilogue == KFN_EPI_L2NORM) cfg = KFN_CFG_128x32;  // one 32-lane half == all channels
+  if (d->epilogue == KFN_EPI_L2NORM && cfg != KFN_CFG_256x32) cfg = KFN_CFG_128x32;  // BN must be 32
   return cfg;
 }
 
@@ -526,6 +583,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const long w_bytes = (long)d->cout_pad * a.Ktot * 4L;
   // 32-bit byte offsets (+ the OOB marker 2^31): weights below 2 GiB, and the images one
   // 160-row tile can touch below 2 GiB (the A descriptor is re-based per tile).
+  KFN_REQUIRE(!d->transposed || x_bytes < (1L << 31), "kfn_conv2d_nhwc: transposed conv input above 2 GiB");
   const long img_bytes = (long)d->H * d->W * d->ldx * 4L;
   const long imgs_per_tile = 160 / ((long)a.Ho * a.Wo) + 2;
   KFN_REQUIRE(M < (1L << 31) && w_bytes < (1L << 31) && img_bytes * imgs_per_tile < (1L << 31),

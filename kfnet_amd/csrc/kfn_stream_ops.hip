@@ -12,61 +12,71 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tower's preprocess+feat1 (KFNet/KFNet.py:317-320) read the image ONCE.
 // Block = 64x4 output pixels; the 66x6x3 preprocessed halo lives in LDS (zero padding is
 // applied in the preprocessed domain, as TF pads the already-normalised tensor).
-// Each thread owns one pixel: its 27 inputs sit in registers, weights are wave-uniform
-// (scalar loads), outputs are produced 16 channels at a time.
 // ------------------------------------------------------------------------------------
 constexpr int FT_W = 64, FT_H = 4;
+constexpr int FT_TW3 = (FT_W + 2) * 3;
 
+// One head of the first layer.  LP = C/4 lanes cooperate on one pixel: lane s owns output
+// channels [4s, 4s+4) (27 float4 weights in registers), so a pixel's C floats leave the
+// wave as one contiguous LP*16-byte run and the 64/LP pixels a wave handles per round are
+// x-adjacent: fully coalesced stores (the layer is store-bound: 98 MB/frame written).
+template <int LP>
+__device__ __forceinline__ void first_head(const float* tile, const float* __restrict__ w,
+                                           const float* __restrict__ b, float* __restrict__ y,
+                                           int n, int H, int W, int x0, int y0, int tid) {
+  constexpr int C = LP * 4;
+  constexpr int SLOTS = 256 / LP;            // pixels in flight per block round
+  constexpr int ROUNDS = (FT_W * FT_H) / SLOTS;
+  const int s = tid % LP;
+  const int ps = tid / LP;
+  f32x4 wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = *reinterpret_cast<const f32x4*>(w + k * C + s * 4);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (b) bias = *reinterpret_cast<const f32x4*>(b + s * 4);
+#pragma unroll 2
+  for (int it = 0; it < ROUNDS; ++it) {
+    const int pi = it * SLOTS + ps;
+    const int ty = pi / FT_W, tx = pi - ty * FT_W;
+    const int gx = x0 + tx, gy = y0 + ty;
+    f32x4 acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* row = tile + (ty + ky) * FT_TW3 + tx * 3;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const float xv = row[j];
+        acc += xv * wk[ky * 9 + j];
+      }
+    }
+    if (gx < W && gy < H) {
+      f32x4 v = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+      *reinterpret_cast<f32x4*>(y + (((size_t)n * H + gy) * W + gx) * C + s * 4) = v;
+    }
+  }
+}
+
+template <int LP1, int LP2>
 __global__ __launch_bounds__(256) void first_conv_kernel(
     const uint8_t* __restrict__ img, int N, int H, int W,
-    const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y1, int C1,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y2, int C2) {
-  __shared__ float tile[(FT_H + 2) * (FT_W + 2) * 3];
+    const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y2) {
+  __shared__ float tile[(FT_H + 2) * FT_TW3];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, n = blockIdx.z;
   const uint8_t* src = img + (size_t)n * H * W * 3;
-  constexpr int TW3 = (FT_W + 2) * 3;
-  for (int i = tid; i < (FT_H + 2) * TW3; i += 256) {
-    int yy = i / TW3, rem = i - yy * TW3;
-    int xx = rem / 3, c = rem - xx * 3;
+  for (int i = tid; i < (FT_H + 2) * FT_TW3; i += 256) {
+    int yy = i / FT_TW3, rem = i - yy * FT_TW3;
+    int xx = rem / 3;
     int gy = y0 + yy - 1, gx = x0 + xx - 1;
     float v = 0.f;
     if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-      v = ((float)src[((size_t)gy * W + gx) * 3 + c] - 128.0f) * 0.00625f;
+      v = ((float)src[((size_t)gy * W + x0 - 1) * 3 + rem] - 128.0f) * 0.00625f;
     tile[i] = v;
   }
   __syncthreads();
-  const int tx = tid & (FT_W - 1), ty = tid / FT_W;
-  const int gx = x0 + tx, gy = y0 + ty;
-  float xin[27];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xin[(ky * 3 + kx) * 3 + c] = tile[(ty + ky) * TW3 + (tx + kx) * 3 + c];
-  if (gx >= W || gy >= H) return;
-  const size_t pix = ((size_t)n * H + gy) * W + gx;
-
-  auto head = [&](const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y, int C) {
-    for (int g = 0; g < C; g += 16) {
-      float acc[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) acc[c] = b ? b[g + c] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 27; ++k)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = fmaf(xin[k], w[k * C + g + c], acc[c]);
-      float* dst = y + pix * C + g;
-#pragma unroll
-      for (int c = 0; c < 16; c += 4) {
-        f32x4 v = {fmaxf(acc[c], 0.f), fmaxf(acc[c + 1], 0.f), fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f)};
-        *reinterpret_cast<f32x4*>(dst + c) = v;
-      }
-    }
-  };
-  head(w1, b1, y1, C1);
-  if (C2 > 0) head(w2, b2, y2, C2);
+  first_head<LP1>(tile, w1, b1, y1, n, H, W, x0, y0, tid);
+  if constexpr (LP2 > 0) first_head<LP2>(tile, w2, b2, y2, n, H, W, x0, y0, tid);
 }
 
 // ------------------------------------------------------------------------------------
@@ -149,6 +159,67 @@ __global__ __launch_bounds__(256) void flow_softargmax_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------
+// OFlowNet 'prediction' conv (3x3, C -> 1, no ReLU; OFlowNet.py:41) fused with the softmax
+// over the 64 window cells (OFlowNet.py:45-47) and the soft-argmax flow (KFNet.py:381-385).
+// One wavefront per pixel, one lane per window cell (i,j): the pixel's 8x8xC activation
+// tile is staged in LDS with a zero border (the conv's SAME padding), each lane does its
+// 9*C MACs with wave-uniform weights, then max/sum/weighted-sum by wave shuffles.  The 64
+// logits never go to HBM.
+// ------------------------------------------------------------------------------------
+constexpr int FH_LD = 36;  // LDS floats per tile cell (C <= 32, +4 pad against bank conflicts)
+
+__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ flow,
+                                                        float* __restrict__ logits_out, int P, int C) {
+  __shared__ __attribute__((aligned(16))) float tiles[4][10 * 10 * FH_LD];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  float* tile = tiles[wv];
+  const int C4 = C >> 2;
+  // zero border once (interior is overwritten per pixel)
+  for (int i = lane; i < 100 * FH_LD; i += 64) tile[i] = 0.f;
+  const int ci = lane >> 3, cj = lane & 7;
+  const float b0 = bias ? bias[0] : 0.f;
+  for (int p = blockIdx.x * 4 + wv; p < P; p += gridDim.x * 4) {
+    const float* src = x + (size_t)p * 64 * C;
+    // 64 cells x C floats, coalesced float4 loads; cell (a,b) -> tile[(a+1)*10 + (b+1)]
+    for (int k = lane; k < 64 * C4; k += 64) {
+      const int cell = k / C4, q = k - cell * C4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + cell * C + q * 4);
+      *reinterpret_cast<f32x4*>(tile + (((cell >> 3) + 1) * 10 + (cell & 7) + 1) * FH_LD + q * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float acc = b0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* cellp = tile + ((ci + ky) * 10 + cj + kx) * FH_LD;
+        const float* wp = w + (ky * 3 + kx) * C;
+        for (int q = 0; q < C4; ++q) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(cellp + q * 4);
+          acc = fmaf(xv.x, wp[q * 4 + 0], acc);
+          acc = fmaf(xv.y, wp[q * 4 + 1], acc);
+          acc = fmaf(xv.z, wp[q * 4 + 2], acc);
+          acc = fmaf(xv.w, wp[q * 4 + 3], acc);
+        }
+      }
+    if (logits_out) logits_out[(size_t)p * 64 + lane] = acc;
+    const float mx = wave_max(acc);
+    const float e = expf(acc - mx);
+    const float se = wave_sum(e);
+    const float pr = e / se;
+    const float sx = wave_sum(pr * (float)(cj - 4));
+    const float sy = wave_sum(pr * (float)(ci - 4));
+    if (lane == 0) {
+      flow[(size_t)p * 2 + 0] = sx;
+      flow[(size_t)p * 2 + 1] = sy;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int ld_src,
                                                             float* __restrict__ dst, int ld_dst,
                                                             int P, int C) {
@@ -168,12 +239,21 @@ extern "C" int kfn_first_conv_u8(const uint8_t* img, int N, int H, int W, const 
                                  const float* b2, float* y2, int C2, void* stream) {
   KFN_REQUIRE(img && w1 && y1, "kfn_first_conv_u8: null argument");
   KFN_REQUIRE(N > 0 && H > 0 && W > 0, "kfn_first_conv_u8: bad shape");
-  KFN_REQUIRE(C1 > 0 && C1 % 16 == 0 && C2 >= 0 && C2 % 16 == 0,
-              "kfn_first_conv_u8: C1=%d C2=%d must be multiples of 16", C1, C2);
   KFN_REQUIRE(C2 == 0 || (w2 && y2), "kfn_first_conv_u8: second head needs w2/y2");
   dim3 grid(kfn::ceil_div(W, FT_W), kfn::ceil_div(H, FT_H), N), block(256);
-  hipLaunchKernelGGL(first_conv_kernel, grid, block, 0, (hipStream_t)stream, img, N, H, W, w1, b1,
-                     y1, C1, w2, b2, y2, C2);
+  hipStream_t s = (hipStream_t)stream;
+#define KFN_FIRST(L1, L2)                                                                     \
+  hipLaunchKernelGGL((first_conv_kernel<L1, L2>), grid, block, 0, s, img, N, H, W, w1, b1, y1, w2, b2, y2)
+  if (C1 == 64 && C2 == 16) KFN_FIRST(16, 4);
+  else if (C1 == 64 && C2 == 0) KFN_FIRST(16, 0);
+  else if (C1 == 16 && C2 == 0) KFN_FIRST(4, 0);
+  else if (C1 == 32 && C2 == 0) KFN_FIRST(8, 0);
+  else if (C1 == 16 && C2 == 64) KFN_FIRST(4, 16);
+  else if (C1 == 32 && C2 == 16) KFN_FIRST(8, 4);
+  else
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_first_conv_u8: head widths (%d,%d) not instantiated "
+                     "(have 64+16, 16+64, 32+16, 64, 32, 16)", C1, C2);
+#undef KFN_FIRST
   KFN_LAUNCH_CHECK("first_conv_kernel");
   return KFN_OK;
 }
@@ -201,6 +281,19 @@ extern "C" int kfn_flow_softargmax(const float* logits, float* flow_xy, float* p
   hipLaunchKernelGGL(flow_softargmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits,
                      flow_xy, prob, P, window);
   KFN_LAUNCH_CHECK("flow_softargmax_kernel");
+  return KFN_OK;
+}
+
+extern "C" int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow_xy,
+                             float* opt_logits, int P, int C, void* stream) {
+  KFN_REQUIRE(x && w && flow_xy, "kfn_flow_head: null argument");
+  KFN_REQUIRE(P > 0 && C > 0 && C % 4 == 0 && C <= 32, "kfn_flow_head: bad shape P=%d C=%d (C%%4==0, C<=32)", P, C);
+  KFN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "kfn_flow_head: x must be 16-byte aligned");
+  int blocks = kfn::ceil_div(P, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(flow_head_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, flow_xy,
+                     opt_logits, P, C);
+  KFN_LAUNCH_CHECK("flow_head_kernel");
   return KFN_OK;
 }
 

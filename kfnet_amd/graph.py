@@ -264,7 +264,8 @@ class ConvOp(Op):
         n, ho, wo, cout = self.y.shape
         return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
 
-    CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2)}
+    CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
+                6: (2, 1, 4, 1), 7: (3, 1, 2, 2)}
 
     def kernel_name(self, lib):
         """Template instantiation this op launches, spelled like rocprofv3 prints it."""
@@ -337,6 +338,32 @@ class FlowOp(Op):
         rc = lib.kfn_flow_softargmax(self.logits.ptr, self.flow.ptr,
                                      self.prob.ptr if self.prob is not None else None, P, self.window, stream)
         _lib.check(rc, 'kfn_flow_softargmax')
+
+
+def pack_flow_head_kernel(w):
+    """TF HWIO [3,3,C,1] -> [3][3][C]."""
+    assert w.shape[0] == 3 and w.shape[1] == 3 and w.shape[3] == 1
+    return np.ascontiguousarray(w[..., 0].astype(np.float32))
+
+
+class FlowHeadOp(Op):
+    """OFlowNet 'prediction' conv + softmax + soft-argmax in one launch (kfn_flow_head)."""
+
+    def __init__(self, x, kernel, bias, flow, logits=None):
+        self.name = 'flow_head'
+        self.x, self.kernel, self.bias, self.flow, self.logits = x, kernel, bias, flow, logits
+
+    def flops(self):
+        n, h, w, c = self.x.shape
+        return 2.0 * n * h * w * 9 * c
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.x.shape
+        assert h == 8 and w == 8 and self.x.ld == c
+        P = _scaled(n, self.x.graph)
+        rc = lib.kfn_flow_head(self.x.ptr, self.kernel.ptr, self.bias.ptr if self.bias is not None else None,
+                               self.flow.ptr, self.logits.ptr if self.logits is not None else None, P, c, stream)
+        _lib.check(rc, 'kfn_flow_head')
 
 
 class CopyChannelsOp(Op):
@@ -417,6 +444,7 @@ class Graph(object):
         self.first_conv = {}  # id(img tensor) -> FirstConvOp
         self.device = None
         self.debug_prob = False
+        self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 
     # -- construction -------------------------------------------------------------------

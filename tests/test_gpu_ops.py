@@ -35,7 +35,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_vs_oracle(case, config):
     from tests.gpu_util import run_conv
     n, h, w, ci, co, k, s, relu = case
@@ -60,7 +60,8 @@ def test_conv_strided_views():
     assert np.abs(y - ref).max() <= _conv_tol(x, wt)
 
 
-@pytest.mark.parametrize('shape', [(3, 1, 1, 128, 64), (2, 2, 2, 64, 32), (2, 4, 4, 32, 16), (1, 5, 7, 16, 40)])
+@pytest.mark.parametrize('shape', [(3, 1, 1, 128, 64), (2, 2, 2, 64, 32), (2, 4, 4, 32, 16), (1, 5, 7, 16, 40),
+                                   (300, 2, 2, 64, 32), (70, 4, 4, 32, 16)])
 def test_deconv_vs_oracle(shape):
     from tests.gpu_util import run_conv
     n, h, w, ci, co = shape
@@ -306,3 +307,29 @@ def test_conv_beyond_2gib_activations():
     y = y.view(N, -1)
     assert float(y[0].abs().max()) > 0
     assert bool((y == y[0:1]).all())
+
+
+@pytest.mark.parametrize('Cc', [16, 32, 4])
+def test_flow_head_vs_oracle(Cc):
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    P = 517
+    x = rng.normal(size=(P, 8, 8, Cc)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, Cc, 1)) * 0.8).astype(np.float32)
+    b = np.array([0.3], np.float32)
+    flow = torch.zeros(P * 2, device='cuda')
+    logits = torch.zeros(P * 64, device='cuda')
+    dx, dw, db = dev(x), dev(w[..., 0]), dev(b)
+    _lib.check(lib.kfn_flow_head(dx.data_ptr(), dw.data_ptr(), db.data_ptr(), flow.data_ptr(), logits.data_ptr(),
+                                 P, Cc, stream()), 'flow_head')
+    sync()
+    ref_logits = O.conv2d_same(x.astype(np.float64), w, b, 1, False)[..., 0].reshape(P, 64)
+    pr = O.softmax(ref_logits)
+    offs = O.coord_volume(np.zeros((1, 2, 2, 1)), np.zeros((1, 2, 2, 1)), 8)[1]
+    # fp32 accumulation of 9*C terms: round-off scales with the logit magnitude
+    tol = 3e-6 * max(1.0, float(np.abs(ref_logits).max()))
+    assert np.abs(logits.cpu().numpy().reshape(P, 64) - ref_logits).max() < tol
+    assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 20 * tol
