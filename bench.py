@@ -120,6 +120,39 @@ def kalman_roofline(device, S=256, T=64, H=60, W=80):
             'avg_launch_ms': round(ms, 4)}
 
 
+def kalman_fuse_roofline(device, P=256 * 64 * 4800):
+    """KFNet.BuildKFCoord alone: 48 B/px = 32 read + 16 written, all HBM."""
+    import torch
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(1)
+    pred = torch.randn(P * 4, generator=g)
+    pred[3::4] = pred[3::4].abs() * 0.3 + 0.05
+    meas = pred.flip(0).contiguous()
+    meas[3::4] = meas[3::4].abs() * 0.3 + 0.05
+    pred, meas = pred.to(device), meas.to(device)
+    out = torch.empty(P * 4, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        _lib.check(lib.kfn_kalman_fuse(pred.data_ptr(), meas.data_ptr(), out.data_ptr(), None, P, stream), 'fuse')
+    launch()
+    torch.cuda.synchronize()
+    reps = 5
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = P * 48.0 / (ms * 1e-3) / 1e9
+    return {'kernel': 'kalman_fuse_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+            'shape': 'P=%d px, 48 B/px (BuildKFCoord only)' % P, 'avg_launch_ms': round(ms, 4)}
+
+
 def cpu_baseline(frames, W, T4, steps):
     """Reference-faithful CPU restatement (oracle/kfnet_oracle_torch.py): both towers on a
     2-frame batch per step, 64 materialised shifts, unfused ops (KFNet/eval.py:41,77-104)."""
@@ -251,6 +284,7 @@ def main():
                               'tflops': round(r[2] / (r[3] * 1e-3) / 1e12, 1) if r[2] else None} for r in top]
         if not args.no_kalman_roofline:
             out['roofline_kalman'] = kalman_roofline(device)
+            out['roofline_kalman_fuse'] = kalman_fuse_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames_all[need_prev:need_prev + max(args.cpu_steps, 2)]
             cb, cpu_recs = cpu_baseline(host_frames, Wt, T4, args.cpu_steps)

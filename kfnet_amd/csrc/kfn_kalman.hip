@@ -10,7 +10,7 @@
 //   eval.py loop body          KFNet/eval.py:87-126    (reset, NIS output gate, state
 //                                                       feedback, ApplyTransform, 1/sigma)
 //
-// One workgroup (1024 threads = 16 wavefronts) per sequence.  The [H*W] x (x,y,z,sigma)
+// One workgroup (768 threads = 12 wavefronts at 60x80) per sequence.  The [H*W] x (x,y,z,sigma)
 // state lives in LDS as float4 (76.8 KB at 60x80) for the whole scan, so the 4-tap warp
 // gather never touches HBM; per frame the kernel streams 28 B/px of inputs (flow 8,
 // sigma_trans 4, measurement 16) and 16 B/px of records from/to HBM, and the inputs of
@@ -24,7 +24,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KT = 1024;  // threads per sequence
 
 struct KalmanArgs {
   const f32x2* flow;
@@ -43,22 +42,27 @@ struct PixIn {
   f32x4 z;
 };
 
-template <int PPT>
+// DBL: the state is double-buffered in LDS (2 x 76.8 KB at 60x80): frame t gathers from
+// buffer t&1 and writes the fused state straight into the other one -- one barrier per
+// frame and no per-thread copy of the new state.  Grids whose two copies exceed the
+// 160 KB LDS use the single-buffer form (fuse into registers, barrier, write back, barrier).
+template <int KT, int PPT, bool DBL, bool PREFETCH>
 __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_k[];
-  f32x4* st = reinterpret_cast<f32x4*>(smem_k);
+  f32x4* st_base = reinterpret_cast<f32x4*>(smem_k);
   const int tid = threadIdx.x;
   const int s = blockIdx.x;
   const int H = a.d.H, W = a.d.W, HW = H * W, T = a.d.T;
   const float eps2 = a.d.min_uncertainty * a.d.min_uncertainty;
   const float xmax = (float)(W - 1), ymax = (float)(H - 1);
+  const bool want_nis = (a.opt_nis != nullptr) || (a.d.nis_gate > 0.f);
 
   // state -> LDS
-  for (int p = tid; p < HW; p += KT) st[p] = a.state[(size_t)s * HW + p];
+  for (int p = tid; p < HW; p += KT) st_base[p] = a.state[(size_t)s * HW + p];
 
   const size_t seq_off = (size_t)s * T * HW;
-  PixIn cur[PPT], nxt[PPT];
-  auto load_inputs = [&](int t, PixIn* dst) {
+  PixIn cur[PPT], nxt[PREFETCH ? PPT : 1];
+  auto load_inputs = [&](int t, auto& dst) {
     const size_t off = seq_off + (size_t)t * HW;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -70,109 +74,126 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
       }
     }
   };
-  load_inputs(0, cur);
+  if (PREFETCH) load_inputs(0, cur);
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) load_inputs(t + 1, nxt);
+    if constexpr (PREFETCH) {
+      if (t + 1 < T) load_inputs(t + 1, nxt);
+    } else {
+      load_inputs(t, cur);
+    }
     const int gi = a.d.t0 + t;
     const bool reset = a.d.reset_period > 0 && (gi % a.d.reset_period) == 0;
     const size_t off = seq_off + (size_t)t * HW;
-    f32x4 newst[PPT];
+    const f32x4* st = DBL ? st_base + (t & 1) * HW : st_base;
+    f32x4* st_new = DBL ? st_base + ((t + 1) & 1) * HW : st_base;
+    f32x4 newst[DBL ? 1 : PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      int p = tid + k * KT;
-      if (p >= HW) continue;
-      const f32x4 z = cur[k].z;  // (zx, zy, zz, sigma_z)
-      f32x4 outv;                // record before transform: (x, y, z, sigma)
-      if (reset) {
-        // eval.py:94-101: state := measurement, outputs := measurement
-        newst[k] = z;
-        outv = z;
-        if (a.opt_temp) a.opt_temp[off + p] = z;
-        if (a.opt_nis) {
-          a.opt_nis[(off + p) * 3 + 0] = 0.f;
-          a.opt_nis[(off + p) * 3 + 1] = 0.f;
-          a.opt_nis[(off + p) * 3 + 2] = 0.f;
+      const int p = tid + k * KT;
+      if (p < HW) {
+        const f32x4 z = cur[k].z;  // (zx, zy, zz, sigma_z)
+        f32x4 outv;                // record before transform: (x, y, z, sigma)
+        f32x4 nv;
+        if (reset) {
+          // eval.py:94-101: state := measurement, outputs := measurement
+          nv = z;
+          outv = z;
+          if (a.opt_temp) a.opt_temp[off + p] = z;
+          if (a.opt_nis) {
+            a.opt_nis[(off + p) * 3 + 0] = 0.f;
+            a.opt_nis[(off + p) * 3 + 1] = 0.f;
+            a.opt_nis[(off + p) * 3 + 2] = 0.f;
+          }
+        } else {
+          const int y = p / W, x = p - y * W;
+          // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
+          const float px = (float)x + cur[k].flow.x;
+          const float py = (float)y + cur[k].flow.y;
+          // bilinear_sampler (tools/util.py:36-93)
+          const float x0 = floorf(px), x1 = x0 + 1.0f;
+          const float y0 = floorf(py), y1 = y0 + 1.0f;
+          const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+          const float y0s = fminf(fmaxf(y0, 0.f), ymax), y1s = fminf(fmaxf(y1, 0.f), ymax);
+          const float wx0 = x1s - px, wx1 = px - x0s;
+          const float wy0 = y1s - py, wy1 = py - y0s;
+          const int ix0 = (int)x0s, ix1 = (int)x1s, iy0 = (int)y0s, iy1 = (int)y1s;
+          const f32x4 im00 = st[iy0 * W + ix0];
+          const f32x4 im01 = st[iy1 * W + ix0];
+          const f32x4 im10 = st[iy0 * W + ix1];
+          const f32x4 im11 = st[iy1 * W + ix1];
+          const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
+          const f32x4 g = ((w00 * im00 + w01 * im01) + w10 * im10) + w11 * im11;  // add_n order
+          // variance propagation (KFNet.py:393-401)
+          const float last_var = fmaxf(g.w * g.w, eps2);
+          const float trans_var = fmaxf(cur[k].st * cur[k].st, eps2);
+          const float temp_unc = sqrtf(trans_var + last_var);
+          // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
+          const float lv = temp_unc * temp_unc;
+          const float mv = z.w * z.w;
+          const float K = lv / (lv + mv);
+          const float om = fmaxf(1.0f - K, 0.0f);
+          nv.x = om * g.x + K * z.x;
+          nv.y = om * g.y + K * z.y;
+          nv.z = om * g.z + K * z.z;
+          nv.w = sqrtf(om * lv);
+          outv = nv;  // eval.py:103-104: the raw KF state (nv) is what is fed back
+          if (want_nis) {
+            // GetNIS (KFNet.py:164-184)
+            const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
+            const float iv = iu * iu;
+            const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
+            const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
+            if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
+              // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
+              outv.x = z.x; outv.y = z.y; outv.z = z.z;
+            }
+            if (a.opt_nis) {
+              a.opt_nis[(off + p) * 3 + 0] = n0;
+              a.opt_nis[(off + p) * 3 + 1] = n1;
+              a.opt_nis[(off + p) * 3 + 2] = n2;
+            }
+          }
+          if (a.opt_temp) {
+            f32x4 tv = {g.x, g.y, g.z, temp_unc};
+            a.opt_temp[off + p] = tv;
+          }
         }
-      } else {
-        const int y = p / W, x = p - y * W;
-        // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
-        const float px = (float)x + cur[k].flow.x;
-        const float py = (float)y + cur[k].flow.y;
-        // bilinear_sampler (tools/util.py:36-93)
-        const float x0 = floorf(px), x1 = x0 + 1.0f;
-        const float y0 = floorf(py), y1 = y0 + 1.0f;
-        const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
-        const float y0s = fminf(fmaxf(y0, 0.f), ymax), y1s = fminf(fmaxf(y1, 0.f), ymax);
-        const float wx0 = x1s - px, wx1 = px - x0s;
-        const float wy0 = y1s - py, wy1 = py - y0s;
-        const int ix0 = (int)x0s, ix1 = (int)x1s, iy0 = (int)y0s, iy1 = (int)y1s;
-        const f32x4 im00 = st[iy0 * W + ix0];
-        const f32x4 im01 = st[iy1 * W + ix0];
-        const f32x4 im10 = st[iy0 * W + ix1];
-        const f32x4 im11 = st[iy1 * W + ix1];
-        const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
-        f32x4 g = ((w00 * im00 + w01 * im01) + w10 * im10) + w11 * im11;  // add_n order
-        // variance propagation (KFNet.py:393-401)
-        const float last_var = fmaxf(g.w * g.w, eps2);
-        const float trans_var = fmaxf(cur[k].st * cur[k].st, eps2);
-        const float temp_unc = sqrtf(trans_var + last_var);
-        // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
-        const float lv = temp_unc * temp_unc;
-        const float mv = z.w * z.w;
-        const float K = lv / (lv + mv);
-        const float om = fmaxf(1.0f - K, 0.0f);
-        f32x4 kf;
-        kf.x = om * g.x + K * z.x;
-        kf.y = om * g.y + K * z.y;
-        kf.z = om * g.z + K * z.z;
-        kf.w = sqrtf(om * lv);
-        newst[k] = kf;  // eval.py:103-104: raw KF state is fed back
-        outv = kf;
-        // GetNIS (KFNet.py:164-184)
-        const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
-        const float iv = iu * iu;
-        const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
-        const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
-        if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
-          // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
-          outv.x = z.x; outv.y = z.y; outv.z = z.z;
+        if (DBL) st_new[p] = nv; else newst[DBL ? 0 : k] = nv;
+        // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
+        f32x4 r;
+        if (a.d.has_transform) {
+          const float* M = a.d.transform;
+          r.x = ((M[0] * outv.x + M[1] * outv.y) + M[2] * outv.z) + M[3];
+          r.y = ((M[4] * outv.x + M[5] * outv.y) + M[6] * outv.z) + M[7];
+          r.z = ((M[8] * outv.x + M[9] * outv.y) + M[10] * outv.z) + M[11];
+        } else {
+          r.x = outv.x; r.y = outv.y; r.z = outv.z;
         }
-        if (a.opt_temp) {
-          f32x4 tv = {g.x, g.y, g.z, temp_unc};
-          a.opt_temp[off + p] = tv;
-        }
-        if (a.opt_nis) {
-          a.opt_nis[(off + p) * 3 + 0] = n0;
-          a.opt_nis[(off + p) * 3 + 1] = n1;
-          a.opt_nis[(off + p) * 3 + 2] = n2;
-        }
+        r.w = 1.0f / outv.w;
+        a.rec[off + p] = r;
       }
-      // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
-      f32x4 r;
-      if (a.d.has_transform) {
-        const float* M = a.d.transform;
-        r.x = ((M[0] * outv.x + M[1] * outv.y) + M[2] * outv.z) + M[3];
-        r.y = ((M[4] * outv.x + M[5] * outv.y) + M[6] * outv.z) + M[7];
-        r.z = ((M[8] * outv.x + M[9] * outv.y) + M[10] * outv.z) + M[11];
-      } else {
-        r.x = outv.x; r.y = outv.y; r.z = outv.z;
+      // keep the unrolled pixels sequential: interleaving them only multiplies live
+      // temporaries (the 128-VGPR budget of a 1024-thread workgroup is tight)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!DBL) {
+      __syncthreads();  // every gather of frame t done
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        int p = tid + k * KT;
+        if (p < HW) st_base[p] = newst[DBL ? 0 : k];
       }
-      r.w = 1.0f / outv.w;
-      a.rec[off + p] = r;
     }
-    __syncthreads();  // every gather of frame t done
+    if constexpr (PREFETCH) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      int p = tid + k * KT;
-      if (p < HW) st[p] = newst[k];
+      for (int k = 0; k < PPT; ++k) cur[k] = nxt[k];
     }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) cur[k] = nxt[k];
-    __syncthreads();  // new state visible
+    __syncthreads();  // new state visible, old buffer free
   }
-  for (int p = tid; p < HW; p += KT) a.state[(size_t)s * HW + p] = st[p];
+  const f32x4* st_fin = DBL ? st_base + (T & 1) * HW : st_base;
+  for (int p = tid; p < HW; p += KT) a.state[(size_t)s * HW + p] = st_fin[p];
 }
 
 // KFNet.BuildKFCoord alone (KFNet/KFNet.py:148-162), optional GetNIS (:164-184):
@@ -204,10 +225,10 @@ __global__ __launch_bounds__(256) void kalman_fuse_kernel(const f32x4* __restric
   }
 }
 
-template <int PPT>
+template <int KT, int PPT, bool DBL, bool PREFETCH>
 int launch_scan(const KalmanArgs& a, hipStream_t stream) {
-  const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4);
-  auto kern = kalman_scan_kernel<PPT>;
+  const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
+  auto kern = kalman_scan_kernel<KT, PPT, DBL, PREFETCH>;
   static bool attr_done = false;
   if (!attr_done) {
     KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -243,10 +264,14 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
   a.opt_nis = opt_nis;
   a.d = *d;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int ppt = kfn::ceil_div(HW, KT);
-  if (ppt <= 5) return launch_scan<5>(a, s);
-  if (ppt <= 8) return launch_scan<8>(a, s);
-  return launch_scan<10>(a, s);
+  // 768 threads (12 wavefronts, 170-VGPR budget) x 7 pixels cover the 60x80 grid without
+  // register spills; larger grids fall back to 1024 threads and the single-buffer form.
+  const bool dbl = (size_t)HW * 32 <= 160 * 1024;  // two LDS copies of the state fit
+  if (dbl && HW <= 768 * 7) return launch_scan<768, 7, true, true>(a, s);
+  // single LDS copy: 512 threads (256-VGPR budget), inputs loaded per frame (no cross-frame prefetch)
+  if (HW <= 512 * 10) return launch_scan<512, 10, false, false>(a, s);
+  if (HW <= 512 * 16) return launch_scan<512, 16, false, false>(a, s);
+  return launch_scan<512, 20, false, false>(a, s);
 }
 
 extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis,
