@@ -106,6 +106,17 @@ int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
  * measured launch times to kernel names. */
 int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles);
 
+/* Winograd F(2x2,3x3) variant for 3x3 stride-1 SAME convolutions (same arguments and
+ * result as kfn_conv2d_nhwc up to fp32 round-off, 2.25x fewer MFMA FLOPs): 16 GEMMs on the
+ * MFMA kernel with the B^T d B input transform evaluated in its loader, then A^T M A +
+ * bias + ReLU.  u_packed = [16][cout_pad][Cin], group g = 4*xi+nu holding (G g G^T)[xi][nu]
+ * transposed to [co][ci]; workspace >= kfn_winograd_workspace_bytes(desc).
+ * phases: 3 = whole convolution; 1 = only the 16 GEMMs, 2 = only the output transform
+ * (lets a profiler time the two kernels separately). */
+int kfn_winograd_workspace_bytes(const kfn_conv_desc* desc, size_t* bytes);
+int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* u_packed,
+                        const float* bias, float* y, float* workspace, int phases, void* stream);
+
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
  * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature
  * tower's preprocess + feat1 (KFNet/KFNet.py:317-320) in ONE pass over the image.

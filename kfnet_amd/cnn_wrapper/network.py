@@ -12,8 +12,8 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, pack_bias,
-                     pack_conv_kernel, pack_deconv_kernel, pack_first_kernel)
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, pack_bias,
+                     pack_conv_kernel, pack_deconv_kernel, pack_first_kernel, pack_winograd_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -172,8 +172,16 @@ class Network(object):
             return y
         n, h, w, cin = input.shape
         y = g.tensor((n, _same_out(h, strides), _same_out(w, strides), filters), name=name)
-        kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_conv_kernel)
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
+        wmin = g.winograd_min_channels
+        if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
+                and min(h, w) >= 8):
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_kernel)
+            op = WinogradConvOp(name, input, y, kern, bias, relu, None)
+            op.workspace = g.winograd_workspace(op.workspace_bytes())
+            self._emit(op)
+            return y
+        kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_conv_kernel)
         self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu))
         return y
 

@@ -74,8 +74,18 @@ __device__ __forceinline__ int swz(int r) {
   return BK == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3);
 }
 
-template <int TM, int TN, int WM, int WN, int BK, bool TRANSPOSED>
+// MODE_CONV: tf.layers.conv2d; MODE_DECONV: conv2d_transpose (stride 2);
+// MODE_WINO: the 16 GEMMs of Winograd F(2x2,3x3) for 3x3 stride-1 SAME convs -- group
+// g = (xi,nu) = tile % 16, A rows are 2x2 output tiles whose B^T d B input transform is
+// evaluated on the fly in the loader (4 signed source pixels per element), B = the
+// pre-transformed weights U_g = (G g G^T)[xi][nu], output = M_g [tiles][Cout] workspace.
+constexpr int MODE_CONV = 0, MODE_DECONV = 1, MODE_WINO = 2;
+
+template <int TM, int TN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
+  constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
+  constexpr bool WINO = (MODE == MODE_WINO);
+  constexpr int NSRC = WINO ? 4 : 1;  // global loads per A quad
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int NT = 64 * WM * WN;
@@ -97,8 +107,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int wm = wave / WN;
   const int wn = wave % WN;
 
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int nwg = p.tiles_m * p.tiles_n * (WINO ? 16 : 1);
+  int tile = xcd_remap(blockIdx.x, nwg);
+  int grp = 0;
+  if (WINO) {  // group fastest: the 16 GEMMs of one (m,n) tile run together and share the
+    grp = tile & 15;  // same source pixels through the XCD's L2
+    tile >>= 4;
+  }
   const int tn = tile % p.tiles_n;
   const int tm = tile / p.tiles_n;
   const int m0 = tm * BM;
@@ -116,8 +131,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
       (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w) + (size_t)grp * p.cout_pad * p.Ktot, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread im2col row state -------------------------------------------------
   // conv:        a_off = byte offset of input pixel (iy0, ix0) (may be "negative" = wrapped;
@@ -126,7 +141,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   unsigned a_off[AP];
   unsigned a_msk[AP];
   int a_y[AP], a_x[AP];
-  const int ntaps = p.kh * p.kw;
+  unsigned a_w4[WINO ? AP : 1][4];  // WINO: byte offsets of the 4 signed source pixels (or OOB)
+  const int ntaps = WINO ? 1 : p.kh * p.kw;
+  // B^T rows of F(2x2,3x3): V[xi] = sa*d[ra] + sb*d[rb]
+  const int w_xi = grp >> 2, w_nu = grp & 3;
+  const int w_ra = (w_xi == 0) ? 0 : 1, w_rb = (w_xi == 3) ? 3 : 2;
+  const int w_ca = (w_nu == 0) ? 0 : 1, w_cb = (w_nu == 3) ? 3 : 2;
+  const float w_sra = (w_xi == 2) ? -1.f : 1.f, w_srb = (w_xi == 0 || w_xi == 3) ? -1.f : 1.f;
+  const float w_sca = (w_nu == 2) ? -1.f : 1.f, w_scb = (w_nu == 0 || w_nu == 3) ? -1.f : 1.f;
+  const float w_s00 = w_sra * w_sca, w_s01 = w_sra * w_scb, w_s10 = w_srb * w_sca, w_s11 = w_srb * w_scb;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int r = r0 + i * RPP;
@@ -156,7 +179,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         ox = rem - oy * p.Wo;
       }
       unsigned msk = 0;
-      if (TRANSPOSED) {
+      if (WINO) {
+        // (oy, ox) is the 2x2 output tile; its 4x4 input patch starts at (2*oy-1, 2*ox-1)
+        const int ys[2] = {2 * oy - 1 + w_ra, 2 * oy - 1 + w_rb};
+        const int xs[2] = {2 * ox - 1 + w_ca, 2 * ox - 1 + w_cb};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const bool ok = ((unsigned)ys[a] < (unsigned)p.H) && ((unsigned)xs[b] < (unsigned)p.W);
+            a_w4[WINO ? i : 0][a * 2 + b] =
+                ok ? (unsigned)(((n_img * p.H + ys[a]) * p.W + xs[b]) * p.ldx + q * 4) * 4u : OOB;
+          }
+        msk = 1u;
+      } else if (TRANSPOSED) {
         const int by = oy + p.pad_t, bx = ox + p.pad_l;
         a_y[i] = by;
         a_x[i] = bx;
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  f32x4 ga[AP], gb[BP];
+  f32x4 ga[AP * NSRC], gb[BP];
 
   // ---- stage iterator of the LOAD stream (compute only counts stages) ---------------
   const int kchunks = p.Cin / BK;
@@ -231,7 +267,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // Issue the global loads of the stage the iterator points at (all-OOB = zeros once the
   // iterator has run off the end: keeps the loop body branch-free).
   auto load_one = [&](int k, bool live, unsigned adelta, unsigned bdelta, int ky, int kx, int tap) {
-    if (k < AP) {
+    if (WINO && k < AP * NSRC) {
+      const unsigned base = a_w4[WINO ? k / NSRC : 0][k % NSRC];
+      ga[k] = buf_load(rsA, live ? base + (unsigned)ld_c0 * 4u : OOB);
+    } else if (k < AP) {
       const int i = k;
       unsigned vo;
       if (TRANSPOSED) {
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo : OOB;
       ga[i] = buf_load(rsA, vo);
     } else {
-      const int i = k - AP;
+      const int i = k - AP * NSRC;
       gb[i] = buf_load(rsB, live ? b_off[i] + bdelta : OOB);
     }
   };
@@ -255,8 +294,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   auto store_one = [&](int k, int buf) {
     if (k < AP) {
       const int i = k;
+      f32x4 v;
+      if (WINO) {  // B^T d B for this (xi,nu): four signed source pixels
+        v = w_s00 * ga[i * NSRC + 0];
+        v += w_s01 * ga[i * NSRC + (WINO ? 1 : 0)];
+        v += w_s10 * ga[i * NSRC + (WINO ? 2 : 0)];
+        v += w_s11 * ga[i * NSRC + (WINO ? 3 : 0)];
+      } else {
+        v = ga[i];
+      }
       if (AP * RPP == BM || r0 + i * RPP < BM)
-        *reinterpret_cast<f32x4*>(As + buf * A_ELEMS + wr_off + i * RPP * BK) = ga[i];
+        *reinterpret_cast<f32x4*>(As + buf * A_ELEMS + wr_off + i * RPP * BK) = v;
     } else {
       const int i = k - AP;
       if (BP * RPP == BN || r0 + i * RPP < BN)
@@ -280,7 +328,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + b_rd + (k - TM) * 32 * BK + rdq[c]);
   };
 
-  constexpr int NLD = AP + BP;     // global loads == LDS stores per stage
+  constexpr int NLD = AP * NSRC + BP;  // global loads per stage
+  constexpr int NST = AP + BP;         // LDS stores per stage
   constexpr int NFR = TM + TN;     // fragment reads per chunk
   constexpr int J = 4 * TM * TN;   // MFMAs per chunk
 
@@ -294,7 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
       advance();
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) store_one(k, 0);
+      for (int k = 0; k < NST; ++k) store_one(k, 0);
     }
     {
       const bool live = ld_tap < 32;
@@ -333,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         constexpr int LOADC = (NCH > 2) ? 1 : NCH - 1;  // chunk that carries the global loads
         // side ops of this chunk, in issue order
         constexpr int n_rd = last ? 0 : NFR;
-        constexpr int n_st = (c == 0) ? NLD : 0;
+        constexpr int n_st = (c == 0) ? NST : 0;
         constexpr int n_ld = (c == LOADC) ? NLD : 0;
         constexpr int n_side = n_rd + n_st + n_ld;
         constexpr int jspan = last ? J / 2 : J;  // in the last chunk side ops ride the first half
@@ -416,7 +465,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           const int op = out_pix[m - m0];
           if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
         } else {
-          if (n_ok && m < p.M) p.y[(size_t)m * p.ldy + n] = v;
+          if (n_ok && m < p.M) p.y[((size_t)grp * p.M + m) * p.ldy + n] = v;
         }
       }
     }
@@ -438,27 +487,27 @@ const TileCfg* find_cfg(int cfg) {
   return nullptr;
 }
 
-template <int TM, int TN, int WM, int WN, int BK, bool TR>
+template <int TM, int TN, int WM, int WN, int BK, int MODE>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
   constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
-  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, TR>;
+  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, MODE>;
   static bool attr_done = false;  // benign race: idempotent attribute
   if (!attr_done) {
     KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  dim3 grid(a.tiles_m * a.tiles_n), block(NT);
+  dim3 grid(a.tiles_m * a.tiles_n * (MODE == MODE_WINO ? 16 : 1)), block(NT);
   hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
   KFN_LAUNCH_CHECK("conv_mfma_kernel");
   return KFN_OK;
 }
 
-template <int BK, bool TR>
+template <int BK, int TR>
 int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
     case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK, TR>(a, s);
@@ -597,9 +646,133 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->transposed) {
-    if (d->Cin % 32 == 0) return dispatch_cfg<32, true>(cfg, a, s);
-    return dispatch_cfg<16, true>(cfg, a, s);
+    if (d->Cin % 32 == 0) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
+    return dispatch_cfg<16, MODE_DECONV>(cfg, a, s);
   }
-  if (d->Cin % 32 == 0) return dispatch_cfg<32, false>(cfg, a, s);
-  return dispatch_cfg<16, false>(cfg, a, s);
+  if (d->Cin % 32 == 0) return dispatch_cfg<32, MODE_CONV>(cfg, a, s);
+  return dispatch_cfg<16, MODE_CONV>(cfg, a, s);
+}
+
+// ------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) path for 3x3 stride-1 SAME convs: 16 GEMMs (MODE_WINO above) into a
+// [16][tiles][Cout] workspace, then the A^T M A output transform + bias + ReLU.
+// ------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ ws,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, int Ho, int Wo, int Th,
+                                                          int Tw, int Cout, int ldy, int relu, long Mt) {
+  const int C4 = Cout >> 2;
+  const long total = Mt * C4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const long t = idx / C4;
+    f32x4 m[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      m[g] = *reinterpret_cast<const f32x4*>(ws + ((size_t)g * Mt + t) * Cout + c4 * 4);
+    // A^T = [[1,1,1,0],[0,1,-1,-1]]
+    f32x4 r0[4], r1[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      r0[nu] = (m[0 * 4 + nu] + m[1 * 4 + nu]) + m[2 * 4 + nu];
+      r1[nu] = (m[1 * 4 + nu] - m[2 * 4 + nu]) - m[3 * 4 + nu];
+    }
+    f32x4 o[4];
+    o[0] = (r0[0] + r0[1]) + r0[2];
+    o[1] = (r0[1] - r0[2]) - r0[3];
+    o[2] = (r1[0] + r1[1]) + r1[2];
+    o[3] = (r1[1] - r1[2]) - r1[3];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+    const int tx = (int)(t % Tw);
+    const long t2 = t / Tw;
+    const int ty = (int)(t2 % Th);
+    const long n = t2 / Th;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        if (oy < Ho && ox < Wo) {
+          f32x4 v = o[a * 2 + b] + bv;
+          if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          *reinterpret_cast<f32x4*>(y + ((size_t)(n * Ho + oy) * Wo + ox) * ldy + c4 * 4) = v;
+        }
+      }
+  }
+}
+
+int wino_validate(const kfn_conv_desc* d) {
+  int rc = validate(d);
+  if (rc != KFN_OK) return rc;
+  KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed,
+              "kfn_conv2d_winograd: only 3x3 stride-1 SAME convolutions");
+  KFN_REQUIRE(d->Cout % 4 == 0 && d->ldy % 4 == 0, "kfn_conv2d_winograd: Cout and ldy must be multiples of 4");
+  KFN_REQUIRE(d->epilogue == KFN_EPI_NONE, "kfn_conv2d_winograd: fused head epilogues are not supported");
+  return KFN_OK;
+}
+
+}  // namespace
+
+extern "C" int kfn_winograd_workspace_bytes(const kfn_conv_desc* d, size_t* bytes) {
+  KFN_REQUIRE(d && bytes, "kfn_winograd_workspace_bytes: null argument");
+  int rc = wino_validate(d);
+  if (rc != KFN_OK) return rc;
+  const size_t Mt = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  *bytes = 16 * Mt * (size_t)d->Cout * sizeof(float);
+  return KFN_OK;
+}
+
+extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const float* u_packed,
+                                   const float* bias, float* y, float* workspace, int phases,
+                                   void* stream) {
+  KFN_REQUIRE(d && x && u_packed && y && workspace, "kfn_conv2d_winograd: null argument");
+  int rc = wino_validate(d);
+  if (rc != KFN_OK) return rc;
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u_packed) |
+                reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+              "kfn_conv2d_winograd: buffers must be 16-byte aligned");
+  const int Th = (d->H + 1) / 2, Tw = (d->W + 1) / 2;
+  const long Mt = (long)d->N * Th * Tw;
+  ConvArgs a;
+  a.x = x; a.w = u_packed; a.bias = nullptr; a.y = workspace;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
+  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->Cout;
+  a.kh = 1; a.kw = 1; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
+  a.relu = 0; a.epilogue = KFN_EPI_NONE;
+  a.Ho = Th; a.Wo = Tw;  // row index space of the GEMMs = 2x2 output tiles
+  a.Ktot = d->Cin;
+  const long in_pix = (long)d->N * d->H * d->W;
+  const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
+  const long w_bytes = (long)d->cout_pad * a.Ktot * 4L;  // one group
+  const long img_bytes = (long)d->H * d->W * d->ldx * 4L;
+  const long imgs_per_tile = 160 / ((long)Th * Tw) + 2;
+  KFN_REQUIRE(Mt < (1L << 31) && w_bytes < (1L << 31) && img_bytes * imgs_per_tile < (1L << 31),
+              "kfn_conv2d_winograd: tensor too large for 32-bit buffer addressing");
+  a.M = (int)Mt;
+  a.x_bytes = (unsigned long long)x_bytes;
+  a.w_bytes = (unsigned)w_bytes;
+  a.tiles_m = a.tiles_n = 0;
+  int cfg = d->config;
+  if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, d->Cout, num_cu());
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  KFN_REQUIRE(phases >= 1 && phases <= 3, "kfn_conv2d_winograd: phases must be 1 (GEMMs), 2 (output) or 3");
+  if (phases & 1) {
+    rc = (d->Cin % 32 == 0) ? dispatch_cfg<32, MODE_WINO>(cfg, a, s) : dispatch_cfg<16, MODE_WINO>(cfg, a, s);
+    if (rc != KFN_OK) return rc;
+  }
+  if (!(phases & 2)) return KFN_OK;
+  int Ho, Wo, pt, pl;
+  out_shape(d, &Ho, &Wo, &pt, &pl);
+  const long total = Mt * (d->Cout / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256L * 64) blocks = 256L * 64;
+  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, bias, y, Ho, Wo, Th,
+                     Tw, d->Cout, d->ldy, d->relu, Mt);
+  KFN_LAUNCH_CHECK("wino_output_kernel");
+  return KFN_OK;
 }

@@ -213,6 +213,21 @@ def pack_conv_kernel(w):
     return out
 
 
+_WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+
+
+def pack_winograd_kernel(w):
+    """TF HWIO [3,3,Cin,Cout] -> U [16][cout_pad][Cin] with U[4*xi+nu] = (G g G^T)[xi][nu]
+    (Winograd F(2x2,3x3) weight transform, evaluated in fp64, rounded once to fp32)."""
+    kh, kw, ci, co = w.shape
+    assert kh == 3 and kw == 3
+    cp = -(-co // 32) * 32
+    U = np.einsum('ai,ijco,bj->abco', _WINO_G, w.astype(np.float64), _WINO_G)  # [4,4,ci,co]
+    out = np.zeros((16, cp, ci), dtype=np.float32)
+    out[:, :co, :] = np.transpose(U.reshape(16, ci, co), (0, 2, 1)).astype(np.float32)
+    return out
+
+
 def pack_deconv_kernel(w):
     """TF conv2d_transpose [kh,kw,Cout,Cin] -> [cout_pad][kh*kw*Cin]."""
     kh, kw, co, ci = w.shape
@@ -280,6 +295,38 @@ class ConvOp(Op):
         rc = lib.kfn_conv2d_nhwc(C.byref(d), self.x.ptr, self.kernel.ptr,
                                  self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_nhwc[%s]' % self.name)
+
+
+class WinogradConvOp(ConvOp):
+    """3x3 stride-1 SAME conv through kfn_conv2d_winograd (2.25x fewer MFMA FLOPs)."""
+
+    def __init__(self, name, x, y, kernel, bias, relu, workspace):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+        self.workspace = workspace  # Storage shared by all Winograd layers of the graph
+
+    def kernel_name(self, lib):
+        d = self.desc()
+        n, h, w, _ = self.x.shape
+        d.N, d.H, d.W, d.kh, d.kw = d.N * ((h + 1) // 2) * ((w + 1) // 2), 1, 1, 1, 1
+        cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (bk.value,))
+
+    def mfma_flops(self):
+        """FLOPs the 16 GEMMs actually execute (algorithmic flops() stays the nominal 2*M*N*K)."""
+        n, ho, wo, cout = self.y.shape
+        return 2.0 * 16 * n * ((ho + 1) // 2) * ((wo + 1) // 2) * cout * self.x.shape[3]
+
+    def workspace_bytes(self):
+        n, ho, wo, cout = self.y.shape
+        return 16 * n * ((ho + 1) // 2) * ((wo + 1) // 2) * cout * 4
+
+    def launch(self, lib, stream, phases=3):
+        d = self.desc()
+        rc = lib.kfn_conv2d_winograd(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                     self.bias.ptr if self.bias is not None else None, self.y.ptr,
+                                     self.workspace.ptr, phases, stream)
+        _lib.check(rc, 'kfn_conv2d_winograd[%s]' % self.name)
 
 
 class FirstConvOp(Op):
@@ -445,6 +492,11 @@ class Graph(object):
         self.device = None
         self.debug_prob = False
         self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
+        # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
+        # (0 disables).  Below ~128 channels the [16][tiles][Cout] workspace traffic outweighs
+        # the 2.25x MFMA saving.
+        self.winograd_min_channels = 128
+        self.winograd_ws = None
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 
     # -- construction -------------------------------------------------------------------
@@ -459,6 +511,14 @@ class Graph(object):
     def add(self, op):
         self.ops.append(op)
         return op
+
+    def winograd_workspace(self, nbytes):
+        """One workspace shared by all Winograd layers (they run one after the other)."""
+        if self.winograd_ws is None:
+            self.winograd_ws = Storage(0, 'f32')
+            self.storages.append(self.winograd_ws)
+        self.winograd_ws.numel = max(self.winograd_ws.numel, (nbytes + 3) // 4)
+        return self.winograd_ws
 
     def variable(self, name, shape, pack):
         full = (current_scope() + '/' + name) if current_scope() else name

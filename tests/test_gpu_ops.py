@@ -333,3 +333,40 @@ def test_flow_head_vs_oracle(Cc):
     tol = 3e-6 * max(1.0, float(np.abs(ref_logits).max()))
     assert np.abs(logits.cpu().numpy().reshape(P, 64) - ref_logits).max() < tol
     assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 20 * tol
+
+
+WINO_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (3, 12, 16, 64, 36),
+              (1, 5, 5, 32, 4), (2, 10, 6, 48, 64)]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+@pytest.mark.parametrize('config', [0, 1, 3, 6])
+def test_winograd_conv_vs_oracle(case, config):
+    """kfn_conv2d_winograd == kfn_conv2d_nhwc == oracle up to fp32 round-off (incl. odd sizes,
+    where the last 2x2 tile overhangs, strided output, bias + ReLU)."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy = co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=1, relu=1, config=config)
+    nb = C.c_size_t()
+    _lib.check(lib.kfn_winograd_workspace_bytes(C.byref(d), C.byref(nb)), 'ws')
+    ws = torch.empty(nb.value // 4, device='cuda')
+    y = torch.full((n * h * w, ldy), -5.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_kernel(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                       ws.data_ptr(), 3, stream()), 'wino')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, co:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
+    assert err <= 3 * _conv_tol(x, wt), err
