@@ -284,7 +284,7 @@ def main():
             'executed_mfma_tflops': round(tf_exec, 2), 'executed_frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'note': ('achieved = ALGORITHMIC (direct-convolution) FLOPs / time; kernels tagged <...,2> run the 16 GEMMs '
                      'of Winograd F(2x2,3x3), which execute 16/36 of those FLOPs on the fp32 MFMA pipe (executed_*), so '
-                     'frac may exceed 1; <...,false> is the direct implicit GEMM'),
+                     'frac may exceed 1; <...,0> is the direct implicit GEMM, <...,1> the transposed conv'),
             'launches_per_batch': n_dom,
             'algorithmic_gflop_per_launch_avg': round(fl_dom / n_dom / 1e9, 3),
             'avg_launch_ms': round(ms_dom / n_dom, 4),

@@ -19,6 +19,7 @@
 // barrier per stage).
 #include "kfn_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -41,6 +42,7 @@ struct ConvArgs {
   int tiles_m, tiles_n;
   unsigned long long x_bytes;
   unsigned w_bytes;
+  int rot_mode;  // K-chunk rotation: 0 off, 1 per (m,n) tile, 2 per (m,n,group)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -254,11 +256,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int kchunks = p.Cin / BK;
   const int n_stages = __builtin_popcount(tapmask) * kchunks;
   int ld_tap = tapmask ? __builtin_ctz(tapmask) : 32;
-  int ld_c0 = 0;
+  // Concurrent workgroups walk the Cin chunks in ROTATED order: with NHWC the pixel stride
+  // is Cin*4 bytes (4 KiB at Cin = 1024), so workgroups in lockstep would all read the same
+  // byte range modulo the pixel stride and pile onto the same L2 channels/sets.
+  const int rot = (p.rot_mode == 0) ? 0 : ((tm * 7 + tn * 3 + (p.rot_mode == 2 ? grp * 5 : 0)) % kchunks);
+  int ld_ci = 0;
+  int ld_c0 = rot * BK;
   auto advance = [&]() {
+    ++ld_ci;
     ld_c0 += BK;
-    if (ld_c0 >= p.Cin) {
-      ld_c0 = 0;
+    if (ld_c0 >= p.Cin) ld_c0 = 0;
+    if (ld_ci >= kchunks) {
+      ld_ci = 0;
+      ld_c0 = rot * BK;
       const unsigned rest = (ld_tap < 31) ? (tapmask & ~((2u << ld_tap) - 1u)) : 0u;
       ld_tap = rest ? __builtin_ctz(rest) : 32;
     }
@@ -379,7 +389,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         constexpr int c = decltype(cc)::value;
         constexpr int slot = c & 1;
         constexpr bool last = (c == NCH - 1);
-        constexpr int LOADC = (NCH > 2) ? 1 : NCH - 1;  // chunk that carries the global loads
+        // chunk that carries the global loads (issuing them in chunk 0 right behind the stores
+        // was measured slightly slower)
+        constexpr int LOADC = (NCH > 2) ? 1 : NCH - 1;
         // side ops of this chunk, in issue order
         constexpr int n_rd = last ? 0 : NFR;
         constexpr int n_st = (c == 0) ? NST : 0;
@@ -539,6 +551,15 @@ int auto_config(int M, int Cout, int num_cu) {
 
 int g_num_cu = 0;
 
+int rot_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("KFN_CONV_ROT");
+    mode = e ? atoi(e) : 0;  // measured: no effect on MI355X (326.4 / 326.5 / 326.6 fps for 0/1/2)
+  }
+  return mode;
+}
+
 int num_cu() {
   if (g_num_cu == 0) {
     int dev = 0;
@@ -642,6 +663,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   a.x_bytes = (unsigned long long)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
+  a.rot_mode = rot_mode();
 
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -757,6 +779,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   a.x_bytes = (unsigned long long)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
+  a.rot_mode = rot_mode();
   int cfg = d->config;
   if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, d->Cout, num_cu());
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

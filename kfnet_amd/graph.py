@@ -288,7 +288,7 @@ class ConvOp(Op):
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
         t = self.CFG_TILE[cfg.value]
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %s>' % (t + (bk.value, 'true' if self.transposed else 'false'))
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d>' % (t + (bk.value, 1 if self.transposed else 0))
 
     def launch(self, lib, stream):
         d = self.desc()
