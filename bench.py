@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=17,
                     help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--autotune', action='store_true',
+                    help='time every tile config per layer at start-up (the heuristic is within ~2%% of it)')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kalman-roofline', action='store_true')
     ap.add_argument('--height', type=int, default=480)
@@ -220,7 +222,7 @@ def main():
     need_prev = 1 if lo > 0 else 0
     frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
-                      max_chunk=max(K, Wm, B), device=str(device))
+                      max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune)
     dev_all = eng.upload_frames(frames_all)
     dev_prev = dev_all[0] if need_prev else None
     dev_frames = dev_all[need_prev:]
@@ -298,6 +300,8 @@ def main():
                                        for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])}
         out['per_kernel_ms_per_batch'] = {r[0] + ('#%d' % i): round(r[3], 4) for i, r in enumerate(rows)}
         top = sorted(rows, key=lambda r: -r[3])[:6]
+        if eng.tuned:
+            out['autotuned_tile_config'] = {k.split('@')[0]: v[0] for k, v in eng.tuned.items()}
         out['top_layers'] = [{'op': r[0], 'ms': round(r[3], 3),
                               'tflops': round(r[2] / (r[3] * 1e-3) / 1e12, 1) if r[2] else None} for r in top]
         if not args.no_kalman_roofline:

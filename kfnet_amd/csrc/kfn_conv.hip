@@ -491,7 +491,7 @@ struct TileCfg {
 const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87}, {KFN_CFG_128x128, 128, 128, 0.84},
                          {KFN_CFG_192x64, 192, 64, 0.78},   {KFN_CFG_128x64, 128, 64, 0.72},
                          {KFN_CFG_256x32, 256, 32, 0.70},   {KFN_CFG_128x32, 128, 32, 0.52},
-                         {KFN_CFG_64x64, 64, 64, 0.50}};
+                         {KFN_CFG_64x64, 64, 64, 0.50},     {KFN_CFG_160x256, 160, 256, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -529,6 +529,7 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK, TR>(a, s);
     case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, BK, TR>(a, s);
     case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR>(a, s);
+    case KFN_CFG_160x256: return launch_cfg<5, 1, 1, 8, BK, TR>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }
@@ -550,6 +551,26 @@ int auto_config(int M, int Cout, int num_cu) {
 }
 
 int g_num_cu = 0;
+
+// k-step per mode.  BK = 16 halves the LDS tile (36 KiB at 160x128) so THREE workgroups fit a
+// CU (VGPR-limited to 3 waves/SIMD): measured +3 % (160x128), +16 % (192x64), +33 % (256x32)
+// over BK = 32 on the direct kernel.  The Winograd GEMMs sit at 256 VGPRs (2 workgroups
+// per CU either way) and prefer the longer BK = 32 stage (-4.5 % with 16).
+// KFN_CONV_BK=16|32 overrides both for experiments.
+int bk_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("KFN_CONV_BK");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+int pick_bk(int cin, int mode) {
+  if (cin % 32 != 0) return 16;
+  const int o = bk_override();
+  if (o == 16 || o == 32) return o;
+  return mode == MODE_WINO ? 32 : 16;
+}
 
 int rot_mode() {
   static int mode = -1;
@@ -626,7 +647,7 @@ extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int
   *config = pick_config(d, M);
   const TileCfg* c = find_cfg(*config);
   KFN_REQUIRE(c, "kfn_conv2d_plan: unknown config %d", *config);
-  *bk = (d->Cin % 32 == 0) ? 32 : 16;
+  *bk = pick_bk(d->Cin, d->transposed ? MODE_DECONV : MODE_CONV);
   *tiles = kfn::ceil_div(M, c->bm) * kfn::ceil_div(d->Cout, c->bn);
   return KFN_OK;
 }
@@ -668,10 +689,10 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d->transposed) {
-    if (d->Cin % 32 == 0) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
+    if (pick_bk(d->Cin, MODE_DECONV) == 32) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
     return dispatch_cfg<16, MODE_DECONV>(cfg, a, s);
   }
-  if (d->Cin % 32 == 0) return dispatch_cfg<32, MODE_CONV>(cfg, a, s);
+  if (pick_bk(d->Cin, MODE_CONV) == 32) return dispatch_cfg<32, MODE_CONV>(cfg, a, s);
   return dispatch_cfg<16, MODE_CONV>(cfg, a, s);
 }
 
@@ -785,7 +806,8 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   KFN_REQUIRE(phases >= 1 && phases <= 3, "kfn_conv2d_winograd: phases must be 1 (GEMMs), 2 (output) or 3");
   if (phases & 1) {
-    rc = (d->Cin % 32 == 0) ? dispatch_cfg<32, MODE_WINO>(cfg, a, s) : dispatch_cfg<16, MODE_WINO>(cfg, a, s);
+    rc = (pick_bk(d->Cin, MODE_WINO) == 32) ? dispatch_cfg<32, MODE_WINO>(cfg, a, s)
+                                            : dispatch_cfg<16, MODE_WINO>(cfg, a, s);
     if (rc != KFN_OK) return rc;
   }
   if (!(phases & 2)) return KFN_OK;

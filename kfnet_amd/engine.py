@@ -30,7 +30,7 @@ def grid_size(image_hw):
 
 class KFNetEngine(object):
     def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
-                 nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False):
+                 nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False):
         import torch
         self.torch = torch
         self.B = int(batch)
@@ -76,6 +76,11 @@ class KFNetEngine(object):
         self.heavy_ops = self.net.frame_ops + self.net.pair_ops
         self.handover = self.net.scan_ops[1]
         self._staging = None
+        self.tuned = None
+        if autotune:
+            g.active = (self.B, self.B)
+            self.tuned = g.autotune(self.heavy_ops)
+            g.active = (1, 1)
 
     # ------------------------------------------------------------------------------
     def _stream(self):

@@ -280,7 +280,7 @@ class ConvOp(Op):
         return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
 
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
-                6: (2, 1, 4, 1), 7: (3, 1, 2, 2)}
+                6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8)}
 
     def kernel_name(self, lib):
         """Template instantiation this op launches, spelled like rocprofv3 prints it."""
@@ -310,7 +310,8 @@ class WinogradConvOp(ConvOp):
         d.N, d.H, d.W, d.kh, d.kw = d.N * ((h + 1) // 2) * ((w + 1) // 2), 1, 1, 1, 1
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (bk.value,))
+        wbk = 32 if self.x.shape[3] % 32 == 0 else 16   # the Winograd GEMMs keep the long k-step
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (wbk,))
 
     def mfma_flops(self):
         """FLOPs the 16 GEMMs actually execute (algorithmic flops() stays the nominal 2*M*N*K)."""
@@ -569,6 +570,40 @@ class Graph(object):
                 op.launch(lib, stream)
         finally:
             self.active = (1, 1)
+
+    def autotune(self, ops=None, reps=2, verbose=False):
+        """Pick the fastest tile configuration for every MFMA conv launch by timing all of
+        them once on the live buffers (a few seconds at engine start-up).  Layer outputs
+        are overwritten with identical results, so this is safe before the first run."""
+        import torch
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        chosen = {}
+        for op in (ops if ops is not None else self.ops):
+            if not isinstance(op, ConvOp) or op.epilogue == _lib.EPI_L2NORM:
+                continue
+            best = None
+            for cfg in (1, 2, 3, 4, 5, 6, 7):
+                op.config = cfg
+                try:
+                    op.launch(lib, stream)   # warm / validity
+                except _lib.KfnError:
+                    continue
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    op.launch(lib, stream)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                if best is None or ms < best[0]:
+                    best = (ms, cfg)
+            op.config = best[1] if best else _lib.CFG_AUTO
+            chosen[op.name + '@%d' % id(op)] = (op.config, best[0] if best else None)
+            if verbose:
+                print('autotune %-12s -> cfg %d (%.3f ms)' % (op.name, op.config, best[0] if best else -1))
+        return chosen
 
     def total_flops(self):
         return sum(op.flops() for op in self.ops if hasattr(op, 'flops'))
