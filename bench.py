@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=17,
                     help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--one-stream', action='store_true', help='serialise the two towers on one stream')
     ap.add_argument('--autotune', action='store_true',
                     help='time every tile config per layer at start-up (the heuristic is within ~2%% of it)')
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -223,6 +224,7 @@ def main():
     frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
                       max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune)
+    eng.two_streams = not args.one_stream
     dev_all = eng.upload_frames(frames_all)
     dev_prev = dev_all[0] if need_prev else None
     dev_frames = dev_all[need_prev:]

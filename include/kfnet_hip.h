@@ -115,6 +115,7 @@ int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles)
  * phases: 3 = whole convolution; 1 = only the 16 GEMMs, 2 = only the output transform
  * (lets a profiler time the two kernels separately). */
 int kfn_winograd_workspace_bytes(const kfn_conv_desc* desc, size_t* bytes);
+int kfn_winograd_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles); /* cf. kfn_conv2d_plan */
 int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* u_packed,
                         const float* bias, float* y, float* workspace, int phases, void* stream);
 

@@ -486,12 +486,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
 struct TileCfg {
   int cfg, bm, bn;
-  double prior;  // measured MFMA utilisation of the instantiation on large problems
+  double prior;   // measured MFMA utilisation of the instantiation on large problems (direct)
+  double wprior;  // same for the Winograd GEMMs (k-step 16: 128x128 keeps 3 workgroups per CU)
 };
-const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87}, {KFN_CFG_128x128, 128, 128, 0.84},
-                         {KFN_CFG_192x64, 192, 64, 0.78},   {KFN_CFG_128x64, 128, 64, 0.72},
-                         {KFN_CFG_256x32, 256, 32, 0.70},   {KFN_CFG_128x32, 128, 32, 0.52},
-                         {KFN_CFG_64x64, 64, 64, 0.50},     {KFN_CFG_160x256, 160, 256, 0.0}};
+const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x128, 128, 128, 0.87, 0.77},
+                         {KFN_CFG_192x64, 192, 64, 0.78, 0.66},   {KFN_CFG_128x64, 128, 64, 0.76, 0.66},
+                         {KFN_CFG_256x32, 256, 32, 0.70, 0.45},   {KFN_CFG_128x32, 128, 32, 0.60, 0.45},
+                         {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -535,13 +536,13 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
 }
 
 // Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) over the CUs.
-int auto_config(int M, int Cout, int num_cu) {
+int auto_config(int M, int Cout, int num_cu, bool wino = false) {
   double best = -1.0;
   int best_cfg = KFN_CFG_128x32;
   for (const TileCfg& c : kCfgs) {
     long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn);
     long rounds = (tiles + num_cu - 1) / num_cu;
-    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn) * c.prior;
+    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn) * (wino ? c.wprior : c.prior);
     if (eff > best) {
       best = eff;
       best_cfg = c.cfg;
@@ -554,8 +555,8 @@ int g_num_cu = 0;
 
 // k-step per mode.  BK = 16 halves the LDS tile (36 KiB at 160x128) so THREE workgroups fit a
 // CU (VGPR-limited to 3 waves/SIMD): measured +3 % (160x128), +16 % (192x64), +33 % (256x32)
-// over BK = 32 on the direct kernel.  The Winograd GEMMs sit at 256 VGPRs (2 workgroups
-// per CU either way) and prefer the longer BK = 32 stage (-4.5 % with 16).
+// over BK = 32 on the direct kernel.  The Winograd GEMMs need the 128x128 tile for that
+// (166 VGPRs; the 160x128 one has 205): 128x128x16 beats 160x128x32 by 1-7 %.
 // KFN_CONV_BK=16|32 overrides both for experiments.
 int bk_override() {
   static int v = -1;
@@ -569,7 +570,7 @@ int pick_bk(int cin, int mode) {
   if (cin % 32 != 0) return 16;
   const int o = bk_override();
   if (o == 16 || o == 32) return o;
-  return mode == MODE_WINO ? 32 : 16;
+  return 16;
 }
 
 int rot_mode() {
@@ -770,6 +771,19 @@ extern "C" int kfn_winograd_workspace_bytes(const kfn_conv_desc* d, size_t* byte
   return KFN_OK;
 }
 
+extern "C" int kfn_winograd_plan(const kfn_conv_desc* d, int* config, int* bk, int* tiles) {
+  KFN_REQUIRE(d && config && bk && tiles, "kfn_winograd_plan: null argument");
+  int rc = wino_validate(d);
+  if (rc != KFN_OK) return rc;
+  const int Mt = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  *config = d->config == KFN_CFG_AUTO ? auto_config(Mt, d->Cout, num_cu(), true) : d->config;
+  const TileCfg* c = find_cfg(*config);
+  KFN_REQUIRE(c, "kfn_winograd_plan: unknown config %d", *config);
+  *bk = pick_bk(d->Cin, MODE_WINO);
+  *tiles = 16 * kfn::ceil_div(Mt, c->bm) * kfn::ceil_div(d->Cout, c->bn);
+  return KFN_OK;
+}
+
 extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const float* u_packed,
                                    const float* bias, float* y, float* workspace, int phases,
                                    void* stream) {
@@ -802,7 +816,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   a.tiles_m = a.tiles_n = 0;
   a.rot_mode = rot_mode();
   int cfg = d->config;
-  if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, d->Cout, num_cu());
+  if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, d->Cout, num_cu(), true);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   KFN_REQUIRE(phases >= 1 && phases <= 3, "kfn_conv2d_winograd: phases must be 1 (GEMMs), 2 (output) or 3");
   if (phases & 1) {

@@ -76,6 +76,19 @@ class KFNetEngine(object):
         self.heavy_ops = self.net.frame_ops + self.net.pair_ops
         self.handover = self.net.scan_ops[1]
         self._staging = None
+        # Two-stream schedule of the heavy phase: the measurement tower (SCoordNet, MFMA-dense
+        # big tiles) on the main stream, the flow-feature tower + OFlowNet (many small
+        # launches that cannot fill the chip alone) on a side stream; they only share the
+        # fused first-layer kernel.
+        first = self.net.frame_ops[0]
+        side = [op for op in self.net.frame_ops[1:] if op in self.net.feat_tower.ops] + self.net.pair_ops
+        self.main_ops = [op for op in self.net.frame_ops[1:] if op not in side]
+        self.side_ops = side
+        self.first_op = first
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.ev_first = torch.cuda.Event()
+        self.ev_side = torch.cuda.Event()
+        self.two_streams = True
         self.tuned = None
         if autotune:
             g.active = (self.B, self.B)
@@ -124,7 +137,17 @@ class KFNetEngine(object):
         for s0 in range(0, T, self.B):
             cnt = min(self.B, T - s0)
             self._set_batch_images(dev_frames, s0, cnt, stream)
-            self.graph.run(stream, self.heavy_ops, active=(cnt, self.B))   # partial batches cost their share
+            if self.two_streams:
+                main = self.torch.cuda.current_stream(self.device)
+                self.graph.run(stream, [self.first_op], active=(cnt, self.B))
+                self.ev_first.record(main)
+                self.side_stream.wait_event(self.ev_first)
+                self.graph.run(self.side_stream.cuda_stream, self.side_ops, active=(cnt, self.B))
+                self.ev_side.record(self.side_stream)
+                self.graph.run(stream, self.main_ops, active=(cnt, self.B))
+                main.wait_event(self.ev_side)
+            else:
+                self.graph.run(stream, self.heavy_ops, active=(cnt, self.B))   # partial batches cost their share
             lib = self.lib
             _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + s0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
             _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + s0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')

@@ -306,12 +306,9 @@ class WinogradConvOp(ConvOp):
 
     def kernel_name(self, lib):
         d = self.desc()
-        n, h, w, _ = self.x.shape
-        d.N, d.H, d.W, d.kh, d.kw = d.N * ((h + 1) // 2) * ((w + 1) // 2), 1, 1, 1, 1
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
-        _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
-        wbk = 32 if self.x.shape[3] % 32 == 0 else 16   # the Winograd GEMMs keep the long k-step
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (wbk,))
+        _lib.check(lib.kfn_winograd_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_winograd_plan')
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (bk.value,))
 
     def mfma_flops(self):
         """FLOPs the 16 GEMMs actually execute (algorithmic flops() stays the nominal 2*M*N*K)."""
