@@ -34,18 +34,21 @@ def run_chunk(eng, dev_frames, first_frame, rank, world, dist=None, dev_prev_fra
             raise ValueError('chunk starting at frame %d needs the preceding frame' % first_frame)
         eng.prime(dev_prev_frame)          # flow features of frame first_frame-1, recomputed locally
     eng.heavy(dev_frames, T)               # state-independent: no waiting on other ranks
+    # RCCL ('nccl') moves the device tensor directly over xGMI; with the 'gloo' backend (CPU
+    # tests, or several ranks sharing one GPU) the 76.8 KB message is staged through the host.
+    via_host = dist is not None and world > 1 and dist.get_backend() != 'nccl'
     if dist is not None and world > 1 and rank > 0:
         state = eng.get_state()
-        if dep:
-            dist.recv(state, src=rank - 1)  # the 76.8 KB hand-off
-        else:
-            # keep the send/recv pairing uniform: the message is sent but ignored by a
-            # chunk that resets on its first frame
-            tmp = state.clone()
-            dist.recv(tmp, src=rank - 1)
+        buf = state.cpu() if via_host else (state if dep else state.clone())
+        dist.recv(buf, src=rank - 1)       # the 76.8 KB hand-off
+        if dep and via_host:
+            state.copy_(buf)
+        # (a chunk that resets on its first frame still receives, to keep the send/recv
+        #  pairing uniform, but ignores the message)
     eng.scan(T, first_frame)
     if dist is not None and world > 1 and rank + 1 < world:
-        dist.send(eng.get_state(), dst=rank + 1)
+        state = eng.get_state()
+        dist.send(state.cpu() if via_host else state, dst=rank + 1)
     return eng.records(T)
 
 

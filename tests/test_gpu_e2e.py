@@ -98,3 +98,24 @@ def test_chunked_equals_single_pass():
     eng3.get_state().copy_(state)
     b = eng3.process(dev[3:], t0=3).cpu().numpy().copy()
     assert np.array_equal(np.concatenate([a, b]), one)
+
+
+def test_two_rank_bench_on_one_gpu(tmp_path):
+    """bench.py's multi-rank path (frame sharding, priming, state hand-off, barriers, max-over-
+    ranks timing) with 2 ranks sharing this GPU over gloo; the RCCL transport itself needs
+    one GPU per rank and is exercised by the driver's multi-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KFN_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29617', os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--steps', '6', '--warmup', '2', '--batch', '2', '--height', '64', '--width', '96',
+           '--no-kalman-roofline']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['frames_total'] == 12 and out['value'] > 0
