@@ -126,11 +126,12 @@ class KFNetEngine(object):
         self.handover.src = ring.batch(1, 1)
         self.handover.launch(self.lib, stream)
 
-    def heavy(self, dev_frames, T=None):
-        """State-independent phase for frames [0,T) of `dev_frames` -> chunk scan buffers."""
+    def heavy(self, dev_frames, T=None, dst0=0):
+        """State-independent phase for frames [0,T) of `dev_frames` -> chunk scan buffers
+        (frame t lands in slot dst0 + t)."""
         T = dev_frames.shape[0] if T is None else T
-        if T > self.max_chunk:
-            raise ValueError('chunk of %d frames exceeds max_chunk=%d' % (T, self.max_chunk))
+        if dst0 + T > self.max_chunk:
+            raise ValueError('chunk of %d frames (at slot %d) exceeds max_chunk=%d' % (T, dst0, self.max_chunk))
         stream = self._stream()
         ring = self.net.temp_feat_maps
         hw = self.hw
@@ -149,9 +150,10 @@ class KFNetEngine(object):
             else:
                 self.graph.run(stream, self.heavy_ops, active=(cnt, self.B))   # partial batches cost their share
             lib = self.lib
-            _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + s0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
-            _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + s0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')
-            _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + s0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
+            d0 = dst0 + s0
+            _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + d0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
+            _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + d0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')
+            _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + d0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
             self.handover.src = ring.batch(cnt, 1)
             self.handover.launch(lib, stream)
 
@@ -167,6 +169,36 @@ class KFNetEngine(object):
         self.heavy(dev_frames, T)
         self.scan(T, t0)
         return self.records(T)
+
+    def process_sequences(self, dev_seqs):
+        """Batch-of-sequences (BASELINE config 5): `dev_seqs` is a uint8 device tensor
+        [S,T,H,W,3] of S independent sequences.  The heavy phase runs sequence after
+        sequence (each restarts the feature ring at its reset frame 0); then ONE scan launch
+        advances all S Kalman filters in lockstep, one workgroup per sequence.
+        Returns the records [S,T,h,w,4] (torch device tensor)."""
+        torch = self.torch
+        S, T = int(dev_seqs.shape[0]), int(dev_seqs.shape[1])
+        if S * T > self.max_chunk:
+            raise ValueError('S*T = %d exceeds max_chunk=%d' % (S * T, self.max_chunk))
+        if self.reset_period <= 0 or 0 % self.reset_period != 0:
+            raise ValueError('batch-of-sequences needs every sequence to start on a reset frame')
+        hw = self.hw
+        lib, stream = self.lib, self._stream()
+        # stage every sequence's scan inputs at [s*T, (s+1)*T) of the chunk buffers
+        for s in range(S):
+            self.heavy(dev_seqs[s], T, dst0=s * T)
+        states = torch.zeros(S * hw * 4, device=self.device)
+        rec = torch.empty(S * T * hw * 4, device=self.device)
+        d = _lib.KalmanDesc(S=S, T=T, H=self.h, W=self.w, t0=0, reset_period=self.reset_period,
+                            min_uncertainty=self.net.min_uncertainty, nis_gate=self.nis_gate,
+                            has_transform=int(self.transform is not None))
+        if self.transform is not None:
+            for i, v in enumerate(np.asarray(self.transform, np.float32)[:3, :4].reshape(-1)):
+                d.transform[i] = float(v)
+        import ctypes as C
+        _lib.check(lib.kfn_kalman_scan(C.byref(d), self.c_flow.ptr, self.c_sigma.ptr, self.c_meas.ptr,
+                                       states.data_ptr(), rec.data_ptr(), None, None, stream), 'kfn_kalman_scan')
+        return rec.view(S, T, self.h, self.w, 4)
 
     def records(self, T):
         buf = self.c_rec.root_storage.buf

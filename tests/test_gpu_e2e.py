@@ -119,3 +119,38 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['frames_total'] == 12 and out['value'] > 0
+
+
+def test_config5_shape_batch_of_sequences():
+    """BASELINE config 5 geometry in fp32: 540x960 frames -> 68x120 grid (odd 135-row level,
+    SAME pad (1,1) there; state sized by ceil), two independent sequences advanced
+    by one batched scan launch; against the torch-CPU oracle."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    seqs = np.stack([synthetic_sequence(2, 540, 960, seed=3), synthetic_sequence(2, 540, 960, seed=4)])
+    T4 = np.eye(4, dtype=np.float32)
+    eng = KFNetEngine(W, image_size=(540, 960), batch=2, transform=T4, reset_period=500, max_chunk=4)
+    import torch
+    rec = eng.process_sequences(torch.from_numpy(seqs).cuda()).cpu().numpy()
+    assert rec.shape == (2, 2, 68, 120, 4)
+    for s in range(2):
+        ref = OT.eval_sequence(seqs[s], W, T4, reset_period=500)
+        _check(rec[s], ref)
+
+
+def test_eval_cli_writes_npy(tmp_path):
+    """kfnet_amd.KFNet.eval keeps the reference's flags and coord_<i>.npy output contract
+    (KFNet/eval.py:121-126): float32 [60,80,4] = (T.x, 1/sigma)."""
+    from kfnet_amd.KFNet import eval as kf_eval
+    out = tmp_path / 'out'
+    out.mkdir()
+    rc = kf_eval.main(['--scene', 'heads', '--output_folder', str(out), '--synthetic', '3', '--random_weights',
+                       '--batch', '2'])
+    assert rc == 0
+    files = sorted(p.name for p in out.iterdir())
+    assert files == ['coord_0.npy', 'coord_1.npy', 'coord_2.npy']
+    a = np.load(out / 'coord_1.npy')
+    assert a.shape == (60, 80, 4) and a.dtype == np.float32 and np.all(np.isfinite(a)) and np.all(a[..., 3] > 0)
+    assert kf_eval.main(['--scene', 'nowhere']) == 1   # KFNet/train.py:142-144: invalid scene
