@@ -82,7 +82,7 @@ def per_kernel_profile(eng, dev_frames):
             rows.append((op.name + ':out', 'wino_output_kernel', 0.0, ms2, 0.0))
             continue
         ms = timed(lambda: op.launch(eng.lib, stream))
-        tag = op.kernel_name(eng.lib) if isinstance(op, ConvOp) else op.name.split('[')[0] + '_kernel'
+        tag = op.kernel_name(eng.lib) if hasattr(op, 'kernel_name') else op.name.split('[')[0] + '_kernel'
         fl = op.flops() if hasattr(op, 'flops') else 0.0
         rows.append((op.name, tag, fl, ms, fl))
     return rows

@@ -134,6 +134,15 @@ int kfn_first_conv_u8(const uint8_t* img, int N, int H, int W,
 int kfn_cost_volume(const float* f1, const float* f2, float* vol, int N, int H, int W, int C,
                     int window, void* stream);
 
+/* BuildCoordVolume fused into OFlowNet's first conv (cnn_wrapper/OFlowNet.py:19, 3x3 SAME on
+ * the 8x8 window grid): y[p, i, j, :] = act(conv0(vol)[p, i, j, :]) with vol generated inside
+ * the MFMA kernel's loader (window fixed at 8, kernel 3x3); the 39 MB/frame volume never
+ * exists in HBM.  f1, f2 [N,H,W,C] (C % 16 == 0); w_packed [cout_pad][9*C] as for
+ * kfn_conv2d_nhwc; y [N*H*W, 8, 8, Cout] with pixel stride ldy. */
+int kfn_cost_volume_conv(const float* f1, const float* f2, const float* w_packed, const float* bias,
+                         float* y, int N, int H, int W, int C, int Cout, int cout_pad, int ldy,
+                         int relu, int config, void* stream);
+
 /* ---- softmax over the window cells + soft-argmax flow ---------------------------------
  * OFlowNet.GetOutput softmax (OFlowNet.py:45-47) + KFNet.BuildOFlowNet flow
  * (KFNet/KFNet.py:381-385): flow[p] = sum_k softmax(logits[p])_k * (j-w/2, i-w/2).

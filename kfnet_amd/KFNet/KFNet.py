@@ -17,7 +17,8 @@ from .. import _lib
 from ..cnn_wrapper.network import Network
 from ..cnn_wrapper.OFlowNet import OFlowNet
 from ..cnn_wrapper.SCoordNet import SCoordNet
-from ..graph import (CostVolumeOp, Graph, KalmanScanOp, MemcpyOp, Tensor, variable_scope)
+from ..graph import (ConvOp, CostVolumeConvOp, CostVolumeOp, Graph, KalmanScanOp, MemcpyOp, Tensor,
+                     variable_scope)
 
 
 class KFNetDataSpec():
@@ -241,4 +242,24 @@ class KFNet():
             prob, transition_uncertainty = coord_flow_net.GetOutput()
         self.oflownet = coord_flow_net
         self.prob = prob
+        self._fuse_cost_volume(diff_feats, feat_map1, feat_map2, window_size)
         return prob.flow, transition_uncertainty
+
+    def _fuse_cost_volume(self, vol, feat_map1, feat_map2, window_size):
+        """Replace (cost_volume launch, conv0 launch reading the volume) by ONE launch that
+        generates the volume in conv0's loader; the [BHW,8,8,C] tensor is then never allocated."""
+        g = self.graph
+        if not g.fuse_cost_volume or window_size != 8:
+            return
+        cv = [op for op in g.ops if isinstance(op, CostVolumeOp) and op.vol is vol]
+        c0 = [op for op in g.ops if isinstance(op, ConvOp) and op.x is vol]
+        if len(cv) != 1 or len(c0) != 1 or c0[0].kh != 3 or c0[0].stride != 1 or c0[0].transposed:
+            return
+        conv0 = c0[0]
+        fused = CostVolumeConvOp(feat_map1, feat_map2, conv0.y, conv0.kernel, conv0.bias, conv0.relu, window_size)
+        g.ops[g.ops.index(conv0)] = fused
+        g.ops.remove(cv[0])
+        net_ops = self.oflownet.ops
+        net_ops[net_ops.index(conv0)] = fused
+        if vol.storage in g.storages:
+            g.storages.remove(vol.storage)

@@ -58,6 +58,7 @@ SYMBOLS = {
     'kfn_conv2d_winograd': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'kfn_cost_volume_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'kfn_flow_head': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -31,6 +31,7 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that always fails the buffer r
 
 struct ConvArgs {
   const float* x;
+  const float* x2;  // MODE_CVOL: f2 (x is f1)
   const float* w;
   const float* bias;
   float* y;
@@ -81,13 +82,17 @@ __device__ __forceinline__ int swz(int r) {
 // g = (xi,nu) = tile % 16, A rows are 2x2 output tiles whose B^T d B input transform is
 // evaluated on the fly in the loader (4 signed source pixels per element), B = the
 // pre-transformed weights U_g = (G g G^T)[xi][nu], output = M_g [tiles][Cout] workspace.
-constexpr int MODE_CONV = 0, MODE_DECONV = 1, MODE_WINO = 2;
+// MODE_CVOL: OFlowNet conv0 (3x3 on the 8x8 window grid) with the local cost volume
+// V[p,i,j,:] = f2[p] - f1[p + (i-4, j-4)] (KFNet/KFNet.py:343-359) generated in the loader:
+// the 39 MB/frame volume is never materialised, f1/f2 (614 KB each) stay L2-resident.
+constexpr int MODE_CONV = 0, MODE_DECONV = 1, MODE_WINO = 2, MODE_CVOL = 3;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
   constexpr bool WINO = (MODE == MODE_WINO);
-  constexpr int NSRC = WINO ? 4 : 1;  // global loads per A quad
+  constexpr bool CVOL = (MODE == MODE_CVOL);
+  constexpr int NSRC = WINO ? 4 : (CVOL ? 2 : 1);  // global loads per A quad
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int NT = 64 * WM * WN;
@@ -127,11 +132,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // The A descriptor is re-based at the first image this tile touches, so 32-bit byte
   // offsets only have to span the few images of ONE tile (activations may exceed 2 GiB).
   const int HoWo = p.Ho * p.Wo;
-  const int n_first = TRANSPOSED ? 0 : m0 / HoWo;
+  const int n_first = TRANSPOSED ? 0 : (CVOL ? (m0 >> 6) / (p.H * p.W) : m0 / HoWo);
   const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
   const unsigned long long a_rest = p.x_bytes - a_base;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
+      (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(  // CVOL: f2 (same shape as f1)
+      const_cast<char*>(reinterpret_cast<const char*>(CVOL ? p.x2 : p.x)) + a_base, 0,
       (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w) + (size_t)grp * p.cout_pad * p.Ktot, 0, p.w_bytes, 0x00020000);
@@ -144,6 +152,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   unsigned a_msk[AP];
   int a_y[AP], a_x[AP];
   unsigned a_w4[WINO ? AP : 1][4];  // WINO: byte offsets of the 4 signed source pixels (or OOB)
+  unsigned a_off2[CVOL ? AP : 1];   // CVOL: byte offset of f2[p]
+  unsigned a_msk2[CVOL ? AP : 1];   // CVOL: taps whose shifted f1 pixel is inside the image
   const int ntaps = WINO ? 1 : p.kh * p.kw;
   // B^T rows of F(2x2,3x3): V[xi] = sa*d[ra] + sb*d[rb]
   const int w_xi = grp >> 2, w_nu = grp & 3;
@@ -161,6 +171,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     a_y[i] = a_x[i] = 0;
     if (r < BM && m < p.M) {
       int n_img, oy, ox;
+      if (CVOL) {
+        // row = (pixel pp, window cell (wi, wj)); conv0 slides over the 8x8 window grid
+        const int pp = m >> 6, pos = m & 63;
+        const int HW = p.H * p.W;
+        const int n_abs = pp / HW;
+        const int rem = pp - n_abs * HW;
+        n_img = n_abs - n_first;
+        oy = rem / p.W;          // pixel coordinates of pp in the feature map
+        ox = rem - oy * p.W;
+        const int wi = pos >> 3, wj = pos & 7;
+        unsigned m1 = 0, m2 = 0;
+        for (int t = 0; t < 9; ++t) {
+          const int ky = t / 3, kx = t - ky * 3;
+          const int ci = wi + ky - 1, cj = wj + kx - 1;          // window cell read by this tap
+          if ((unsigned)ci < 8u && (unsigned)cj < 8u) {          // else conv0's SAME zero padding
+            m1 |= 1u << t;
+            const int sy = oy + ci - 4, sx = ox + cj - 4;        // translate(): f1 shifted, 0 outside
+            if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) m2 |= 1u << t;
+          }
+        }
+        a_off[i] = (unsigned)(((n_img * p.H + oy + wi - 5) * p.W + (ox + wj - 5)) * p.ldx + q * 4) * 4u;
+        a_off2[CVOL ? i : 0] = (unsigned)((n_img * HW + rem) * p.ldx + q * 4) * 4u;
+        a_msk[i] = m1;
+        a_msk2[CVOL ? i : 0] = m2;
+        continue;
+      }
       if (TRANSPOSED) {
         // parity-class-major row order: m = cls*(N*H*W) + (n, i, j); output pixel
         // (2i + (cls>>1), 2j + (cls&1)).  All rows of a tile (bar 3 seams) then share a
@@ -280,6 +316,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     if (WINO && k < AP * NSRC) {
       const unsigned base = a_w4[WINO ? k / NSRC : 0][k % NSRC];
       ga[k] = buf_load(rsA, live ? base + (unsigned)ld_c0 * 4u : OOB);
+    } else if (CVOL && k < AP * NSRC) {
+      const int i = k / NSRC;
+      if (k % NSRC == 0) {  // f2[p]: same for every tap that lies inside the window
+        const bool ok = live && ((a_msk[i] >> tap) & 1u);
+        ga[k] = buf_load(rsA2, ok ? a_off2[CVOL ? i : 0] + (unsigned)ld_c0 * 4u : OOB);
+      } else {              // shifted f1
+        const bool ok = live && ((a_msk2[CVOL ? i : 0] >> tap) & 1u);
+        ga[k] = buf_load(rsA, ok ? a_off[i] + adelta : OOB);
+      }
     } else if (k < AP) {
       const int i = k;
       unsigned vo;
@@ -310,6 +355,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         v += w_s01 * ga[i * NSRC + (WINO ? 1 : 0)];
         v += w_s10 * ga[i * NSRC + (WINO ? 2 : 0)];
         v += w_s11 * ga[i * NSRC + (WINO ? 3 : 0)];
+      } else if (CVOL) {
+        v = ga[i * NSRC] - ga[i * NSRC + (CVOL ? 1 : 0)];   // diff_feat = feat_map2 - shift(feat_map1)
       } else {
         v = ga[i];
       }
@@ -662,7 +709,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
               "kfn_conv2d_nhwc: x / w_packed must be 16-byte aligned");
 
   ConvArgs a;
-  a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+  a.x = x; a.x2 = nullptr; a.w = w_packed; a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
@@ -796,7 +843,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   const int Th = (d->H + 1) / 2, Tw = (d->W + 1) / 2;
   const long Mt = (long)d->N * Th * Tw;
   ConvArgs a;
-  a.x = x; a.w = u_packed; a.bias = nullptr; a.y = workspace;
+  a.x = x; a.x2 = nullptr; a.w = u_packed; a.bias = nullptr; a.y = workspace;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->Cout;
   a.kh = 1; a.kw = 1; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
@@ -834,4 +881,43 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
                      Tw, d->Cout, d->ldy, d->relu, Mt);
   KFN_LAUNCH_CHECK("wino_output_kernel");
   return KFN_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// KFNet.BuildCoordVolume (KFNet/KFNet.py:343-359,372) fused into OFlowNet's conv0
+// (cnn_wrapper/OFlowNet.py:19): the 8x8 local cost volume is generated in the MFMA
+// kernel's loader (MODE_CVOL) and never written to HBM.
+// ------------------------------------------------------------------------------------
+extern "C" int kfn_cost_volume_conv(const float* f1, const float* f2, const float* w_packed,
+                                    const float* bias, float* y, int N, int H, int W, int C, int Cout,
+                                    int cout_pad, int ldy, int relu, int config, void* stream) {
+  KFN_REQUIRE(f1 && f2 && w_packed && y, "kfn_cost_volume_conv: null argument");
+  KFN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "kfn_cost_volume_conv: bad shape N=%d H=%d W=%d C=%d", N, H, W, C);
+  KFN_REQUIRE(Cout > 0 && ldy >= Cout && cout_pad >= Cout && cout_pad % 32 == 0, "kfn_cost_volume_conv: bad Cout/ldy");
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(f1) | reinterpret_cast<uintptr_t>(f2) |
+                reinterpret_cast<uintptr_t>(w_packed)) & 15) == 0, "kfn_cost_volume_conv: misaligned buffer");
+  ConvArgs a;
+  a.x = f1; a.x2 = f2; a.w = w_packed; a.bias = bias; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = C; a.ldx = C;
+  a.Cout = Cout; a.cout_pad = cout_pad; a.ldy = ldy;
+  a.kh = 3; a.kw = 3; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
+  a.relu = relu; a.epilogue = KFN_EPI_NONE;
+  a.Ho = 8; a.Wo = 8;
+  const long M = (long)N * H * W * 64;
+  const long x_bytes = (long)N * H * W * C * 4L;
+  a.Ktot = 9 * C;
+  const long w_bytes = (long)cout_pad * a.Ktot * 4L;
+  const long img_bytes = (long)H * W * C * 4L;
+  KFN_REQUIRE(M < (1L << 31) && w_bytes < (1L << 31) && 3 * img_bytes < (1L << 31),
+              "kfn_cost_volume_conv: tensor too large for 32-bit buffer addressing");
+  a.M = (int)M;
+  a.x_bytes = (unsigned long long)x_bytes;
+  a.w_bytes = (unsigned)w_bytes;
+  a.tiles_m = a.tiles_n = 0;
+  a.rot_mode = 0;
+  int cfg = config;
+  if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, Cout, num_cu());
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dispatch_cfg<16, MODE_CVOL>(cfg, a, s);
 }

@@ -373,6 +373,39 @@ class CostVolumeOp(Op):
         _lib.check(rc, 'kfn_cost_volume')
 
 
+class CostVolumeConvOp(Op):
+    """BuildCoordVolume + OFlowNet conv0 in one MFMA launch (kfn_cost_volume_conv): the cost
+    volume is generated in the kernel's loader and never written."""
+
+    def __init__(self, f1, f2, y, kernel, bias, relu, window):
+        assert window == 8
+        self.name = 'conv0[cost_volume]'
+        self.f1, self.f2, self.y, self.kernel, self.bias, self.relu = f1, f2, y, kernel, bias, relu
+        self.config = _lib.CFG_AUTO
+
+    def flops(self):
+        n, h, w, c = self.f2.shape
+        return 2.0 * n * h * w * 64 * 9 * c * self.y.shape[3]
+
+    def kernel_name(self, lib):
+        n, h, w, c = self.f2.shape
+        d = _lib.ConvDesc(N=n * h * w, H=8, W=8, Cin=c, ldx=c, Cout=self.y.shape[3],
+                          cout_pad=-(-self.y.shape[3] // 32) * 32, ldy=self.y.ld, kh=3, kw=3, stride=1, config=self.config)
+        cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
+        return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 3>' % ConvOp.CFG_TILE[cfg.value]
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.f2.shape
+        n = _scaled(n, self.f2.graph)
+        assert self.f1.ld == c and self.f2.ld == c
+        cout = self.y.shape[3]
+        rc = lib.kfn_cost_volume_conv(self.f1.ptr, self.f2.ptr, self.kernel.ptr,
+                                      self.bias.ptr if self.bias is not None else None, self.y.ptr, n, h, w, c,
+                                      cout, -(-cout // 32) * 32, self.y.ld, int(self.relu), self.config, stream)
+        _lib.check(rc, 'kfn_cost_volume_conv')
+
+
 class FlowOp(Op):
     def __init__(self, logits, flow, prob, window):
         self.name = 'flow_softargmax'
@@ -490,6 +523,7 @@ class Graph(object):
         self.device = None
         self.debug_prob = False
         self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
+        self.fuse_cost_volume = True  # BuildCoordVolume generated inside OFlowNet conv0's loader
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
         # (0 disables).  Below ~128 channels the [16][tiles][Cout] workspace traffic outweighs
         # the 2.25x MFMA saving.

@@ -370,3 +370,34 @@ def test_winograd_conv_vs_oracle(case, config):
     ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
     err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
     assert err <= 3 * _conv_tol(x, wt), err
+
+
+@pytest.mark.parametrize('shape', [(2, 7, 9, 32, 32), (1, 60, 80, 32, 32), (3, 5, 4, 16, 48)])
+def test_cost_volume_conv_vs_oracle(shape):
+    """kfn_cost_volume_conv == conv0(BuildCoordVolume(f1, f2)) of the oracle (volume generated
+    in the loader, incl. image-border zero fill of the shifted f1 and conv0's own SAME padding
+    at the window border), written into a channel window of a wider buffer."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_conv_kernel
+    lib = _lib.load()
+    N, H, W, Cc, co = shape
+    rng = np.random.default_rng(77)
+    f = rng.normal(size=(N + 1, H, W, Cc)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, Cc, co)) / np.sqrt(9 * Cc)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy, off = co + 16, 16
+    fd, wd, bd = dev(f), dev(pack_conv_kernel(wt)), dev(b)
+    y = torch.full((N * H * W * 64, ldy), -9.0, device='cuda')
+    _lib.check(lib.kfn_cost_volume_conv(fd.data_ptr(), fd.data_ptr() + H * W * Cc * 4, wd.data_ptr(), bd.data_ptr(),
+                                        y.data_ptr() + off * 4, N, H, W, Cc, co, -(-co // 32) * 32, ldy, 1, 0,
+                                        stream()), 'cvconv')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, :off] == -9.0)
+    for n in range(N):
+        vol, _ = O.coord_volume(f[n:n + 1].astype(np.float64), f[n + 1:n + 2].astype(np.float64), 8)
+        ref = O.conv2d_same(vol, wt, b, 1, True).reshape(H * W * 64, co)
+        g = got[n * H * W * 64:(n + 1) * H * W * 64, off:off + co]
+        assert np.abs(g - ref).max() < 2e-5
