@@ -154,3 +154,21 @@ def test_eval_cli_writes_npy(tmp_path):
     a = np.load(out / 'coord_1.npy')
     assert a.shape == (60, 80, 4) and a.dtype == np.float32 and np.all(np.isfinite(a)) and np.all(a[..., 3] > 0)
     assert kf_eval.main(['--scene', 'nowhere']) == 1   # KFNet/train.py:142-144: invalid scene
+
+
+def test_long_recursion_error_does_not_grow():
+    """48 frames without a reset: the recurrent state feeds back 47 times, so any systematic
+    fp32 drift of the HIP warp/fuse chain against the fp64 oracle would accumulate here."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(4321)
+    imgs = synthetic_sequence(48, 64, 96, seed=9)
+    T4 = O.get_transform(synthetic_transform())
+    ref = O.eval_sequence(imgs, W, T4, reset_period=500, dtype=np.float64)
+    eng = KFNetEngine(W, image_size=(64, 96), batch=5, transform=T4, reset_period=500, max_chunk=48)
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    _check(rec, ref)
+    d_first = np.abs(rec[1:9, ..., :3] - ref[1:9, ..., :3]).max()
+    d_last = np.abs(rec[-8:, ..., :3] - ref[-8:, ..., :3]).max()
+    assert d_last < 10 * max(d_first, 1e-7)
