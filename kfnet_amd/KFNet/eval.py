@@ -11,8 +11,9 @@ reachable from the build environment); `--random_weights` replaces the checkpoin
 Host loop semantics kept from eval.py: sequence_length = 500 irrespective of --scene
 (KFNetDataSpec() is built with the default scene), reset at i % 500 == 0,
 raw (untransformed, ungated) KF state fed back, NIS gate on the output only.
-Not reproduced: loss/accuracy/median-distance log fields (they need label maps; SURVEY
-§8(f) rank 1) and --show plotting.
+When label_list.txt is present the reference's per-frame log line (losses, accuracies, median
+distance errors in cm, NIS-in-band fraction) and the final summary are printed
+(kfnet_amd/KFNet/metrics.py).  Not reproduced: --show plotting.
 """
 import argparse
 import os
@@ -48,13 +49,23 @@ def load_images(paths, image_size):
 
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
-         frames=None, sequence_length=500, chunk=256, verbose=True):
-    """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records."""
+         frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None):
+    """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
+    With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
+    log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
+    returns (records, metrics) in that case."""
     from ..engine import KFNetEngine
+    from . import metrics as M
     T = len(image_paths) if frames is None else frames.shape[0]
+    want_metrics = label_paths is not None or labels is not None
     eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
-                      reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk)
-    records = []
+                      reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk,
+                      emit_debug=want_metrics)
+    records, all_metrics = [], []
+
+    def label(i):
+        return labels[i] if labels is not None else M.read_label(label_paths[i], image_size)
+
     for lo in range(0, T, chunk):
         hi = min(T, lo + chunk)
         host = frames[lo:hi] if frames is not None else load_images(image_paths[lo:hi], image_size)
@@ -64,9 +75,28 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         if output_folder and os.path.isdir(output_folder):
             for k in range(hi - lo):
                 np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
-        if verbose:
+        if want_metrics:
+            dbg = eng.debug(hi - lo)
+            for k in range(hi - lo):
+                i = lo + k
+                # pair schedule of KFNet/train.py:67-71: step 0 = (1, 0), step i = (i-1, i)
+                pair = (1, 0) if i == 0 else (i - 1, i)
+                reset = sequence_length > 0 and i % sequence_length == 0
+                m = M.frame_metrics(i, pair, dbg['meas'][k], dbg['temp'][k], rec[k], dbg['nis'][k],
+                                    (label(min(pair[0], T - 1)), label(pair[1])), transform, reset, (eng.h, eng.w))
+                all_metrics.append(m)
+                if verbose:
+                    print(M.format_line(m))
+        elif verbose:
             print('frames %d~%d done' % (lo, hi - 1))
-    return np.concatenate(records)
+    records = np.concatenate(records)
+    if want_metrics:
+        if verbose and all_metrics:
+            for name, fn in (('Median dist error: ', np.median), ('Mean dist error: ', np.mean), ('stddev error: ', np.std)):
+                print(name, fn([m['d_m'] for m in all_metrics]), fn([m['d_t'] for m in all_metrics]),
+                      fn([m['d_kf'] for m in all_metrics]))
+        return records, all_metrics
+    return records
 
 
 def main(argv=None):
@@ -107,7 +137,11 @@ def main(argv=None):
     print('scene: ', a.scene)
     print('image number: ', len(image_paths))
     print('----------------------------------')
-    eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, batch=a.batch)
+    label_list = os.path.join(a.input_folder, 'label_list.txt')
+    label_paths = read_lines(label_list) if os.path.exists(label_list) else None
+    if label_paths is not None:
+        assert len(image_paths) == len(label_paths)   # KFNet/eval.py:37
+    eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, batch=a.batch, label_paths=label_paths)
     return 0
 
 

@@ -172,3 +172,26 @@ def test_long_recursion_error_does_not_grow():
     d_first = np.abs(rec[1:9, ..., :3] - ref[1:9, ..., :3]).max()
     d_last = np.abs(rec[-8:, ..., :3] - ref[-8:, ..., :3]).max()
     assert d_last < 10 * max(d_first, 1e-7)
+
+
+def test_eval_with_labels_prints_reference_metrics(capsys):
+    """eval() with label maps reproduces the reference's log line fields (KFNet/eval.py:113-118)."""
+    from kfnet_amd.KFNet import eval as kf_eval
+    from kfnet_amd.KFNet import metrics as M
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    rng = np.random.default_rng(5)
+    frames = synthetic_sequence(4, 64, 96, seed=6)
+    labels = rng.normal(size=(4, 64, 96, 4)).astype(np.float32)
+    labels[..., 3] = (rng.random(size=(4, 64, 96)) > 0.3).astype(np.float32)
+    T4 = np.eye(4, dtype=np.float32)
+    rec, mets = kf_eval.eval(None, T4, synthetic_weights(3), None, image_size=(64, 96), batch=2, frames=frames,
+                             labels=labels, chunk=4)
+    assert len(mets) == 4 and mets[0]['pair'] == (1, 0) and mets[2]['pair'] == (1, 2)
+    out = capsys.readouterr().out
+    assert '2, frame 1~2, l_m = ' in out and 'Median dist error:' in out
+    gt = M.resize_nearest(labels[3], (8, 12))
+    d_kf, _ = M.dist_error(rec[3][..., :3], gt[..., :3], gt[..., 3:4])
+    assert np.isclose(mets[3]['d_kf'], d_kf)
+    assert all(np.isfinite(m[k]) for m in mets for k in ('l_m', 'l_t', 'l_kf', 'a_kf', 'nis'))
+    assert mets[0]['d_t'] == mets[0]['d_m']      # reset step: temp output := measurement
