@@ -45,6 +45,8 @@ def parse():
                     help='time every tile config per layer at start-up (the heuristic is within ~2%% of it)')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kalman-roofline', action='store_true')
+    ap.add_argument('--conv-operands', choices=['f32', 'f16'], default='f32',
+                    help="f16 = BASELINE config 5's fp16-operand convs (fp32 accumulate, fp32 Kalman); NOT the headline")
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
     return ap.parse_args()
@@ -232,7 +234,8 @@ def main():
     need_prev = 1 if lo > 0 else 0
     frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
-                      max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune)
+                      max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune,
+                      conv_operands=args.conv_operands)
     eng.two_streams = not args.one_stream
     dev_all = eng.upload_frames(frames_all)
     dev_prev = dev_all[0] if need_prev else None
@@ -265,7 +268,8 @@ def main():
     out = {
         'metric': 'frames/sec on 480x640 seq', 'value': round(fps, 3), 'unit': 'frames/s',
         'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': round(elapsed * 1e3 / K, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.conv_operands == 'f32' else 'f16 conv operands (f32 accumulate, f32 activations, f32 Kalman)',
         'data': 'synthetic (rolled random texture uint8 frames, seeded He-uniform random weights)',
         'config': {'workload': 'full KFNet (SCoordNet+OFlowNet+Kalman) %d-frame %dx%d seq per GPU, random weights'
                                % (K, args.height, args.width),

@@ -34,7 +34,7 @@ extern "C" {
 #define KFN_ERR_HIP (-2)
 #define KFN_ERR_UNSUPPORTED (-3)
 
-#define KFN_ABI_VERSION 1
+#define KFN_ABI_VERSION 2
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -81,7 +81,14 @@ typedef struct kfn_conv_desc {
   int32_t relu;         /* fuse tf.nn.relu */
   int32_t epilogue;     /* KFN_EPI_* applied after bias(+relu) */
   int32_t config;       /* 0 = auto tile choice, else KFN_CFG_* */
+  int32_t operand_dtype; /* KFN_OPERAND_F32 (exact fp32 MFMA) or KFN_OPERAND_F16: operands rounded
+                          * to fp16 while staged, fp32 accumulate on v_mfma_f32_32x32x16_f16
+                          * (BASELINE config 5); then w_packed holds IEEE halfs and Cin % 32 == 0.
+                          * Activations and outputs stay fp32 in memory either way. */
 } kfn_conv_desc;
+
+#define KFN_OPERAND_F32 0
+#define KFN_OPERAND_F16 1
 
 #define KFN_EPI_NONE 0
 #define KFN_EPI_L2NORM 1   /* tf.nn.l2_normalize(axis=-1), KFNet/KFNet.py:340; needs Cout == 32 */

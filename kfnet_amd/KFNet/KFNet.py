@@ -256,6 +256,8 @@ class KFNet():
         if len(cv) != 1 or len(c0) != 1 or c0[0].kh != 3 or c0[0].stride != 1 or c0[0].transposed:
             return
         conv0 = c0[0]
+        if conv0.operand_dtype != _lib.OPERAND_F32:
+            return   # the loader-generated volume exists for the fp32 kernel only
         fused = CostVolumeConvOp(feat_map1, feat_map2, conv0.y, conv0.kernel, conv0.bias, conv0.relu, window_size)
         g.ops[g.ops.index(conv0)] = fused
         g.ops.remove(cv[0])

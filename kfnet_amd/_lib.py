@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
+OPERAND_F32, OPERAND_F16 = 0, 1
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -21,7 +22,7 @@ class KfnError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
-        'transposed', 'relu', 'epilogue', 'config')]
+        'transposed', 'relu', 'epilogue', 'config', 'operand_dtype')]
 
 
 class KalmanDesc(C.Structure):
@@ -82,7 +83,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.kfn_abi_version() != 1:
+    if lib.kfn_abi_version() != 2:
         raise KfnError('libkfnet_hip.so ABI version mismatch')
     _lib = lib
     return lib

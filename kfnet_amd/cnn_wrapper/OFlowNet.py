@@ -1,7 +1,7 @@
 """OFlowNet, the process-model head over the local cost volume -- same class surface as
 the reference's cnn_wrapper/OFlowNet.py:6-57."""
 from .. import _lib
-from ..graph import ConvOp, FlowHeadOp, FlowOp, pack_bias, pack_dense_kernel, pack_flow_head_kernel
+from ..graph import ConvOp, FlowHeadOp, FlowOp, as_f16, pack_bias, pack_dense_kernel, pack_flow_head_kernel
 from .network import Network
 
 
@@ -49,9 +49,11 @@ class OFlowNet(Network):
         g = self.graph
         n, h, w, cin = x.shape
         y = g.tensor((n, h, w, units), name=name)
-        kern = g.variable(name + '/kernel', (cin, units), pack_dense_kernel)
+        f16 = g.conv_operands == 'f16' and cin % 32 == 0
+        kern = g.variable(name + '/kernel', (cin, units), as_f16(pack_dense_kernel) if f16 else pack_dense_kernel)
         bias = g.variable(name + '/bias', (units,), pack_bias)
-        self._emit(ConvOp(name, x, y, kern, bias, 1, 1, 1, relu, epilogue=epilogue))
+        self._emit(ConvOp(name, x, y, kern, bias, 1, 1, 1, relu, epilogue=epilogue,
+                          operand_dtype=_lib.OPERAND_F16 if f16 else _lib.OPERAND_F32))
         self.layers[name] = y
         return y
 

@@ -12,7 +12,7 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, pack_bias,
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, as_f16, pack_bias,
                      pack_conv_kernel, pack_deconv_kernel, pack_first_kernel, pack_winograd_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
@@ -174,6 +174,11 @@ class Network(object):
         y = g.tensor((n, _same_out(h, strides), _same_out(w, strides), filters), name=name)
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
         wmin = g.winograd_min_channels
+        f16 = g.conv_operands == 'f16' and cin % 32 == 0
+        if f16:
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_conv_kernel))
+            self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16))
+            return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_kernel)
@@ -195,9 +200,12 @@ class Network(object):
         k = int(kernel_size)
         n, h, w, cin = input.shape
         y = g.tensor((n, h * strides, w * strides, filters), name=name)
-        kern = g.variable(name + '/kernel', (k, k, filters, cin), pack_deconv_kernel)
+        f16 = g.conv_operands == 'f16' and cin % 32 == 0
+        kern = g.variable(name + '/kernel', (k, k, filters, cin),
+                          as_f16(pack_deconv_kernel) if f16 else pack_deconv_kernel)
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
-        self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, transposed=True))
+        self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, transposed=True,
+                          operand_dtype=_lib.OPERAND_F16 if f16 else _lib.OPERAND_F32))
         return y
 
     @layer

@@ -87,12 +87,22 @@ __device__ __forceinline__ int swz(int r) {
 // the 39 MB/frame volume is never materialised, f1/f2 (614 KB each) stay L2-resident.
 constexpr int MODE_CONV = 0, MODE_DECONV = 1, MODE_WINO = 2, MODE_CVOL = 3;
 
-template <int TM, int TN, int WM, int WN, int BK, int MODE>
+// F16 (conv / transposed conv only): operands are rounded to fp16 while they are staged
+// (activations stay fp32 in HBM, weights are pre-packed fp16), products accumulate in fp32 on
+// v_mfma_f32_32x32x16_f16 -- 16x the fp32 MFMA rate, for BASELINE config 5 ("fp16 convs").
+// An LDS row is still 64 bytes = four 16-byte quads, now holding 32 halfs: BK (the fp32
+// k-step, must be 16) covers KCH = 32 channels per stage.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int TM, int TN, int WM, int WN, int BK, int MODE, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
   constexpr bool WINO = (MODE == MODE_WINO);
   constexpr bool CVOL = (MODE == MODE_CVOL);
-  constexpr int NSRC = WINO ? 4 : (CVOL ? 2 : 1);  // global loads per A quad
+  static_assert(!F16 || (BK == 16 && (MODE == MODE_CONV || MODE == MODE_DECONV)), "F16: conv/deconv at BK=16 only");
+  constexpr int NSRC = WINO ? 4 : ((CVOL || F16) ? 2 : 1);  // global loads per A quad
+  constexpr int QCH = F16 ? 8 : 4;                           // channels per 16-byte LDS quad
+  constexpr int KCH = F16 ? 2 * BK : BK;                     // channels per stage
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int NT = 64 * WM * WN;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
       } else {
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * 4) * 4u;
+        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * 4u;
         for (int t = 0; t < ntaps; ++t) {
           const int ky = t / p.kw, kx = t - ky * p.kw;
           const int iy = iy0 + ky, ix = ix0 + kx;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int i = 0; i < BP; ++i) {
     const int r = r0 + i * RPP;
     const int n = n0 + r;
-    b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * 4) * 4u : OOB;
+    b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * QCH) * (F16 ? 2u : 4u) : OOB;
   }
 
   // ---- which taps touch at least one in-range input pixel of this tile? -----------
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   f32x4 ga[AP * NSRC], gb[BP];
 
   // ---- stage iterator of the LOAD stream (compute only counts stages) ---------------
-  const int kchunks = p.Cin / BK;
+  const int kchunks = p.Cin / KCH;
   const int n_stages = __builtin_popcount(tapmask) * kchunks;
   int ld_tap = tapmask ? __builtin_ctz(tapmask) : 32;
   // Concurrent workgroups walk the Cin chunks in ROTATED order: with NHWC the pixel stride
@@ -297,14 +307,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // byte range modulo the pixel stride and pile onto the same L2 channels/sets.
   const int rot = (p.rot_mode == 0) ? 0 : ((tm * 7 + tn * 3 + (p.rot_mode == 2 ? grp * 5 : 0)) % kchunks);
   int ld_ci = 0;
-  int ld_c0 = rot * BK;
+  int ld_c0 = rot * KCH;
   auto advance = [&]() {
     ++ld_ci;
-    ld_c0 += BK;
+    ld_c0 += KCH;
     if (ld_c0 >= p.Cin) ld_c0 = 0;
     if (ld_ci >= kchunks) {
       ld_ci = 0;
-      ld_c0 = rot * BK;
+      ld_c0 = rot * KCH;
       const unsigned rest = (ld_tap < 31) ? (tapmask & ~((2u << ld_tap) - 1u)) : 0u;
       ld_tap = rest ? __builtin_ctz(rest) : 32;
     }
@@ -325,13 +335,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         const bool ok = live && ((a_msk2[CVOL ? i : 0] >> tap) & 1u);
         ga[k] = buf_load(rsA, ok ? a_off[i] + adelta : OOB);
       }
-    } else if (k < AP) {
+    } else if (F16 && k < AP * NSRC) {   // two consecutive float4 = the 8 channels of one fp16 quad
+      const int i = k / NSRC;
+      unsigned vo;
+      if (TRANSPOSED) {
+        const int ty = a_y[i] - ky, tx = a_x[i] - kx;
+        const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
+        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
+      } else {
+        vo = a_off[i] + adelta;
+      }
+      vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo + (unsigned)(k % NSRC) * 16u : OOB;
+      ga[k] = buf_load(rsA, vo);
+    } else if (!F16 && k < AP) {
       const int i = k;
       unsigned vo;
       if (TRANSPOSED) {
         const int ty = a_y[i] - ky, tx = a_x[i] - kx;
         const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
-        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * 4)) * 4u;
+        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
       } else {
         vo = a_off[i] + adelta;
       }
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       ga[i] = buf_load(rsA, vo);
     } else {
       const int i = k - AP * NSRC;
-      gb[i] = buf_load(rsB, live ? b_off[i] + bdelta : OOB);
+      gb[i] = buf_load(rsB, live ? b_off[i] + (F16 ? bdelta >> 1 : bdelta) : OOB);
     }
   };
 
@@ -357,6 +379,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         v += w_s11 * ga[i * NSRC + (WINO ? 3 : 0)];
       } else if (CVOL) {
         v = ga[i * NSRC] - ga[i * NSRC + (CVOL ? 1 : 0)];   // diff_feat = feat_map2 - shift(feat_map1)
+      } else if (F16) {
+        const f32x4 lo = ga[i * NSRC], hi = ga[i * NSRC + (F16 ? 1 : 0)];
+        f16x8 h = {(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w,
+                   (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};   // RNE
+        v = __builtin_bit_cast(f32x4, h);
       } else {
         v = ga[i];
       }
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr int NLD = AP * NSRC + BP;  // global loads per stage
   constexpr int NST = AP + BP;         // LDS stores per stage
   constexpr int NFR = TM + TN;     // fragment reads per chunk
-  constexpr int J = 4 * TM * TN;   // MFMAs per chunk
+  constexpr int J = (F16 ? 1 : 4) * TM * TN;   // MFMAs per chunk
 
   if (n_stages > 0) {
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers ----------------------
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         constexpr int n_st = (c == 0) ? NST : 0;
         constexpr int n_ld = (c == LOADC) ? NLD : 0;
         constexpr int n_side = n_rd + n_st + n_ld;
-        constexpr int jspan = last ? J / 2 : J;  // in the last chunk side ops ride the first half
+        constexpr int jspan = last ? (J / 2 > 0 ? J / 2 : 1) : J;  // in the last chunk side ops ride the first half
         static_for<J>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
@@ -454,7 +481,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
             asm volatile("" ::: "memory");
             static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0); });
           }
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
+          if constexpr (F16)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[slot][mi]),
+                                                                 __builtin_bit_cast(f16x8, fr[slot][TM + ni]),
+                                                                 acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
           // side ops k with floor(k*jspan/n_side) == j ride behind MFMA j
           constexpr int kb = n_side ? (j * n_side + jspan - 1) / jspan : 0;
           constexpr int ke0 = n_side ? ((j + 1) * n_side + jspan - 1) / jspan : 0;
@@ -547,14 +579,14 @@ const TileCfg* find_cfg(int cfg) {
   return nullptr;
 }
 
-template <int TM, int TN, int WM, int WN, int BK, int MODE>
+template <int TM, int TN, int WM, int WN, int BK, int MODE, bool F16 = false>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
   constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
-  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, MODE>;
+  auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, MODE, F16>;
   static bool attr_done = false;  // benign race: idempotent attribute
   if (!attr_done) {
     KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -567,17 +599,17 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   return KFN_OK;
 }
 
-template <int BK, int TR>
+template <int BK, int TR, bool F16 = false>
 int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
-    case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK, TR>(a, s);
-    case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, BK, TR>(a, s);
-    case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, TR>(a, s);
-    case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, BK, TR>(a, s);
-    case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK, TR>(a, s);
-    case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, BK, TR>(a, s);
-    case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR>(a, s);
-    case KFN_CFG_160x256: return launch_cfg<5, 1, 1, 8, BK, TR>(a, s);
+    case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK, TR, F16>(a, s);
+    case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, BK, TR, F16>(a, s);
+    case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, TR, F16>(a, s);
+    case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, BK, TR, F16>(a, s);
+    case KFN_CFG_64x64: return launch_cfg<1, 1, 2, 2, BK, TR, F16>(a, s);
+    case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, BK, TR, F16>(a, s);
+    case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR, F16>(a, s);
+    case KFN_CFG_160x256: return launch_cfg<5, 1, 1, 8, BK, TR, F16>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }
@@ -719,7 +751,10 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const long in_pix = (long)d->N * d->H * d->W;
   const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
   a.Ktot = d->kh * d->kw * d->Cin;
-  const long w_bytes = (long)d->cout_pad * a.Ktot * 4L;
+  const bool f16 = d->operand_dtype == KFN_OPERAND_F16;
+  KFN_REQUIRE(d->operand_dtype == KFN_OPERAND_F32 || f16, "kfn_conv2d_nhwc: unknown operand_dtype %d", d->operand_dtype);
+  KFN_REQUIRE(!f16 || d->Cin % 32 == 0, "kfn_conv2d_nhwc: fp16 operands need Cin %% 32 == 0 (Cin=%d)", d->Cin);
+  const long w_bytes = (long)d->cout_pad * a.Ktot * (f16 ? 2L : 4L);
   // 32-bit byte offsets (+ the OOB marker 2^31): weights below 2 GiB, and the images one
   // 160-row tile can touch below 2 GiB (the A descriptor is re-based per tile).
   KFN_REQUIRE(!d->transposed || x_bytes < (1L << 31), "kfn_conv2d_nhwc: transposed conv input above 2 GiB");
@@ -736,6 +771,10 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
 
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (f16) {
+    if (d->transposed) return dispatch_cfg<16, MODE_DECONV, true>(cfg, a, s);
+    return dispatch_cfg<16, MODE_CONV, true>(cfg, a, s);
+  }
   if (d->transposed) {
     if (pick_bk(d->Cin, MODE_DECONV) == 32) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
     return dispatch_cfg<16, MODE_DECONV>(cfg, a, s);

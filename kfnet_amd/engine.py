@@ -30,7 +30,8 @@ def grid_size(image_hw):
 
 class KFNetEngine(object):
     def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
-                 nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False):
+                 nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False,
+                 conv_operands='f32'):
         import torch
         self.torch = torch
         self.B = int(batch)
@@ -43,6 +44,7 @@ class KFNetEngine(object):
         self.emit_debug = emit_debug
 
         g = self.graph = Graph()
+        g.conv_operands = conv_operands
         spec = KFNetDataSpec(batch_size=self.B, image_size=image_size)
         self.images = g.placeholder((self.B, self.H, self.W, 3), 'u8', name='images')
         self.state = g.placeholder((1, self.h, self.w, 4), name='last_state')

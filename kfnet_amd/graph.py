@@ -228,6 +228,14 @@ def pack_winograd_kernel(w):
     return out
 
 
+def as_f16(pack):
+    """Wrap a weight packer so that the packed matrix is stored as IEEE halfs (fp16-operand convs)."""
+    def f(w):
+        return pack(w).astype(np.float16)
+    f.__name__ = pack.__name__ + '_f16'
+    return f
+
+
 def pack_deconv_kernel(w):
     """TF conv2d_transpose [kh,kw,Cout,Cin] -> [cout_pad][kh*kw*Cin]."""
     kh, kw, co, ci = w.shape
@@ -253,13 +261,14 @@ def pack_bias(b):
 
 class ConvOp(Op):
     def __init__(self, name, x, y, kernel, bias, kh, kw, stride, relu, transposed=False,
-                 epilogue=_lib.EPI_NONE, config=_lib.CFG_AUTO):
+                 epilogue=_lib.EPI_NONE, config=_lib.CFG_AUTO, operand_dtype=_lib.OPERAND_F32):
         self.name = name
         self.x, self.y, self.kernel, self.bias = x, y, kernel, bias
         self.kh, self.kw, self.stride, self.relu = kh, kw, stride, relu
         self.transposed = transposed
         self.epilogue = epilogue
         self.config = config
+        self.operand_dtype = operand_dtype
         self._desc = None
 
     def desc(self):
@@ -268,7 +277,7 @@ class ConvOp(Op):
         d = _lib.ConvDesc(N=_scaled(n, self.x.graph), H=h, W=w, Cin=cin, ldx=self.x.ld, Cout=cout,
                           cout_pad=-(-cout // 32) * 32, ldy=self.y.ld, kh=self.kh, kw=self.kw,
                           stride=self.stride, transposed=int(self.transposed), relu=int(self.relu),
-                          epilogue=self.epilogue, config=self.config)
+                          epilogue=self.epilogue, config=self.config, operand_dtype=self.operand_dtype)
         return d
 
     def flops(self):
@@ -288,6 +297,8 @@ class ConvOp(Op):
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
         t = self.CFG_TILE[cfg.value]
+        if self.operand_dtype == _lib.OPERAND_F16:
+            return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, true>' % (t + (1 if self.transposed else 0,))
         return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d>' % (t + (bk.value, 1 if self.transposed else 0))
 
     def launch(self, lib, stream):
@@ -529,6 +540,10 @@ class Graph(object):
         # the 2.25x MFMA saving.
         self.winograd_min_channels = 128
         self.winograd_ws = None
+        # 'f32': exact fp32 MFMA everywhere (the parity path).  'f16': convolutions with
+        # Cin % 32 == 0 round their operands to fp16 while staging (fp32 accumulate, fp32
+        # activations in memory) -- BASELINE config 5 "fp16 convs + fp32 Kalman", own tolerance.
+        self.conv_operands = 'f32'
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 
     # -- construction -------------------------------------------------------------------

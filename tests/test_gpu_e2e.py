@@ -195,3 +195,29 @@ def test_eval_with_labels_prints_reference_metrics(capsys):
     assert np.isclose(mets[3]['d_kf'], d_kf)
     assert all(np.isfinite(m[k]) for m in mets for k in ('l_m', 'l_t', 'l_kf', 'a_kf', 'nis'))
     assert mets[0]['d_t'] == mets[0]['d_m']      # reset step: temp output := measurement
+
+
+def test_config5_fp16_convs_fp32_kalman():
+    """BASELINE config 5: fp16-operand convolutions (fp32 accumulate) + fp32 Kalman, at the
+    540x960 geometry.  Own tolerance (stated here): coord max-abs <= 2e-2, confidence
+    max-rel <= 5e-2 against the fp32 oracle -- this is NOT the headline parity path."""
+    import torch
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.graph import ConvOp
+    from kfnet_amd import _lib
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    seq = synthetic_sequence(3, 540, 960, seed=3)
+    T4 = np.eye(4, dtype=np.float32)
+    eng = KFNetEngine(W, image_size=(540, 960), batch=3, transform=T4, reset_period=500, max_chunk=3,
+                      conv_operands='f16')
+    n16 = sum(1 for op in eng.heavy_ops if isinstance(op, ConvOp) and op.operand_dtype == _lib.OPERAND_F16)
+    assert n16 >= 25
+    rec = eng.process(eng.upload_frames(seq)).cpu().numpy()
+    ref = OT.eval_sequence(seq, W, T4, reset_period=500)
+    dc = np.abs(rec[..., :3] - ref[..., :3]).max()
+    dr = (np.abs(rec[..., 3] - ref[..., 3]) / np.abs(ref[..., 3])).max()
+    print('fp16-operand convs: coord max-abs %.3g, confidence max-rel %.3g' % (dc, dr))
+    assert dc <= 2e-2 and dr <= 5e-2
+    assert dc > 1e-6   # and it is measurably not the fp32 path

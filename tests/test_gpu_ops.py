@@ -401,3 +401,39 @@ def test_cost_volume_conv_vs_oracle(shape):
         ref = O.conv2d_same(vol, wt, b, 1, True).reshape(H * W * 64, co)
         g = got[n * H * W * 64:(n + 1) * H * W * 64, off:off + co]
         assert np.abs(g - ref).max() < 2e-5
+
+
+F16_CASES = [(1, 8, 8, 32, 32, 3, 1), (2, 13, 17, 64, 48, 3, 1), (1, 12, 20, 64, 64, 3, 2), (1, 15, 9, 32, 100, 3, 2),
+             (2, 6, 10, 256, 128, 1, 1), (1, 60, 80, 128, 160, 3, 1), (6, 2, 2, 64, 64, 3, 1)]
+
+
+@pytest.mark.parametrize('case', F16_CASES)
+@pytest.mark.parametrize('config', [0, 1, 2, 4, 6])
+def test_conv_fp16_operands(case, config):
+    """operand_dtype = F16: the kernel must equal an fp64 convolution of the fp16-ROUNDED
+    operands (products of halfs are exact in fp32, accumulation is fp32), i.e. the only error
+    vs that reference is fp32 summation order; vs the unrounded fp32 conv it is ~1e-3 relative."""
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co, k, s = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
+    wt = (rng.normal(size=(k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, s, True, config=config, f16=True)
+    xr = x.astype(np.float16).astype(np.float64)
+    wr = wt.astype(np.float16).astype(np.float64)
+    ref = O.conv2d_same(xr, wr, b, s, True)
+    assert np.abs(y - ref).max() <= _conv_tol(x, wt)
+    full = O.conv2d_same(x.astype(np.float64), wt, b, s, True)
+    assert np.abs(y - full).max() < 2e-2 and np.abs(y - full).max() > 0   # it really is reduced precision
+
+
+def test_deconv_fp16_operands():
+    from tests.gpu_util import run_conv
+    rng = np.random.default_rng(31)
+    x = rng.normal(size=(40, 4, 4, 32)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, 16, 32)) / 17).astype(np.float32)
+    b = rng.normal(size=16).astype(np.float32)
+    y = run_conv(x, wt, b, 2, True, transposed=True, f16=True)
+    ref = O.conv2d_transpose_same(x.astype(np.float16).astype(np.float64), wt.astype(np.float16).astype(np.float64), b, 2, True)
+    assert np.abs(y - ref).max() <= _conv_tol(x, wt, True)

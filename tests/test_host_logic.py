@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     lib = _lib.load()
-    assert lib.kfn_abi_version() == 1
+    assert lib.kfn_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure():
