@@ -305,9 +305,9 @@ def main():
             'unit': 'TFLOP/s', 'frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'traffic': traffic,
             'algorithmic_tflops': round(tf, 2), 'algorithmic_frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': ('kernels tagged <...,2> run the 16 GEMMs of Winograd F(2x2,3x3) (fp32): algorithmic_* counts the '
-                     'direct-convolution FLOPs they replace and may exceed the MFMA peak; <...,0> is the direct '
-                     'implicit GEMM, <...,1> the transposed conv'),
+            'note': ('kernel template args <TM,TN,WM,WN,BK,MODE,F16>: MODE 2 = the 16 GEMMs of Winograd F(2x2,3x3) (fp32): '
+                     'algorithmic_* counts the direct-convolution FLOPs they replace and may exceed the MFMA peak; MODE 0 = '
+                     'direct implicit GEMM, 1 = transposed conv, 3 = conv0 with the cost volume generated in the loader'),
             'launches_per_batch': n_dom,
             'algorithmic_gflop_per_launch_avg': round(fl_dom / n_dom / 1e9, 3),
             'executed_gflop_per_launch_avg': round(ex_dom / n_dom / 1e9, 3),

@@ -299,7 +299,7 @@ class ConvOp(Op):
         t = self.CFG_TILE[cfg.value]
         if self.operand_dtype == _lib.OPERAND_F16:
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, true>' % (t + (1 if self.transposed else 0,))
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d>' % (t + (bk.value, 1 if self.transposed else 0))
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, false>' % (t + (bk.value, 1 if self.transposed else 0))
 
     def launch(self, lib, stream):
         d = self.desc()
@@ -319,7 +319,7 @@ class WinogradConvOp(ConvOp):
         d = self.desc()
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_winograd_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_winograd_plan')
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2>' % (self.CFG_TILE[cfg.value] + (bk.value,))
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2, false>' % (self.CFG_TILE[cfg.value] + (bk.value,))
 
     def mfma_flops(self):
         """FLOPs the 16 GEMMs actually execute (algorithmic flops() stays the nominal 2*M*N*K)."""
@@ -404,7 +404,7 @@ class CostVolumeConvOp(Op):
                           cout_pad=-(-self.y.shape[3] // 32) * 32, ldy=self.y.ld, kh=3, kw=3, stride=1, config=self.config)
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
-        return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 3>' % ConvOp.CFG_TILE[cfg.value]
+        return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 3, false>' % ConvOp.CFG_TILE[cfg.value]
 
     def launch(self, lib, stream):
         n, h, w, c = self.f2.shape
