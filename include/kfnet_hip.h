@@ -89,6 +89,10 @@ typedef struct kfn_conv_desc {
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1
+/* fp32-class accuracy on the fp16 MFMA: operands split into hi + lo halfs while staged,
+ * hi*hi + hi*lo + lo*hi accumulated in fp32 (forward convs, Cin % 32 == 0).  w_packed =
+ * [hi | lo] half matrices of 1024*w (each [cout_pad][K]); the kernel scales the sum by 2^-10. */
+#define KFN_OPERAND_F16X3 2
 
 #define KFN_EPI_NONE 0
 #define KFN_EPI_L2NORM 1   /* tf.nn.l2_normalize(axis=-1), KFNet/KFNet.py:340; needs Cout == 32 */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
-OPERAND_F32, OPERAND_F16 = 0, 1
+OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 
 

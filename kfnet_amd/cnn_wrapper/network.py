@@ -12,7 +12,8 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, as_f16, pack_bias,
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, as_f16, as_f16x3,
+                     pack_bias,
                      pack_conv_kernel, pack_deconv_kernel, pack_first_kernel, pack_winograd_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
@@ -178,6 +179,10 @@ class Network(object):
         if f16:
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_conv_kernel))
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16))
+            return y
+        if g.conv_operands == 'f16x3' and cin % 32 == 0 and cin >= g.f16x3_min_channels:
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16x3(pack_conv_kernel))
+            self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16X3))
             return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):

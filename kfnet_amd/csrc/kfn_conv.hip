@@ -44,6 +44,8 @@ struct ConvArgs {
   unsigned long long x_bytes;
   unsigned w_bytes;
   int rot_mode;  // K-chunk rotation: 0 off, 1 per (m,n) tile, 2 per (m,n,group)
+  unsigned w_lo_bytes;  // f16x3: byte offset of the lo weight matrix behind the hi one
+  float out_scale;      // f16x3: 2^-k undoing the weight pre-scale
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -94,8 +96,20 @@ constexpr int MODE_CONV = 0, MODE_DECONV = 1, MODE_WINO = 2, MODE_CVOL = 3;
 // k-step, must be 16) covers KCH = 32 channels per stage.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TM, int TN, int WM, int WN, int BK, int MODE, bool F16 = false>
+// PREC 2 ("f16x3"): every fp32 operand x is split while staged into hi = f16(x) and
+// lo = f16(x - hi) (22 significand bits together); the product is evaluated as
+// hi*hi + hi*lo + lo*hi on the fp16 MFMA with fp32 accumulation -- three MFMAs at 16x the
+// fp32 rate instead of eight fp32 MFMAs per 16-wide k-step.  Weights are pre-split (and
+// pre-scaled by 2^10 so that their lo parts are fp16 normals; the epilogue multiplies the
+// exact power of two back).  Dropped lo*lo term and fp16 rounding of lo: ~2^-21 relative
+// per product, i.e. fp32-class accuracy.
+constexpr int PREC_F32 = 0, PREC_F16 = 1, PREC_F16X3 = 2;
+
+template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
+  constexpr bool F16 = (PREC != PREC_F32);   // operands live in LDS as halfs
+  constexpr bool X3 = (PREC == PREC_F16X3);  // ... as separate hi and lo tiles
+  constexpr int NPART = X3 ? 2 : 1;
   constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
   constexpr bool WINO = (MODE == MODE_WINO);
   constexpr bool CVOL = (MODE == MODE_CVOL);
@@ -110,8 +124,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr int RPP = NT / QPR;     // tile rows covered per pass of the whole block
   constexpr int AP = (BM + RPP - 1) / RPP;
   constexpr int BP = (BN + RPP - 1) / RPP;
-  constexpr int A_ELEMS = BM * BK;
-  constexpr int B_ELEMS = BN * BK;
+  constexpr int A_PART = BM * BK, B_PART = BN * BK;   // one (hi or lo) tile, in floats
+  constexpr int A_ELEMS = A_PART * NPART;
+  constexpr int B_ELEMS = B_PART * NPART;
   constexpr int NCH = BK / 8;       // 8-wide k-chunks per stage
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  f32x4 ga[AP * NSRC], gb[BP];
+  f32x4 ga[AP * NSRC], gb[BP * NPART];
 
   // ---- stage iterator of the LOAD stream (compute only counts stages) ---------------
   const int kchunks = p.Cin / KCH;
@@ -360,8 +375,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo : OOB;
       ga[i] = buf_load(rsA, vo);
     } else {
-      const int i = k - AP * NSRC;
-      gb[i] = buf_load(rsB, live ? b_off[i] + (F16 ? bdelta >> 1 : bdelta) : OOB);
+      const int kk = k - AP * NSRC;
+      const int i = kk / NPART;
+      // f16x3: the packed weights are [hi | lo], lo starts w_lo_bytes after hi
+      const unsigned part_off = (X3 && (kk % NPART)) ? p.w_lo_bytes : 0u;
+      gb[kk] = buf_load(rsB, live ? b_off[i] + (F16 ? bdelta >> 1 : bdelta) + part_off : OOB);
     }
   };
 
@@ -380,19 +398,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       } else if (CVOL) {
         v = ga[i * NSRC] - ga[i * NSRC + (CVOL ? 1 : 0)];   // diff_feat = feat_map2 - shift(feat_map1)
       } else if (F16) {
-        const f32x4 lo = ga[i * NSRC], hi = ga[i * NSRC + (F16 ? 1 : 0)];
-        f16x8 h = {(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w,
-                   (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};   // RNE
+        const f32x4 c0 = ga[i * NSRC], c1 = ga[i * NSRC + (F16 ? 1 : 0)];   // channels 0-3, 4-7
+        const f16x8 h = {(_Float16)c0.x, (_Float16)c0.y, (_Float16)c0.z, (_Float16)c0.w,
+                         (_Float16)c1.x, (_Float16)c1.y, (_Float16)c1.z, (_Float16)c1.w};   // RNE
         v = __builtin_bit_cast(f32x4, h);
+        if (X3 && (AP * RPP == BM || r0 + i * RPP < BM)) {
+          const f16x8 l = {(_Float16)(c0.x - (float)h[0]), (_Float16)(c0.y - (float)h[1]),
+                           (_Float16)(c0.z - (float)h[2]), (_Float16)(c0.w - (float)h[3]),
+                           (_Float16)(c1.x - (float)h[4]), (_Float16)(c1.y - (float)h[5]),
+                           (_Float16)(c1.z - (float)h[6]), (_Float16)(c1.w - (float)h[7])};
+          *reinterpret_cast<f32x4*>(As + buf * A_ELEMS + A_PART + wr_off + i * RPP * BK) =
+              __builtin_bit_cast(f32x4, l);
+        }
       } else {
         v = ga[i];
       }
       if (AP * RPP == BM || r0 + i * RPP < BM)
         *reinterpret_cast<f32x4*>(As + buf * A_ELEMS + wr_off + i * RPP * BK) = v;
     } else {
-      const int i = k - AP;
+      const int kk = k - AP;
+      const int i = kk / NPART;
       if (BP * RPP == BN || r0 + i * RPP < BN)
-        *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + wr_off + i * RPP * BK) = gb[i];
+        *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + (kk % NPART) * B_PART + wr_off + i * RPP * BK) = gb[kk];
     }
   };
 
@@ -404,18 +431,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int a_rd = (wm * TM * 32 + li) * BK;
   const int b_rd = (wn * TN * 32 + li) * BK;
 
-  f32x4 fr[2][TM + TN];  // double-buffered A (TM) + B (TN) fragments
+  // double-buffered fragments: [A hi (TM) | B hi (TN)] and, for f16x3, [A lo | B lo] behind them
+  f32x4 fr[2][(TM + TN) * NPART];
   auto read_one = [&](int k, int slot, int buf, int c) {
-    if (k < TM)
-      fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + a_rd + k * 32 * BK + rdq[c]);
+    const int part = k / (TM + TN), kk = k % (TM + TN);
+    if (kk < TM)
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + part * A_PART + a_rd + kk * 32 * BK + rdq[c]);
     else
-      fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + b_rd + (k - TM) * 32 * BK + rdq[c]);
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + part * B_PART + b_rd + (kk - TM) * 32 * BK + rdq[c]);
   };
 
-  constexpr int NLD = AP * NSRC + BP;  // global loads per stage
-  constexpr int NST = AP + BP;         // LDS stores per stage
-  constexpr int NFR = TM + TN;     // fragment reads per chunk
-  constexpr int J = (F16 ? 1 : 4) * TM * TN;   // MFMAs per chunk
+  constexpr int NLD = AP * NSRC + BP * NPART;  // global loads per stage
+  constexpr int NST = AP + BP * NPART;         // LDS store ops per stage (an f16x3 A op writes hi and lo)
+  constexpr int NFR = (TM + TN) * NPART;       // fragment reads per chunk
+  constexpr int NTERM = X3 ? 3 : 1;
+  constexpr int J = (F16 ? NTERM : 4) * TM * TN;   // MFMAs per chunk
 
   if (n_stages > 0) {
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers ----------------------
@@ -481,11 +511,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
             asm volatile("" ::: "memory");
             static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0); });
           }
-          if constexpr (F16)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[slot][mi]),
-                                                                 __builtin_bit_cast(f16x8, fr[slot][TM + ni]),
+          if constexpr (F16) {
+            // t = term: f16x3 adds the two cross terms first, the hi*hi term last
+            constexpr int LO = TM + TN;
+            constexpr int ia = (X3 && t == 0) ? LO + mi : mi;
+            constexpr int ib = (X3 && t == 1) ? LO + TM + ni : TM + ni;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[slot][ia]),
+                                                                 __builtin_bit_cast(f16x8, fr[slot][ib]),
                                                                  acc[mi][ni], 0, 0, 0);
-          else
+          } else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
           // side ops k with floor(k*jspan/n_side) == j ride behind MFMA j
           constexpr int kb = n_side ? (j * n_side + jspan - 1) / jspan : 0;
@@ -537,7 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + rowh;
-        float v = acc[mi][ni][e] + bv;
+        float v = (X3 ? acc[mi][ni][e] * p.out_scale : acc[mi][ni][e]) + bv;
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.epilogue == KFN_EPI_L2NORM) {
           float ss = n_ok ? v * v : 0.f;
@@ -579,10 +613,10 @@ const TileCfg* find_cfg(int cfg) {
   return nullptr;
 }
 
-template <int TM, int TN, int WM, int WN, int BK, int MODE, bool F16 = false>
+template <int TM, int TN, int WM, int WN, int BK, int MODE, int F16 = PREC_F32>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
@@ -599,7 +633,7 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   return KFN_OK;
 }
 
-template <int BK, int TR, bool F16 = false>
+template <int BK, int TR, int F16 = PREC_F32>
 int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
     case KFN_CFG_160x128: return launch_cfg<5, 1, 1, 4, BK, TR, F16>(a, s);
@@ -751,10 +785,13 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   const long in_pix = (long)d->N * d->H * d->W;
   const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
   a.Ktot = d->kh * d->kw * d->Cin;
-  const bool f16 = d->operand_dtype == KFN_OPERAND_F16;
+  const bool x3 = d->operand_dtype == KFN_OPERAND_F16X3;
+  const bool f16 = d->operand_dtype == KFN_OPERAND_F16 || x3;
   KFN_REQUIRE(d->operand_dtype == KFN_OPERAND_F32 || f16, "kfn_conv2d_nhwc: unknown operand_dtype %d", d->operand_dtype);
   KFN_REQUIRE(!f16 || d->Cin % 32 == 0, "kfn_conv2d_nhwc: fp16 operands need Cin %% 32 == 0 (Cin=%d)", d->Cin);
-  const long w_bytes = (long)d->cout_pad * a.Ktot * (f16 ? 2L : 4L);
+  const long w_bytes = (long)d->cout_pad * a.Ktot * (f16 ? 2L : 4L) * (x3 ? 2L : 1L);
+  a.w_lo_bytes = x3 ? (unsigned)((long)d->cout_pad * a.Ktot * 2L) : 0u;
+  a.out_scale = x3 ? (1.0f / 1024.0f) : 1.0f;
   // 32-bit byte offsets (+ the OOB marker 2^31): weights below 2 GiB, and the images one
   // 160-row tile can touch below 2 GiB (the A descriptor is re-based per tile).
   KFN_REQUIRE(!d->transposed || x_bytes < (1L << 31), "kfn_conv2d_nhwc: transposed conv input above 2 GiB");
@@ -771,9 +808,13 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
 
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (x3) {
+    KFN_REQUIRE(!d->transposed, "kfn_conv2d_nhwc: f16x3 operands are implemented for forward convolutions only");
+    return dispatch_cfg<16, MODE_CONV, PREC_F16X3>(cfg, a, s);
+  }
   if (f16) {
-    if (d->transposed) return dispatch_cfg<16, MODE_DECONV, true>(cfg, a, s);
-    return dispatch_cfg<16, MODE_CONV, true>(cfg, a, s);
+    if (d->transposed) return dispatch_cfg<16, MODE_DECONV, PREC_F16>(cfg, a, s);
+    return dispatch_cfg<16, MODE_CONV, PREC_F16>(cfg, a, s);
   }
   if (d->transposed) {
     if (pick_bk(d->Cin, MODE_DECONV) == 32) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
@@ -901,6 +942,8 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
   a.rot_mode = rot_mode();
+  a.w_lo_bytes = 0;
+  a.out_scale = 1.0f;
   int cfg = d->config;
   if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, d->Cout, num_cu(), true);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -955,6 +998,8 @@ extern "C" int kfn_cost_volume_conv(const float* f1, const float* f2, const floa
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
   a.rot_mode = 0;
+  a.w_lo_bytes = 0;
+  a.out_scale = 1.0f;
   int cfg = config;
   if (cfg == KFN_CFG_AUTO) cfg = auto_config(a.M, Cout, num_cu());
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -236,6 +236,17 @@ def as_f16(pack):
     return f
 
 
+def as_f16x3(pack):
+    """Packer for KFN_OPERAND_F16X3: [hi | lo] half matrices of 1024*w (lo = f16(1024 w - hi))."""
+    def f(w):
+        m = pack(w).astype(np.float32) * np.float32(1024.0)
+        hi = m.astype(np.float16)
+        lo = (m - hi.astype(np.float32)).astype(np.float16)
+        return np.stack([hi, lo])
+    f.__name__ = pack.__name__ + '_f16x3'
+    return f
+
+
 def pack_deconv_kernel(w):
     """TF conv2d_transpose [kh,kw,Cout,Cin] -> [cout_pad][kh*kw*Cin]."""
     kh, kw, co, ci = w.shape
@@ -298,8 +309,10 @@ class ConvOp(Op):
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
         t = self.CFG_TILE[cfg.value]
         if self.operand_dtype == _lib.OPERAND_F16:
-            return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, true>' % (t + (1 if self.transposed else 0,))
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, false>' % (t + (bk.value, 1 if self.transposed else 0))
+            return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, 1>' % (t + (1 if self.transposed else 0,))
+        if self.operand_dtype == _lib.OPERAND_F16X3:
+            return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 0, 2>' % t
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, 0>' % (t + (bk.value, 1 if self.transposed else 0))
 
     def launch(self, lib, stream):
         d = self.desc()
@@ -319,7 +332,7 @@ class WinogradConvOp(ConvOp):
         d = self.desc()
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_winograd_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_winograd_plan')
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2, false>' % (self.CFG_TILE[cfg.value] + (bk.value,))
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 2, 0>' % (self.CFG_TILE[cfg.value] + (bk.value,))
 
     def mfma_flops(self):
         """FLOPs the 16 GEMMs actually execute (algorithmic flops() stays the nominal 2*M*N*K)."""
@@ -404,7 +417,7 @@ class CostVolumeConvOp(Op):
                           cout_pad=-(-self.y.shape[3] // 32) * 32, ldy=self.y.ld, kh=3, kw=3, stride=1, config=self.config)
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
-        return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 3, false>' % ConvOp.CFG_TILE[cfg.value]
+        return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 3, 0>' % ConvOp.CFG_TILE[cfg.value]
 
     def launch(self, lib, stream):
         n, h, w, c = self.f2.shape
@@ -543,7 +556,10 @@ class Graph(object):
         # 'f32': exact fp32 MFMA everywhere (the parity path).  'f16': convolutions with
         # Cin % 32 == 0 round their operands to fp16 while staging (fp32 accumulate, fp32
         # activations in memory) -- BASELINE config 5 "fp16 convs + fp32 Kalman", own tolerance.
+        # 'f16x3': forward convs split every operand into hi+lo halfs (3 fp16 MFMAs per product,
+        # fp32 accumulate): fp32-class accuracy at the fp16 MFMA rate (experimental, opt-in).
         self.conv_operands = 'f32'
+        self.f16x3_min_channels = 64
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 
     # -- construction -------------------------------------------------------------------

@@ -23,7 +23,7 @@ def sync():
 
 
 def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config=0, ldx=None, ldy=None,
-             x_off=0, y_off=0, f16=False):
+             x_off=0, y_off=0, f16=False, x3=False):
     """x [N,H,W,Cin] np fp32; w TF layout; returns y np [N,Ho,Wo,Cout] computed by the HIP library.
     ldx/ldy > C exercise the strided-view paths (input/output living in wider buffers)."""
     import torch
@@ -43,11 +43,17 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     xb[:, x_off:x_off + cin] = x.reshape(-1, cin)
     xd = dev(xb)
     yd = torch.full((n * ho * wo, ldy), -123.0, dtype=torch.float32, device='cuda')
-    wd_ = dev(wp.astype(np.float16) if f16 else wp)
+    if x3:
+        m = wp * np.float32(1024.0)
+        hi = m.astype(np.float16)
+        wp_dev = np.stack([hi, (m - hi.astype(np.float32)).astype(np.float16)])
+    else:
+        wp_dev = wp.astype(np.float16) if f16 else wp
+    wd_ = dev(wp_dev)
     bd = dev(b.astype(np.float32)) if b is not None else None
     d = _lib.ConvDesc(N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, cout_pad=wp.shape[0], ldy=ldy, kh=kh, kw=kw,
                       stride=stride, transposed=int(transposed), relu=int(relu), epilogue=epilogue, config=config,
-                      operand_dtype=int(f16))
+                      operand_dtype=2 if x3 else int(f16))
     rc = lib.kfn_conv2d_nhwc(C.byref(d), xd.data_ptr() + 4 * x_off, wd_.data_ptr(),
                              bd.data_ptr() if bd is not None else None, yd.data_ptr() + 4 * y_off, stream())
     _lib.check(rc, 'kfn_conv2d_nhwc')

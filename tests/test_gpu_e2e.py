@@ -221,3 +221,28 @@ def test_config5_fp16_convs_fp32_kalman():
     print('fp16-operand convs: coord max-abs %.3g, confidence max-rel %.3g' % (dc, dr))
     assert dc <= 2e-2 and dr <= 5e-2
     assert dc > 1e-6   # and it is measurably not the fp32 path
+
+
+@pytest.mark.parametrize('size,batch', [((64, 96), 2), ((480, 640), 3)])
+def test_f16x3_split_mode_meets_fp32_tolerance(size, batch):
+    """conv_operands='f16x3' (operands split into hi+lo halfs, 3 fp16 MFMA products, fp32
+    accumulate) must meet the SAME tolerance as the fp32 path: coord max-abs <= 1e-4,
+    confidence max-rel <= 1e-4."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.graph import ConvOp
+    from kfnet_amd import _lib
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    imgs = synthetic_sequence(4, size[0], size[1], seed=1)
+    T4 = O.get_transform(synthetic_transform())
+    if size[0] <= 64:
+        ref = O.eval_sequence(imgs, W, T4, reset_period=500, dtype=np.float64)
+    else:
+        ref = OT.eval_sequence(imgs, W, T4, reset_period=500)
+    eng = KFNetEngine(W, image_size=size, batch=batch, transform=T4, reset_period=500, max_chunk=4,
+                      conv_operands='f16x3')
+    assert sum(1 for op in eng.heavy_ops if isinstance(op, ConvOp) and op.operand_dtype == _lib.OPERAND_F16X3) >= 12
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    dc, dr = _check(rec, ref)
+    print('f16x3 %s: coord max-abs %.3g, confidence max-rel %.3g' % (size, dc, dr))

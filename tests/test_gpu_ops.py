@@ -437,3 +437,22 @@ def test_deconv_fp16_operands():
     y = run_conv(x, wt, b, 2, True, transposed=True, f16=True)
     ref = O.conv2d_transpose_same(x.astype(np.float16).astype(np.float64), wt.astype(np.float16).astype(np.float64), b, 2, True)
     assert np.abs(y - ref).max() <= _conv_tol(x, wt, True)
+
+
+@pytest.mark.parametrize('case', F16_CASES)
+@pytest.mark.parametrize('config', [0, 1, 2, 6])
+def test_conv_f16x3_split_operands(case, config):
+    """operand_dtype = F16X3 (hi/lo split, 3 fp16 MFMA products, fp32 accumulate) must be
+    fp32-class accurate against the fp64 convolution of the ORIGINAL fp32 operands."""
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co, k, s = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32) * 3
+    wt = (rng.normal(size=(k, k, ci, co)) * np.sqrt(2.0 / (k * k * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, s, True, config=config, x3=True)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, s, True)
+    d32 = O.conv2d_same(x, wt, b, s, True)
+    err, err32 = np.abs(y - ref).max(), np.abs(d32 - ref).max()
+    print('f16x3 err %.3g vs plain fp32 err %.3g (scale %.3g)' % (err, err32, np.abs(ref).max()))
+    assert err <= 4 * _conv_tol(x, wt)
