@@ -1,51 +1,55 @@
-"""OFlowNet, the process-model head over the local cost volume -- same class surface as
-the reference's cnn_wrapper/OFlowNet.py:6-57."""
+"""Process-model head: a small U-Net over every pixel's 8x8x32 local cost volume, behind
+the reference's `OFlowNet` class surface `(inputs, window_area, is_training, reuse)`,
+`setup()`, `GetOutput()` (reference: cnn_wrapper/OFlowNet.py:6-57).
+
+Encoder 8x8 -> 4x4 -> 2x2 -> 1x1, decoder back up with skip concatenations:
+
+    conv0 (32) - conv1a (32, /2) - conv1b (32) - conv2a (64, /2) - conv2b (64)
+        - conv3a (128, /2) - conv3b (128) - upconv2 (64, x2)
+    concat2 = [upconv2, conv2b] - conv4 (64) - upconv1 (32, x2)
+    concat1 = [upconv1, conv1b] - conv5 (32) - upconv0 (16, x2)
+    concat0 = [upconv0, conv0 ] - conv6 (16) - prediction (1, linear)
+    heads: softmax over the 64 'prediction' cells; fc1 (64) - fc2 (32) - uncertainty (1) on conv3b
+"""
 from .. import _lib
-from ..graph import ConvOp, FlowHeadOp, FlowOp, as_f16, pack_bias, pack_dense_kernel, pack_flow_head_kernel
+from ..graph import (ConvOp, FlowHeadOp, FlowOp, as_f16, pack_bias, pack_dense_kernel,
+                     pack_flow_head_kernel)
 from .network import Network
 
+# Program for Network: ('conv'|'deconv', name, channels, stride) or ('join', name, producer, skip)
+ENCODER = (('conv', 'conv0', 32, 1), ('conv', 'conv1a', 32, 2), ('conv', 'conv1b', 32, 1),
+           ('conv', 'conv2a', 64, 2), ('conv', 'conv2b', 64, 1), ('conv', 'conv3a', 128, 2),
+           ('conv', 'conv3b', 128, 1), ('deconv', 'upconv2', 64, 2))
+DECODER = (('join', 'concat2', 'upconv2', 'conv2b'), ('conv', 'conv4', 64, 1), ('deconv', 'upconv1', 32, 2),
+           ('join', 'concat1', 'upconv1', 'conv1b'), ('conv', 'conv5', 32, 1), ('deconv', 'upconv0', 16, 2),
+           ('join', 'concat0', 'upconv0', 'conv0'), ('conv', 'conv6', 16, 1))
+LOGITS = 'prediction'
+FC = (('fc1', 64, True), ('fc2', 32, True), ('uncertainty', 1, False))
 
-# Input BxHxWxN cost volume
-# Outout BxHxWx3 coordinate map & BxHxWx1 uncertainty map
+
+# Input BHWx8x8xC cost volume; output flow probabilities and transition uncertainty
 class OFlowNet(Network):
     def __init__(self, inputs, window_area, is_training, reuse=False):
-        images = inputs['input']
-        shape = images.get_shape().as_list()
-        self.batch_size = shape[0]
-        self.height = shape[1]
-        self.width = shape[2]
+        n, h, w = inputs['input'].get_shape().as_list()[:3]
+        self.batch_size, self.height, self.width = n, h, w   # set before setup() runs, as in the reference
         self.window_area = window_area
-
         Network.__init__(self, inputs, is_training, reuse=reuse)
 
     def setup(self):
-        (self.feed('input')
-         .conv(3, 32, 1, name='conv0')  # 8x8x32
-         .conv(3, 32, 2, name='conv1a') # 4x4x32
-         .conv(3, 32, 1, name='conv1b') # 4x4x32
-         .conv(3, 64, 2, name='conv2a') # 2x2x64
-         .conv(3, 64, 1, name='conv2b') # 2x2x64
-         .conv(3, 128, 2, name='conv3a')  # 1x1x128
-         .conv(3, 128, 1, name='conv3b')  # 1x1x128
-         .deconv(3, 64, 2, name='upconv2'))    # 2x2x64
-
-        (self.feed('upconv2', 'conv2b')
-         .concat(-1, name='concat2')    # 2x2x128
-         .conv(3, 64, 1, name='conv4')  # 2x2x64
-         .deconv(3, 32, 2, name='upconv1')) # 4x4x32
-
-        (self.feed('upconv1', 'conv1b')
-         .concat(-1, name='concat1')    # 4x4x64
-         .conv(3, 32, 1, name='conv5')  # 4x4x32
-         .deconv(3, 16, 2, name='upconv0'))  # 8x8x16
-
-        (self.feed('upconv0', 'conv0')
-         .concat(-1, name='concat0')    # 8x8x48
-         .conv(3, 16, 1, name='conv6')   # 8x8x16
-         .conv(3, 1, 1, relu=False, name='prediction')) # 8x8x1
+        net = self.feed('input')
+        for step in ENCODER + DECODER:
+            kind, name = step[0], step[1]
+            if kind == 'join':
+                net = self.feed(step[2], step[3]).concat(-1, name=name)
+            elif kind == 'deconv':
+                net = net.deconv(3, step[2], step[3], name=name)
+            else:
+                net = net.conv(3, step[2], step[3], name=name)
+        net.conv(3, 1, 1, relu=False, name=LOGITS)
 
     def _dense(self, x, units, name, relu, epilogue=_lib.EPI_NONE):
-        """tf.layers.dense (OFlowNet.py:50-55) == 1x1 conv on a [BHW,1,1,C] tensor."""
+        """Fully connected layer (tf.layers.dense in the reference, OFlowNet.py:50-55) run as a
+        1x1 convolution on the [BHW,1,1,C] tensor."""
         g = self.graph
         n, h, w, cin = x.shape
         y = g.tensor((n, h, w, units), name=name)
@@ -58,37 +62,37 @@ class OFlowNet(Network):
         return y
 
     def GetOutput(self):
-        """prob = softmax over the window cells of `prediction`; uncertainty =
-        exp(fc3(fc2(fc1(conv3b)))) * 1e-2  (OFlowNet.py:43-57).
+        """Returns (prob_map [BHW,1,1,window_area], uncertainty [BHW,1,1,1]) like reference
+        OFlowNet.py:43-57: softmax over the window cells of `prediction`, and
+        exp(fc3(fc2(fc1(conv3b)))) * 1e-2.
 
-        Returns (prob_map [BHW,1,1,window_area], uncertainty [BHW,1,1,1]).  The same kernel
-        that evaluates the softmax also produces the soft-argmax flow that
-        KFNet.BuildOFlowNet derives from prob (KFNet/KFNet.py:381-385); it is attached as
-        `prob_map.flow` ([BHW,1,1,2]) so the caller does not need a second pass.  The
-        probabilities themselves are only written when `graph.debug_prob` is set."""
+        The kernel that evaluates the softmax also produces the soft-argmax flow that
+        KFNet.BuildOFlowNet derives from the probabilities (reference KFNet.py:381-385); it is
+        attached as `prob_map.flow` ([BHW,1,1,2]).  With `graph.fuse_flow_head` the
+        `prediction` convolution itself is absorbed too (kfn_flow_head) and the probabilities are
+        only materialised when `graph.debug_prob` is set."""
         g = self.graph
-        output = self.get_output_by_name('prediction')  # BHWx8x8x1
-        n = output.shape[0]
-        window = output.shape[1]
-        assert output.shape[1] * output.shape[2] == self.window_area and output.is_whole()
+        logits = self.get_output_by_name(LOGITS)  # BHW x 8 x 8 x 1
+        n, window = logits.shape[0], logits.shape[1]
+        assert logits.shape[1] * logits.shape[2] == self.window_area and logits.is_whole()
         prob_map = g.tensor((n, 1, 1, self.window_area), name='prob')
         flow = g.tensor((n, 1, 1, 2), name='flow')
-        pred_op = [op for op in self.ops if op.name == 'prediction'][0]
+        pred_op = [op for op in self.ops if op.name == LOGITS][0]
         x = pred_op.x
-        if (g.fuse_flow_head and not g.debug_prob and window == 8 and x.is_whole() and x.shape[3] % 4 == 0
-                and x.shape[3] <= 32):
-            # the 'prediction' conv is absorbed into the flow head: its 64 logits per pixel are
-            # produced and consumed on chip (the 'prediction' layer tensor is not written)
+        fusable = (g.fuse_flow_head and not g.debug_prob and window == 8 and x.is_whole()
+                   and x.shape[3] % 4 == 0 and x.shape[3] <= 32)
+        if fusable:
+            # the logits are produced and consumed on chip; the 'prediction' tensor is not written
             g.ops.remove(pred_op)
             self.ops.remove(pred_op)
             kern = g.params[pred_op.kernel.name]
             kern.pack = pack_flow_head_kernel
             self._emit(FlowHeadOp(x, kern, pred_op.bias, flow))
         else:
-            self._emit(FlowOp(output, flow, prob_map if g.debug_prob else None, window))
+            self._emit(FlowOp(logits, flow, prob_map if g.debug_prob else None, window))
         prob_map.flow = flow
-        feat = self.get_output_by_name('conv3b')  # BHWx1x1x128
-        fc1 = self._dense(feat, 64, 'fc1', True)
-        fc2 = self._dense(fc1, 32, 'fc2', True)
-        uncertainty = self._dense(fc2, 1, 'uncertainty', False, epilogue=_lib.EPI_EXP_1E2)
-        return prob_map, uncertainty
+        feat = self.get_output_by_name('conv3b')  # BHW x 1 x 1 x 128
+        for name, units, relu in FC:
+            last = (name == FC[-1][0])
+            feat = self._dense(feat, units, name, relu, epilogue=_lib.EPI_EXP_1E2 if last else _lib.EPI_NONE)
+        return prob_map, feat

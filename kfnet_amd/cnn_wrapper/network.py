@@ -26,24 +26,26 @@ except NameError:
 
 
 def layer(op):
-    """Decorator for composable network layers (cnn_wrapper/network.py:8-31)."""
+    """Makes a method chainable the way the reference's decorator does (network.py:8-31):
+    the wrapped method consumes the current terminal tensor(s), its result is registered in
+    `self.layers` under the (possibly auto-generated) `name` keyword, becomes the new
+    terminal, and the network itself is returned so that calls can be chained."""
 
-    def layer_decorated(self, *args, **kwargs):
-        name = kwargs.setdefault('name', self.get_unique_name(op.__name__))
-        if not self.terminals:
-            raise RuntimeError('No input variables found for layer %s.' % name)
-        elif len(self.terminals) == 1:
-            layer_input = self.terminals[0]
-        else:
-            layer_input = list(self.terminals)
-        layer_output = op(self, layer_input, *args, **kwargs)
-        self.layers[name] = layer_output
-        self.feed(layer_output)
-        return self
+    def chained(net, *args, **kwargs):
+        if 'name' not in kwargs:
+            kwargs['name'] = net.get_unique_name(op.__name__)
+        label = kwargs['name']
+        fed = net.terminals
+        if len(fed) == 0:
+            raise RuntimeError('No input variables found for layer %s.' % label)
+        result = op(net, fed[0] if len(fed) == 1 else list(fed), *args, **kwargs)
+        net.layers[label] = result
+        net.feed(result)
+        return net
 
-    layer_decorated.__name__ = op.__name__
-    layer_decorated.__doc__ = op.__doc__
-    return layer_decorated
+    chained.__name__ = op.__name__
+    chained.__doc__ = op.__doc__
+    return chained
 
 
 class PreprocessedImage(object):
@@ -74,70 +76,68 @@ def _off_path(name):
 
 
 class Network(object):
-    """Class NetWork"""
+    """Base class of the layer DSL; subclasses describe their architecture in `setup()`."""
 
     def __init__(self, inputs, is_training, dropout_rate=0.5, seed=None, reuse=False):
-        self.inputs = inputs
-        self.terminals = []
-        self.layers = dict(inputs)
-        self.trainable = is_training
+        self.inputs = inputs              # name -> input tensor
+        self.layers = dict(inputs)        # name -> tensor of every layer built so far
+        self.terminals = []               # tensor(s) the next layer call will consume
+        self.trainable = self.training = is_training   # kept for signature parity (inference only here)
         self.reuse = reuse
-        self.training = is_training
         self.seed = seed
         self.dropout_rate = dropout_rate
-        self.ops = []  # launches appended by this network, in order
+        self.ops = []                     # launches appended by this network, in order
         self.setup()
 
     def setup(self):
-        '''Construct the network. '''
         raise NotImplementedError('Must be implemented by the subclass.')
 
     # ------------------------------------------------------------------------------
     @property
     def graph(self):
-        for v in self.inputs.values():
-            return v.graph
+        for tensor in self.inputs.values():
+            return tensor.graph
         raise RuntimeError('network has no inputs')
 
     def load(self, data_path, session=None, ignore_missing=False):
-        '''Load network weights from the reference's numpy dict format
-        {op_name: {param_name: array}} (cnn_wrapper/network.py:60-75).  `session` is
-        accepted for signature compatibility; weights go to the graph's device buffers.'''
-        from ..weights import from_network_load_dict
+        """Weights from the reference's numpy dict format {op_name: {param_name: array}}
+        (network.py:60-75).  `session` is accepted for signature compatibility; the arrays go
+        to the graph's device buffers under the variable scope active at call time."""
         from ..graph import current_scope
-        data_dict = np.load(data_path, allow_pickle=True).item()
-        flat = from_network_load_dict(data_dict, current_scope() or self._scope)
-        self.graph.load_weights(flat, strict=not ignore_missing)
+        from ..weights import from_network_load_dict
+        table = np.load(data_path, allow_pickle=True).item()
+        self.graph.load_weights(from_network_load_dict(table, current_scope()), strict=not ignore_missing)
 
     def feed(self, *args):
-        '''Set the input(s) for the next operation by replacing the terminal nodes.
-        The arguments can be either layer names or the actual layers.'''
-        assert args
-        self.terminals = []
-        for fed_layer in args:
-            if isinstance(fed_layer, string_types):
-                try:
-                    fed_layer = self.layers[fed_layer]
-                except KeyError:
-                    raise KeyError('Unknown layer name fed: %s' % fed_layer)
-            self.terminals.append(fed_layer)
+        """Select the input(s) of the next layer call: layer names or tensors."""
+        if not args:
+            raise AssertionError('feed() needs at least one layer')
+        picked = []
+        for item in args:
+            if isinstance(item, string_types):
+                if item not in self.layers:
+                    raise KeyError('Unknown layer name fed: %s' % item)
+                item = self.layers[item]
+            picked.append(item)
+        self.terminals = picked
         return self
 
     def get_output(self):
-        '''Returns the current network output.'''
+        """The most recent terminal."""
         return self.terminals[-1]
 
     def get_output_by_name(self, layer_name):
         return self.layers[layer_name]
 
     def get_unique_name(self, prefix):
-        ident = sum(t.startswith(prefix) for t, _ in self.layers.items()) + 1
-        return '%s_%d' % (prefix, ident)
+        """`<prefix>_<n>` with n = 1 + number of existing layers whose name starts with prefix."""
+        taken = [label for label in self.layers if label.startswith(prefix)]
+        return '%s_%d' % (prefix, len(taken) + 1)
 
     def change_inputs(self, inputs):
-        assert len(inputs) == 1
-        for key in inputs:
-            self.layers[key] = inputs[key]
+        if len(inputs) != 1:
+            raise AssertionError('change_inputs() takes exactly one input')
+        self.layers.update(inputs)
 
     def _emit(self, op):
         self.graph.add(op)
