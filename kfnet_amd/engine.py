@@ -168,6 +168,8 @@ class KFNetEngine(object):
     def process(self, dev_frames, t0=0):
         """heavy + scan; returns the device records tensor view [T,h,w,4] (torch)."""
         T = dev_frames.shape[0]
+        if T == 0:   # empty chunk: nothing to do, state untouched
+            return self.records(0)
         self.heavy(dev_frames, T)
         self.scan(T, t0)
         return self.records(T)

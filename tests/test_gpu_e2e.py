@@ -246,3 +246,23 @@ def test_f16x3_split_mode_meets_fp32_tolerance(size, batch):
     rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
     dc, dr = _check(rec, ref)
     print('f16x3 %s: coord max-abs %.3g, confidence max-rel %.3g' % (size, dc, dr))
+
+
+def test_edge_cases_empty_single_and_ragged_chunks():
+    """Empty chunk, single frame, T < batch, and ragged chunking all agree with one pass."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(11)
+    imgs = synthetic_sequence(7, 64, 96, seed=12)
+    eng = KFNetEngine(W, image_size=(64, 96), batch=4, reset_period=500, max_chunk=8)
+    dev = eng.upload_frames(imgs)
+    one = eng.process(dev).cpu().numpy().copy()
+    eng2 = KFNetEngine(W, image_size=(64, 96), batch=4, reset_period=500, max_chunk=8)
+    assert tuple(eng2.process(dev[:0]).shape) == (0, 8, 12, 4)
+    parts = []
+    for lo, hi in ((0, 1), (1, 1), (1, 3), (3, 7)):       # single frame, empty, T < batch, rest
+        parts.append(eng2.process(dev[lo:hi], t0=lo).cpu().numpy().copy())
+    assert np.array_equal(np.concatenate(parts), one)
+    with pytest.raises(ValueError):
+        eng2.process(eng2.upload_frames(synthetic_sequence(9, 64, 96)))   # exceeds max_chunk
