@@ -31,7 +31,7 @@ def grid_size(image_hw):
 class KFNetEngine(object):
     def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
                  nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False,
-                 conv_operands='f32'):
+                 conv_operands='f32', use_graph=False):
         import torch
         self.torch = torch
         self.B = int(batch)
@@ -91,6 +91,12 @@ class KFNetEngine(object):
         self.ev_first = torch.cuda.Event()
         self.ev_side = torch.cuda.Event()
         self.two_streams = True
+        # Optional hipGraph replay of the (full-batch) heavy phase: every C-ABI launch is
+        # stream-ordered and allocation-free, so the whole two-stream schedule of a batch is
+        # captured once and replayed with a single host call (matters when batches are
+        # small / launch-bound, e.g. batch=1 latency mode).
+        self.use_graph = bool(use_graph)
+        self._graph = None
         self.tuned = None
         if autotune:
             g.active = (self.B, self.B)
@@ -140,7 +146,9 @@ class KFNetEngine(object):
         for s0 in range(0, T, self.B):
             cnt = min(self.B, T - s0)
             self._set_batch_images(dev_frames, s0, cnt, stream)
-            if self.two_streams:
+            if self.use_graph and cnt == self.B:
+                self._replay_heavy_graph()
+            elif self.two_streams:
                 main = self.torch.cuda.current_stream(self.device)
                 self.graph.run(stream, [self.first_op], active=(cnt, self.B))
                 self.ev_first.record(main)
@@ -158,6 +166,32 @@ class KFNetEngine(object):
             _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + d0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
             self.handover.src = ring.batch(cnt, 1)
             self.handover.launch(lib, stream)
+
+    def _launch_heavy_full(self, stream_ptr, main):
+        """Full-batch heavy phase on (main, side) streams; used directly and under capture."""
+        B = self.B
+        self.graph.run(stream_ptr, [self.first_op], active=(B, B))
+        self.ev_first.record(main)
+        self.side_stream.wait_event(self.ev_first)
+        self.graph.run(self.side_stream.cuda_stream, self.side_ops, active=(B, B))
+        self.ev_side.record(self.side_stream)
+        self.graph.run(stream_ptr, self.main_ops, active=(B, B))
+        main.wait_event(self.ev_side)
+
+    def _replay_heavy_graph(self):
+        torch = self.torch
+        if self._graph is None:
+            main = torch.cuda.current_stream(self.device)
+            self._launch_heavy_full(main.cuda_stream, main)   # warm-up outside capture (one-time attributes)
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream(device=self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(g, stream=cap):
+                    cur = torch.cuda.current_stream(self.device)
+                    self._launch_heavy_full(cur.cuda_stream, cur)
+            self._graph = g
+        self._graph.replay()
 
     def scan(self, T, t0=0):
         """Sequential phase: one launch over the T frames staged by `heavy`."""

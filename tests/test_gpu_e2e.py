@@ -266,3 +266,19 @@ def test_edge_cases_empty_single_and_ragged_chunks():
     assert np.array_equal(np.concatenate(parts), one)
     with pytest.raises(ValueError):
         eng2.process(eng2.upload_frames(synthetic_sequence(9, 64, 96)))   # exceeds max_chunk
+
+
+def test_hipgraph_replay_of_heavy_phase_is_bit_identical():
+    """The C ABI claims every launch is hipGraph-capturable: capture the two-stream heavy phase
+    of a batch once, replay it for every batch, and get bit-identical records."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(21)
+    imgs = synthetic_sequence(9, 64, 96, seed=22)
+    a = KFNetEngine(W, image_size=(64, 96), batch=3, reset_period=500, max_chunk=9)
+    ref = a.process(a.upload_frames(imgs)).cpu().numpy().copy()
+    b = KFNetEngine(W, image_size=(64, 96), batch=3, reset_period=500, max_chunk=9, use_graph=True)
+    got = b.process(b.upload_frames(imgs)).cpu().numpy().copy()
+    assert b._graph is not None
+    assert np.array_equal(got, ref)
