@@ -142,9 +142,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int nwg = p.tiles_m * p.tiles_n * (WINO ? 16 : 1);
   int tile = xcd_remap(blockIdx.x, nwg);
   int grp = 0;
-  if (WINO) {  // group fastest: the 16 GEMMs of one (m,n) tile run together and share the
-    grp = tile & 15;  // same source pixels through the XCD's L2
-    tile >>= 4;
+  if (WINO) {
+    if (p.rot_mode == 3) {  // experiment: group slowest
+      const int per = p.tiles_m * p.tiles_n;
+      grp = tile / per;
+      tile -= grp * per;
+    } else {  // group fastest: the 16 GEMMs of one (m,n) tile run together and share the
+      grp = tile & 15;  // same source pixels through the XCD's L2
+      tile >>= 4;
+    }
   }
   const int tn = tile % p.tiles_n;
   const int tm = tile / p.tiles_n;
@@ -653,9 +659,10 @@ int auto_config(int M, int Cout, int num_cu, bool wino = false) {
   double best = -1.0;
   int best_cfg = KFN_CFG_128x32;
   for (const TileCfg& c : kCfgs) {
-    long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn);
+    const long groups = wino ? 16 : 1;  // the 16 Winograd GEMMs are one launch
+    long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn) * groups;
     long rounds = (tiles + num_cu - 1) / num_cu;
-    double eff = ((double)M * Cout) / ((double)rounds * num_cu * c.bm * c.bn) * (wino ? c.wprior : c.prior);
+    double eff = ((double)M * Cout * groups) / ((double)rounds * num_cu * c.bm * c.bn) * (wino ? c.wprior : c.prior);
     if (eff > best) {
       best = eff;
       best_cfg = c.cfg;
