@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the heavy phase of full batches from a captured hipGraph')
     ap.add_argument('--autotune', action='store_true',
                     help='time every tile config per layer at start-up (the heuristic is within ~2%% of it)')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-kalman-roofline', action='store_true')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
                     help="f16 = BASELINE config 5's fp16-operand convs (fp32 accumulate, fp32 Kalman); NOT the headline")
