@@ -35,7 +35,8 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=136)
+    ap.add_argument('--steps', type=int, default=256,
+                    help='frames per GPU in the timed region (BASELINE config 3: a 256-frame sequence)')
     ap.add_argument('--warmup', type=int, default=17)
     ap.add_argument('--batch', type=int, default=17,
                     help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
