@@ -611,7 +611,8 @@ struct TileCfg {
 const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x128, 128, 128, 0.87, 0.77},
                          {KFN_CFG_192x64, 192, 64, 0.78, 0.66},   {KFN_CFG_128x64, 128, 64, 0.76, 0.66},
                          {KFN_CFG_256x32, 256, 32, 0.70, 0.45},   {KFN_CFG_128x32, 128, 32, 0.60, 0.45},
-                         {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0}};
+                         {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0},
+                         {KFN_CFG_128x256, 128, 256, 0.0, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -650,6 +651,7 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, BK, TR, F16>(a, s);
     case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR, F16>(a, s);
     case KFN_CFG_160x256: return launch_cfg<5, 1, 1, 8, BK, TR, F16>(a, s);
+    case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, BK, TR, F16>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }

@@ -300,7 +300,7 @@ class ConvOp(Op):
         return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
 
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
-                6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8)}
+                6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2)}
 
     def kernel_name(self, lib):
         """Template instantiation this op launches, spelled like rocprofv3 prints it."""

@@ -35,7 +35,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv_vs_oracle(case, config):
     from tests.gpu_util import run_conv
     n, h, w, ci, co, k, s, relu = case

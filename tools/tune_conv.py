@@ -28,7 +28,7 @@ for op in eng.heavy_ops:
     if not isinstance(op, ConvOp) or op.epilogue == _lib.EPI_L2NORM: continue
     if len(sys.argv) > 2 and op.name not in sys.argv[2].split(','): continue
     res = {}
-    for cfg in (0, 1, 2, 8, 7, 3, 6, 4, 5):
+    for cfg in (0, 1, 2, 9, 8, 7, 3, 6, 4, 5):
         op.config = cfg
         try: res[cfg] = t(op)
         except _lib.KfnError: pass
