@@ -131,6 +131,13 @@ int kfn_winograd_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tile
 int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* u_packed,
                         const float* bias, float* y, float* workspace, int phases, void* stream);
 
+/* Single-kernel variant of the above: one workgroup computes all 16 (xi,nu) GEMMs of its
+ * 64-tile x 64-channel block and applies A^T M A in registers -- no workspace, every source
+ * pixel fetched once per workgroup.  Same arguments/result as kfn_conv2d_winograd
+ * (Cin % 8 == 0; fp32 only). */
+int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const float* u_packed,
+                              const float* bias, float* y, void* stream);
+
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
  * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature
  * tower's preprocess + feat1 (KFNet/KFNet.py:317-320) in ONE pass over the image.

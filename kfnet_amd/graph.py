@@ -345,6 +345,12 @@ class WinogradConvOp(ConvOp):
 
     def launch(self, lib, stream, phases=3):
         d = self.desc()
+        if self.x.graph.winograd_fused:
+            if phases & 1:
+                rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                                   self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+                _lib.check(rc, 'kfn_conv2d_winograd_fused[%s]' % self.name)
+            return
         rc = lib.kfn_conv2d_winograd(C.byref(d), self.x.ptr, self.kernel.ptr,
                                      self.bias.ptr if self.bias is not None else None, self.y.ptr,
                                      self.workspace.ptr, phases, stream)
@@ -553,6 +559,7 @@ class Graph(object):
         # the 2.25x MFMA saving.
         self.winograd_min_channels = 128
         self.winograd_ws = None
+        self.winograd_fused = False  # single-kernel Winograd (all 16 groups per workgroup, no workspace)
         # 'f32': exact fp32 MFMA everywhere (the parity path).  'f16': convolutions with
         # Cin % 32 == 0 round their operands to fp16 while staging (fp32 accumulate, fp32
         # activations in memory) -- BASELINE config 5 "fp16 convs + fp32 Kalman", own tolerance.

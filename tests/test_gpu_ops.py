@@ -456,3 +456,32 @@ def test_conv_f16x3_split_operands(case, config):
     err, err32 = np.abs(y - ref).max(), np.abs(d32 - ref).max()
     print('f16x3 err %.3g vs plain fp32 err %.3g (scale %.3g)' % (err, err32, np.abs(ref).max()))
     assert err <= 4 * _conv_tol(x, wt)
+
+
+@pytest.mark.parametrize('case', WINO_CASES + [(2, 30, 40, 64, 96), (1, 9, 70, 8, 32)])
+def test_winograd_fused_vs_oracle(case):
+    """kfn_conv2d_winograd_fused (all 16 groups in one workgroup, inverse transform in
+    registers, no workspace) == oracle."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 5)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy = co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=1, relu=1)
+    y = torch.full((n * h * w, ldy), -5.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_kernel(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                             stream()), 'wino16')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, co:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
+    assert err <= 3 * _conv_tol(x, wt), err

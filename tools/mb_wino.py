@@ -21,6 +21,7 @@ for (N, H, W, ci, co) in [(17, 60, 80, 1024, 1024), (17, 120, 160, 512, 512), (1
     d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1)
     t_gemm = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, st), 'w'))
     t_out = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 2, st), 'w'))
+    t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 'wf'))
     fl = 2.0 * 16 * Mt * ci * co
     # 1x1 conv with the same MFMA work: M = 16*Mt rows
     v = torch.randn(16 * Mt * ci, device='cuda')
@@ -30,6 +31,6 @@ for (N, H, W, ci, co) in [(17, 60, 80, 1024, 1024), (17, 120, 160, 512, 512), (1
     dd = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1)
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(dd), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
-    print('%dx%d C%d: wino gemm %.3f ms (%.1f TF exec), out %.3f ms | 1x1 same-work %.3f ms (%.1f TF) | direct %.3f ms (%.1f TF)'
-          % (H, W, ci, t_gemm, fl / t_gemm / 1e9, t_out, t_1x1, fl / t_1x1 / 1e9, t_dir, fl * 2.25 / t_dir / 1e9))
+    print('%dx%d C%d: FUSED %.3f ms (%.1f TF exec) | wino gemm %.3f ms (%.1f TF exec), out %.3f ms | 1x1 same-work %.3f ms (%.1f TF) | direct %.3f ms (%.1f TF)'
+          % (H, W, ci, t_fused, fl / t_fused / 1e9, t_gemm, fl / t_gemm / 1e9, t_out, t_1x1, fl / t_1x1 / 1e9, t_dir, fl * 2.25 / t_dir / 1e9))
     del x, u, y, ws, v, w9
