@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=17,
                     help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-host-streamed', action='store_true',
+                    help='skip the PCIe-inclusive run (frames from pinned host memory)')
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip the extra (non-headline) measurement of the f16x3 split-operand mode')
     ap.add_argument('--one-stream', action='store_true', help='serialise the two towers on one stream')
@@ -196,6 +198,31 @@ def kalman_fuse_roofline(device, P=256 * 64 * 4800):
             'shape': 'P=%d px, 48 B/px (BuildKFCoord only)' % P, 'avg_launch_ms': round(ms, 4)}
 
 
+def host_streamed(eng, host_frames, dev_frames):
+    """PCIe-inclusive rate (never the headline `value`): the same frames start in pinned HOST
+    memory and the records end there; uploads (0.92 MB/frame) and downloads (76.8 KB/frame)
+    run on their own streams beside the compute (kfnet_amd/pipeline.py)."""
+    import torch
+    from kfnet_amd.pipeline import ChunkLoader, StreamedSequence
+    K = int(host_frames.shape[0])
+    chunk = max(eng.B, min(4 * eng.B, eng.max_chunk))
+    runner = StreamedSequence(eng, chunk)
+    pinned = torch.from_numpy(np.ascontiguousarray(host_frames)).pin_memory()
+    chunks = [(lo, pinned[lo:lo + chunk]) for lo in range(0, K, chunk)]
+    for _ in runner.run(chunks[:2]):       # warm the copy streams
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for lo, rec in runner.run(chunks):
+        last = (lo, rec)
+    dt = time.perf_counter() - t0
+    ref = eng.process(dev_frames, t0=0)[last[0]:last[0] + last[1].shape[0]].cpu().numpy()
+    return {'value': round(K / dt, 3), 'unit': 'frames/s', 'chunk': chunk,
+            'bit_identical_to_resident_run': bool(np.array_equal(ref, last[1])),
+            'note': 'frames from pinned host memory, records back to host; H2D/D2H overlapped with compute'}
+
+
 def cpu_baseline(frames, W, T4, steps):
     """Reference-faithful CPU restatement (oracle/kfnet_oracle_torch.py): both towers on a
     2-frame batch per step, 64 materialised shifts, unfused ops (KFNet/eval.py:41,77-104)."""
@@ -212,9 +239,17 @@ def cpu_baseline(frames, W, T4, steps):
         rec, sx, ss = OT.eval_step_reference_style(pair, W, sx, ss, T4, i % 500 == 0)
         recs.append(rec)
     dt = time.time() - t0
+    # the same restatement with the reference's redundancy removed (towers once per frame,
+    # SURVEY.md F9), so that the GPU/CPU ratio can be read without it
+    nd = max(2, min(steps, 3))
+    t1 = time.time()
+    OT.eval_sequence(frames[:nd], W, T4, 500, dedup=True)
+    dt_d = time.time() - t1
     return {'value': round(steps / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'sample': '%d eval.py-style steps (2-frame tower batches, 64 shifts) of the same 480x640 '
-                      'sequence, torch-CPU fp32, %.1f s' % (steps, dt)}, np.stack(recs)
+                      'sequence, torch-CPU fp32, %.1f s' % (steps, dt),
+            'deduplicated_value': round(nd / dt_d, 4),
+            'deduplicated_sample': '%d frames, towers once per frame, %.1f s' % (nd, dt_d)}, np.stack(recs)
 
 
 def main():
@@ -362,6 +397,8 @@ def main():
         if not args.no_kalman_roofline:
             out['roofline_kalman'] = kalman_roofline(device)
             out['roofline_kalman_fuse'] = kalman_fuse_roofline(device)
+        if world == 1 and not args.no_host_streamed:
+            out['host_streamed'] = host_streamed(eng, frames_all[need_prev:], dev_frames)
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames_all[need_prev:need_prev + max(args.cpu_steps, 2)]
             cb, cpu_recs = cpu_baseline(host_frames, Wt, T4, args.cpu_steps)

@@ -37,25 +37,24 @@ def get_transform(transform_file=None):
 
 def load_images(paths, image_size):
     """tf.image.decode_png(channels=3) replacement (KFNet/train.py:213-217)."""
-    from PIL import Image
+    from ..pipeline import decode_image
     H, W = image_size
     out = np.empty((len(paths), H, W, 3), dtype=np.uint8)
     for i, p in enumerate(paths):
-        im = np.asarray(Image.open(p).convert('RGB'))
-        if im.shape[:2] != (H, W):
-            raise ValueError('%s is %s, expected %dx%d' % (p, im.shape, H, W))
-        out[i] = im
+        out[i] = decode_image(p, image_size)
     return out
 
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
-         frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None):
+         frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None,
+         decode_workers=8):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
     returns (records, metrics) in that case."""
     from ..engine import KFNetEngine
     from . import metrics as M
+    from ..pipeline import ChunkLoader, StreamedSequence
     T = len(image_paths) if frames is None else frames.shape[0]
     want_metrics = label_paths is not None or labels is not None
     eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
@@ -66,37 +65,45 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     def label(i):
         return labels[i] if labels is not None else M.read_label(label_paths[i], image_size)
 
-    for lo in range(0, T, chunk):
-        hi = min(T, lo + chunk)
-        host = frames[lo:hi] if frames is not None else load_images(image_paths[lo:hi], image_size)
-        dev = eng.upload_frames(host)
-        rec = eng.process(dev, t0=lo).cpu().numpy()   # state and feature ring carry over
+    def emit(lo, rec):
         records.append(rec)
         if output_folder and os.path.isdir(output_folder):
-            for k in range(hi - lo):
+            for k in range(rec.shape[0]):
                 np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
-        if want_metrics:
-            dbg = eng.debug(hi - lo)
-            for k in range(hi - lo):
-                i = lo + k
-                # pair schedule of KFNet/train.py:67-71: step 0 = (1, 0), step i = (i-1, i)
-                pair = (1, 0) if i == 0 else (i - 1, i)
-                reset = sequence_length > 0 and i % sequence_length == 0
-                m = M.frame_metrics(i, pair, dbg['meas'][k], dbg['temp'][k], rec[k], dbg['nis'][k],
-                                    (label(min(pair[0], T - 1)), label(pair[1])), transform, reset, (eng.h, eng.w))
-                all_metrics.append(m)
-                if verbose:
-                    print(M.format_line(m))
-        elif verbose:
-            print('frames %d~%d done' % (lo, hi - 1))
+
+    # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239)
+    loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
+                         workers=decode_workers)
+    if not want_metrics:
+        # uploads / compute / downloads overlapped on three streams
+        for lo, rec in StreamedSequence(eng, chunk).run(loader):
+            emit(lo, rec.copy())
+            if verbose:
+                print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
+        return np.concatenate(records) if records else np.zeros((0, eng.h, eng.w, 4), np.float32)
+    # with labels: per-frame metrics need the intermediate maps of every chunk on the host
+    for lo, host in loader:
+        hi = lo + int(host.shape[0])
+        dev = eng.upload_frames(host.numpy())
+        rec = eng.process(dev, t0=lo).cpu().numpy()   # state and feature ring carry over
+        emit(lo, rec)
+        dbg = eng.debug(hi - lo)
+        for k in range(hi - lo):
+            i = lo + k
+            # pair schedule of KFNet/train.py:67-71: step 0 = (1, 0), step i = (i-1, i)
+            pair = (1, 0) if i == 0 else (i - 1, i)
+            reset = sequence_length > 0 and i % sequence_length == 0
+            m = M.frame_metrics(i, pair, dbg['meas'][k], dbg['temp'][k], rec[k], dbg['nis'][k],
+                                (label(min(pair[0], T - 1)), label(pair[1])), transform, reset, (eng.h, eng.w))
+            all_metrics.append(m)
+            if verbose:
+                print(M.format_line(m))
     records = np.concatenate(records)
-    if want_metrics:
-        if verbose and all_metrics:
-            for name, fn in (('Median dist error: ', np.median), ('Mean dist error: ', np.mean), ('stddev error: ', np.std)):
-                print(name, fn([m['d_m'] for m in all_metrics]), fn([m['d_t'] for m in all_metrics]),
-                      fn([m['d_kf'] for m in all_metrics]))
-        return records, all_metrics
-    return records
+    if verbose and all_metrics:
+        for name, fn in (('Median dist error: ', np.median), ('Mean dist error: ', np.mean), ('stddev error: ', np.std)):
+            print(name, fn([m['d_m'] for m in all_metrics]), fn([m['d_t'] for m in all_metrics]),
+                  fn([m['d_kf'] for m in all_metrics]))
+    return records, all_metrics
 
 
 def main(argv=None):

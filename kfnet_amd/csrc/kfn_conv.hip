@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   int tile = xcd_remap(blockIdx.x, nwg);
   int grp = 0;
   if (WINO) {
-    if (p.rot_mode == 3) {  // experiment: group slowest
+    if ((p.rot_mode & 3) == 3) {  // experiment: group slowest
       const int per = p.tiles_m * p.tiles_n;
       grp = tile / per;
       tile -= grp * per;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // Concurrent workgroups walk the Cin chunks in ROTATED order: with NHWC the pixel stride
   // is Cin*4 bytes (4 KiB at Cin = 1024), so workgroups in lockstep would all read the same
   // byte range modulo the pixel stride and pile onto the same L2 channels/sets.
-  const int rot = (p.rot_mode == 0) ? 0 : ((tm * 7 + tn * 3 + (p.rot_mode == 2 ? grp * 5 : 0)) % kchunks);
+  const int rot = ((p.rot_mode & 3) == 0 || (p.rot_mode & 3) == 3) ? 0 : ((tm * 7 + tn * 3 + ((p.rot_mode & 3) == 2 ? grp * 5 : 0)) % kchunks);
   int ld_ci = 0;
   int ld_c0 = rot * KCH;
   auto advance = [&]() {
@@ -596,7 +596,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           const int op = out_pix[m - m0];
           if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
         } else {
-          if (n_ok && m < p.M) p.y[((size_t)grp * p.M + m) * p.ldy + n] = v;
+          // Winograd workspace is [tile][16][Cout]: the 16 GEMMs of a tile run together
+          // (group-fastest order) and complete 16*Cout contiguous floats
+          if (n_ok && m < p.M) p.y[(WINO ? (size_t)m * 16 + grp : (size_t)m) * p.ldy + n] = v;
         }
       }
     }
@@ -835,7 +837,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
 
 // ------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) path for 3x3 stride-1 SAME convs: 16 GEMMs (MODE_WINO above) into a
-// [16][tiles][Cout] workspace, then the A^T M A output transform + bias + ReLU.
+// [tiles][16][Cout] workspace, then the A^T M A output transform + bias + ReLU.
 // ------------------------------------------------------------------------------------
 namespace {
 
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     f32x4 m[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g)
-      m[g] = *reinterpret_cast<const f32x4*>(ws + ((size_t)g * Mt + t) * Cout + c4 * 4);
+      m[g] = *reinterpret_cast<const f32x4*>(ws + ((size_t)t * 16 + g) * Cout + c4 * 4);
     // A^T = [[1,1,1,0],[0,1,-1,-1]]
     f32x4 r0[4], r1[4];
 #pragma unroll

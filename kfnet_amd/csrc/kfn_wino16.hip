@@ -4,7 +4,7 @@
 // output channels and ALL 16 transform positions (xi,nu): each wavefront accumulates
 // 16 x (32 tiles x 32 channels) in 256 accumulator registers per lane, so the inverse
 // transform Y = A^T M A is evaluated in registers in the epilogue and the
-// [16][tiles][Cout] workspace of the two-kernel path (kfn_conv2d_winograd) never exists;
+// [tiles][16][Cout] workspace of the two-kernel path (kfn_conv2d_winograd) never exists;
 // every source pixel is fetched once per workgroup (not once per (xi,nu) group).
 //
 // Per k-step of 8 input channels:

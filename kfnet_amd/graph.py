@@ -555,7 +555,7 @@ class Graph(object):
         self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
         self.fuse_cost_volume = True  # BuildCoordVolume generated inside OFlowNet conv0's loader
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
-        # (0 disables).  Below ~128 channels the [16][tiles][Cout] workspace traffic outweighs
+        # (0 disables).  Below ~128 channels the [tiles][16][Cout] workspace traffic outweighs
         # the 2.25x MFMA saving.
         self.winograd_min_channels = 128
         self.winograd_ws = None

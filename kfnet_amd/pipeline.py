@@ -1,0 +1,186 @@
+"""Host side of the image stream: decode -> pinned host chunks -> HBM -> records -> host.
+
+The reference feeds its graph through TF queue runners (KFNet/train.py:195-239:
+`string_input_producer`, `tf.image.decode_png(channels=3)`, `tf.train.batch`, a 2-frame
+batch per step) and fetches every result synchronously (`sess.run`, KFNet/eval.py:77-104).
+Here a sequence is cut into chunks:
+
+* `ChunkLoader`  -- a background thread fills page-locked uint8 buffers [n,H,W,3], decoding
+  the PNGs of chunk k+1 on a small thread pool (PIL releases the GIL while inflating) while
+  chunk k is on the GPU;
+* `StreamedSequence` -- three HIP streams: the upload of chunk k+1 (0.92 MB per frame) and
+  the download of chunk k-1's records (76.8 KB per frame) run beside the compute of chunk
+  k, so PCIe never sits on the critical path.  The Kalman state and the flow-feature ring
+  stay in HBM from chunk to chunk (KFNetEngine).
+
+Nothing here touches the numbers: records are bit-identical to `KFNetEngine.process` on a
+resident sequence (tests/test_gpu_e2e.py).
+"""
+import queue
+import threading
+
+import numpy as np
+
+
+def decode_image(path, image_size):
+    """tf.image.decode_png(channels=3) (KFNet/train.py:213-217): uint8 RGB [H,W,3]."""
+    from PIL import Image
+    H, W = image_size
+    with Image.open(path) as im:
+        a = np.asarray(im.convert('RGB'))
+    if a.shape[:2] != (H, W):
+        raise ValueError('%s is %dx%d, expected %dx%d' % (path, a.shape[0], a.shape[1], H, W))
+    return a
+
+
+def _host_buffer(shape, dtype, pinned):
+    """uint8/float32 staging buffer; page-locked when a GPU runtime is there to lock it."""
+    import torch
+    t = torch.empty(shape, dtype=dtype)
+    if pinned and torch.cuda.is_available():
+        t = t.pin_memory()
+    return t
+
+
+class ChunkLoader(object):
+    """Iterates over (first_index, uint8 host tensor [n,H,W,3]) for consecutive chunks of a
+    sequence.  `source` is a list of image paths (decoded here) or a uint8 array
+    [T,H,W,3] already in memory (copied through the same staging buffers so that both kinds
+    of input take the same path).  `depth` staging buffers rotate: a chunk handed out stays
+    valid until `depth - 1` further chunks have been requested."""
+
+    def __init__(self, source, image_size, chunk, workers=8, depth=3, pinned=True, decode=decode_image):
+        import torch
+        self.image_size = tuple(image_size)
+        self.chunk = int(chunk)
+        if self.chunk <= 0:
+            raise ValueError('chunk must be positive')
+        self.source = source
+        self.T = len(source)
+        self.workers = max(1, int(workers))
+        self.decode = decode
+        H, W = self.image_size
+        if isinstance(source, np.ndarray):
+            if source.dtype != np.uint8 or source.shape[1:] != (H, W, 3):
+                raise ValueError('frames must be uint8 [T,%d,%d,3]' % (H, W))
+        self.depth = max(2, int(depth))
+        self.bufs = [_host_buffer((self.chunk, H, W, 3), torch.uint8, pinned) for _ in range(self.depth)]
+        self.free = queue.Queue()
+        for i in range(self.depth):
+            self.free.put(i)
+        self.ready = queue.Queue()
+        self.thread = None
+        self._held = []
+
+    def __len__(self):
+        return (self.T + self.chunk - 1) // self.chunk
+
+    def _fill(self, buf, lo, hi):
+        dst = buf.numpy()
+        if isinstance(self.source, np.ndarray):
+            dst[:hi - lo] = self.source[lo:hi]
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(i):
+            dst[i - lo] = self.decode(self.source[i], self.image_size)
+        if self.workers == 1:
+            for i in range(lo, hi):
+                one(i)
+        else:
+            with ThreadPoolExecutor(self.workers) as pool:
+                list(pool.map(one, range(lo, hi)))   # list(): re-raise decode errors here
+
+    def _produce(self):
+        try:
+            for lo in range(0, self.T, self.chunk):
+                hi = min(self.T, lo + self.chunk)
+                b = self.free.get()
+                if b is None:
+                    return
+                self._fill(self.bufs[b], lo, hi)
+                self.ready.put((lo, hi - lo, b, None))
+            self.ready.put((None, 0, None, None))
+        except BaseException as e:   # hand decode errors to the consumer thread
+            self.ready.put((None, 0, None, e))
+
+    def __iter__(self):
+        if self.thread is not None:
+            raise RuntimeError('a ChunkLoader can be iterated once')
+        self.thread = threading.Thread(target=self._produce, name='kfnet-chunk-loader', daemon=True)
+        self.thread.start()
+        try:
+            while True:
+                lo, n, b, err = self.ready.get()
+                if err is not None:
+                    raise err
+                if lo is None:
+                    return
+                # recycle the buffer handed out depth-1 chunks ago
+                self._held.append(b)
+                if len(self._held) >= self.depth:
+                    self.free.put(self._held.pop(0))
+                yield lo, self.bufs[b][:n]
+        finally:
+            self.free.put(None)   # unblock the producer if the consumer stopped early
+
+
+class StreamedSequence(object):
+    """Runs host-resident chunks through a `KFNetEngine` with uploads, compute and downloads
+    overlapped.  `run(chunks)` takes an iterable of (first_index, uint8 host tensor
+    [n,H,W,3]) -- e.g. a `ChunkLoader` -- and yields (first_index, float32 numpy records
+    [n,h,w,4]); a yielded array is a view of a rotating pinned buffer and is valid until the
+    generator is advanced again."""
+
+    def __init__(self, eng, chunk=None):
+        torch = eng.torch
+        self.eng = eng
+        self.chunk = int(chunk or eng.max_chunk)
+        if self.chunk > eng.max_chunk:
+            raise ValueError('chunk %d exceeds the engine\'s max_chunk %d' % (self.chunk, eng.max_chunk))
+        dev = eng.device
+        self.up = torch.cuda.Stream(device=dev)
+        self.down = torch.cuda.Stream(device=dev)
+        self.dev_frames = [torch.empty((self.chunk, eng.H, eng.W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.dev_rec = [torch.empty((self.chunk, eng.h, eng.w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.host_rec = [_host_buffer((self.chunk, eng.h, eng.w, 4), torch.float32, True) for _ in range(2)]
+        self.ev_up = [torch.cuda.Event() for _ in range(2)]
+        self.ev_done = [None, None]
+        self.ev_down = [None, None]
+
+    def run(self, chunks):
+        torch = self.eng.torch
+        eng = self.eng
+        main = torch.cuda.current_stream(eng.device)
+        pending = None   # (first_index, n, slot) whose download is in flight
+        for k, (lo, host) in enumerate(chunks):
+            n = int(host.shape[0])
+            if n > self.chunk:
+                raise ValueError('chunk of %d frames exceeds %d' % (n, self.chunk))
+            b = k & 1
+            with torch.cuda.stream(self.up):
+                if self.ev_done[b] is not None:
+                    self.up.wait_event(self.ev_done[b])      # compute of chunk k-2 has read dev_frames[b]
+                self.dev_frames[b][:n].copy_(host, non_blocking=True)
+                self.ev_up[b].record(self.up)
+            main.wait_event(self.ev_up[b])
+            if self.ev_down[b] is not None:
+                main.wait_event(self.ev_down[b])             # download of chunk k-2 has read dev_rec[b]
+            rec = eng.process(self.dev_frames[b][:n], t0=lo)
+            self.dev_rec[b][:n].copy_(rec)                   # the engine's record buffer is reused by chunk k+1
+            self.ev_done[b] = torch.cuda.Event()
+            self.ev_done[b].record(main)
+            with torch.cuda.stream(self.down):
+                self.down.wait_event(self.ev_done[b])
+                self.host_rec[b][:n].copy_(self.dev_rec[b][:n], non_blocking=True)
+                self.ev_down[b] = torch.cuda.Event()
+                self.ev_down[b].record(self.down)
+            if pending is not None:
+                plo, pn, pb = pending
+                self.ev_down[pb].synchronize()
+                yield plo, self.host_rec[pb][:pn].numpy()
+            pending = (lo, n, b)
+        if pending is not None:
+            plo, pn, pb = pending
+            self.ev_down[pb].synchronize()
+            yield plo, self.host_rec[pb][:pn].numpy()

@@ -24,3 +24,17 @@ def get_snapshot(folder):
         return int(nums[-1]) if nums else 0
     best = max(cands, key=step)
     return best, step(best)
+
+
+def confident_points(npy_file, thres=20.0):
+    """What the downstream consumers do with a `coord_<i>.npy` record
+    (vis/vis_scene_coordinate_map.py:10-26, and the PnP step of README.md:132-138): load the
+    float32 [h,w,4] map, split scene coordinates (channels 0-2) from the confidence
+    (channel 3 = 1/sigma) and keep the points whose confidence exceeds `thres`.
+    Returns (points [n,3], pixel indices [n,2] as (row, col))."""
+    import numpy as np
+    rec = np.load(npy_file)
+    if rec.ndim != 3 or rec.shape[2] != 4:
+        raise ValueError('%s: expected a [h,w,4] scene-coordinate map, got %s' % (npy_file, rec.shape))
+    keep = rec[:, :, 3] > thres
+    return rec[:, :, 0:3][keep], np.argwhere(keep)

@@ -56,3 +56,72 @@ def test_load_images_checks_size(tmp_path):
 
 def test_invalid_scene_is_rejected():
     assert kf_eval.main(['--scene', 'livingroom']) == 1      # KFNet/train.py:142-144
+
+
+# ---- kfnet_amd/pipeline.py: the decode/staging side of the image stream (no GPU needed) ----
+def _png_sequence(tmp_path, T, size=(6, 8)):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(T,) + size + (3,), dtype=np.uint8)
+    paths = []
+    for i in range(T):
+        p = str(tmp_path / ('f%03d.png' % i))
+        Image.fromarray(frames[i]).save(p)
+        paths.append(p)
+    return frames, paths
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+def test_chunk_loader_orders_and_ragged_tail(tmp_path, workers):
+    from kfnet_amd.pipeline import ChunkLoader
+    frames, paths = _png_sequence(tmp_path, 11)
+    for source in (paths, frames):
+        loader = ChunkLoader(source, (6, 8), chunk=4, workers=workers, pinned=False)
+        assert len(loader) == 3
+        got = [(lo, host.numpy().copy()) for lo, host in loader]
+        assert [lo for lo, _ in got] == [0, 4, 8]
+        assert [a.shape[0] for _, a in got] == [4, 4, 3]
+        assert np.array_equal(np.concatenate([a for _, a in got]), frames)
+
+
+def test_chunk_loader_buffer_lifetime(tmp_path):
+    """A chunk stays intact while depth-1 further chunks are requested (the upload of chunk k
+    may still be in flight when chunk k+1 is being filled)."""
+    from kfnet_amd.pipeline import ChunkLoader
+    frames, _ = _png_sequence(tmp_path, 12)
+    held = []
+    for lo, host in ChunkLoader(frames, (6, 8), chunk=2, depth=3, pinned=False):
+        held.append((lo, host))
+        for plo, ph in held[-2:]:
+            assert np.array_equal(ph.numpy(), frames[plo:plo + 2])
+
+
+def test_chunk_loader_propagates_decode_errors_and_early_exit(tmp_path):
+    from kfnet_amd.pipeline import ChunkLoader
+    frames, paths = _png_sequence(tmp_path, 6)
+    with pytest.raises(ValueError):
+        list(ChunkLoader(paths, (480, 640), chunk=4, pinned=False))      # wrong size, raised in the consumer
+    with pytest.raises(ValueError):
+        ChunkLoader(frames.astype(np.float32), (6, 8), chunk=4, pinned=False)
+    loader = ChunkLoader(paths, (6, 8), chunk=1, pinned=False)
+    for lo, host in loader:          # consumer walks away: the producer thread must not hang
+        break
+    loader.thread.join(timeout=10)
+    assert not loader.thread.is_alive()
+    assert list(ChunkLoader([], (6, 8), chunk=4, pinned=False)) == []     # empty sequence
+
+
+def test_confident_points_reads_records_like_the_vis_tools(tmp_path):
+    from kfnet_amd.tools.io import confident_points
+    rec = np.zeros((3, 4, 4), np.float32)
+    rec[..., :3] = np.arange(36, dtype=np.float32).reshape(3, 4, 3)
+    rec[..., 3] = 1.0
+    rec[1, 2, 3] = 25.0
+    rec[2, 0, 3] = 20.0            # not strictly above the threshold
+    p = str(tmp_path / 'coord_0.npy')
+    np.save(p, rec)
+    pts, idx = confident_points(p, 20.0)
+    assert pts.shape == (1, 3) and np.array_equal(pts[0], rec[1, 2, :3]) and idx.tolist() == [[1, 2]]
+    np.save(p, rec[..., :3])
+    with pytest.raises(ValueError):
+        confident_points(p)

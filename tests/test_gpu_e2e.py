@@ -282,3 +282,34 @@ def test_hipgraph_replay_of_heavy_phase_is_bit_identical():
     got = b.process(b.upload_frames(imgs)).cpu().numpy().copy()
     assert b._graph is not None
     assert np.array_equal(got, ref)
+
+
+def test_streamed_pipeline_is_bit_identical_to_resident(tmp_path):
+    """PNG list -> ChunkLoader (decode thread, pinned staging) -> StreamedSequence (upload /
+    compute / download on three streams, ragged last chunk) gives exactly the records of one
+    resident pass; eval() over image paths writes them as coord_<i>.npy."""
+    from PIL import Image
+    from kfnet_amd.KFNet import eval as kf_eval
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.pipeline import ChunkLoader, StreamedSequence
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(7)
+    imgs = synthetic_sequence(13, 64, 96, seed=4)
+    paths = []
+    for i in range(13):
+        paths.append(str(tmp_path / ('im%02d.png' % i)))
+        Image.fromarray(imgs[i]).save(paths[-1])
+    eng = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=5, max_chunk=13)
+    ref = eng.process(eng.upload_frames(imgs)).cpu().numpy().copy()
+    for source in (paths, imgs):
+        eng2 = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=5, max_chunk=4)
+        got = [(lo, rec.copy()) for lo, rec in StreamedSequence(eng2, 4).run(ChunkLoader(source, (64, 96), 4, workers=3))]
+        assert [lo for lo, _ in got] == [0, 4, 8, 12]
+        assert np.array_equal(np.concatenate([r for _, r in got]), ref)
+    out = tmp_path / 'out'
+    out.mkdir()
+    rec = kf_eval.eval(paths, None, W, str(out), image_size=(64, 96), batch=2, sequence_length=5, chunk=4,
+                       verbose=False)
+    assert np.array_equal(rec, ref)
+    assert np.array_equal(np.load(out / 'coord_12.npy'), ref[12])
