@@ -188,6 +188,9 @@ int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow
  *   eval.py:87-126: reset when (t0+t) % reset_period == 0 (state := measurement),
  *     optional NIS gate on the OUTPUT only, record = (T.x, 1/sigma) via ApplyTransform
  *     (KFNet/util.py:12-40).
+ * Grids above 10 240 pixels (state > 160 KB) run one launch per frame with the state
+ * ping-ponging between `state` and a stream-ordered scratch copy (hipMallocAsync); results
+ * are the same function of the inputs.
  */
 typedef struct kfn_kalman_desc {
   int32_t S, T, H, W;

@@ -42,6 +42,94 @@ struct PixIn {
   f32x4 z;
 };
 
+// One pixel of one frame: process model (warp + variance propagation), Kalman update, NIS,
+// output record.  `st` is the previous state of this sequence (LDS in the scan kernel,
+// global memory in the per-frame kernel); returns the new state of pixel p.
+__device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a, const f32x4* st, const PixIn& in, int p,
+                                            size_t off, bool reset, int W, float xmax, float ymax,
+                                            float eps2, bool want_nis) {
+  const f32x4 z = in.z;  // (zx, zy, zz, sigma_z)
+  f32x4 outv;                // record before transform: (x, y, z, sigma)
+  f32x4 nv;
+  if (reset) {
+    // eval.py:94-101: state := measurement, outputs := measurement
+    nv = z;
+    outv = z;
+    if (a.opt_temp) a.opt_temp[off + p] = z;
+    if (a.opt_nis) {
+      a.opt_nis[(off + p) * 3 + 0] = 0.f;
+      a.opt_nis[(off + p) * 3 + 1] = 0.f;
+      a.opt_nis[(off + p) * 3 + 2] = 0.f;
+    }
+  } else {
+    const int y = p / W, x = p - y * W;
+    // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
+    const float px = (float)x + in.flow.x;
+    const float py = (float)y + in.flow.y;
+    // bilinear_sampler (tools/util.py:36-93)
+    const float x0 = floorf(px), x1 = x0 + 1.0f;
+    const float y0 = floorf(py), y1 = y0 + 1.0f;
+    const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+    const float y0s = fminf(fmaxf(y0, 0.f), ymax), y1s = fminf(fmaxf(y1, 0.f), ymax);
+    const float wx0 = x1s - px, wx1 = px - x0s;
+    const float wy0 = y1s - py, wy1 = py - y0s;
+    const int ix0 = (int)x0s, ix1 = (int)x1s, iy0 = (int)y0s, iy1 = (int)y1s;
+    const f32x4 im00 = st[iy0 * W + ix0];
+    const f32x4 im01 = st[iy1 * W + ix0];
+    const f32x4 im10 = st[iy0 * W + ix1];
+    const f32x4 im11 = st[iy1 * W + ix1];
+    const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
+    const f32x4 g = ((w00 * im00 + w01 * im01) + w10 * im10) + w11 * im11;  // add_n order
+    // variance propagation (KFNet.py:393-401)
+    const float last_var = fmaxf(g.w * g.w, eps2);
+    const float trans_var = fmaxf(in.st * in.st, eps2);
+    const float temp_unc = sqrtf(trans_var + last_var);
+    // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
+    const float lv = temp_unc * temp_unc;
+    const float mv = z.w * z.w;
+    const float K = lv / (lv + mv);
+    const float om = fmaxf(1.0f - K, 0.0f);
+    nv.x = om * g.x + K * z.x;
+    nv.y = om * g.y + K * z.y;
+    nv.z = om * g.z + K * z.z;
+    nv.w = sqrtf(om * lv);
+    outv = nv;  // eval.py:103-104: the raw KF state (nv) is what is fed back
+    if (want_nis) {
+      // GetNIS (KFNet.py:164-184)
+      const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
+      const float iv = iu * iu;
+      const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
+      const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
+      if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
+        // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
+        outv.x = z.x; outv.y = z.y; outv.z = z.z;
+      }
+      if (a.opt_nis) {
+        a.opt_nis[(off + p) * 3 + 0] = n0;
+        a.opt_nis[(off + p) * 3 + 1] = n1;
+        a.opt_nis[(off + p) * 3 + 2] = n2;
+      }
+    }
+    if (a.opt_temp) {
+      f32x4 tv = {g.x, g.y, g.z, temp_unc};
+      a.opt_temp[off + p] = tv;
+    }
+  }
+  // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
+  f32x4 r;
+  if (a.d.has_transform) {
+    const float* M = a.d.transform;
+    r.x = ((M[0] * outv.x + M[1] * outv.y) + M[2] * outv.z) + M[3];
+    r.y = ((M[4] * outv.x + M[5] * outv.y) + M[6] * outv.z) + M[7];
+    r.z = ((M[8] * outv.x + M[9] * outv.y) + M[10] * outv.z) + M[11];
+  } else {
+    r.x = outv.x; r.y = outv.y; r.z = outv.z;
+  }
+  r.w = 1.0f / outv.w;
+  a.rec[off + p] = r;
+  return nv;
+}
+
 // DBL: the state is double-buffered in LDS (2 x 76.8 KB at 60x80): frame t gathers from
 // buffer t&1 and writes the fused state straight into the other one -- one barrier per
 // frame and no per-thread copy of the new state.  Grids whose two copies exceed the
@@ -93,86 +181,8 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
     for (int k = 0; k < PPT; ++k) {
       const int p = tid + k * KT;
       if (p < HW) {
-        const f32x4 z = cur[k].z;  // (zx, zy, zz, sigma_z)
-        f32x4 outv;                // record before transform: (x, y, z, sigma)
-        f32x4 nv;
-        if (reset) {
-          // eval.py:94-101: state := measurement, outputs := measurement
-          nv = z;
-          outv = z;
-          if (a.opt_temp) a.opt_temp[off + p] = z;
-          if (a.opt_nis) {
-            a.opt_nis[(off + p) * 3 + 0] = 0.f;
-            a.opt_nis[(off + p) * 3 + 1] = 0.f;
-            a.opt_nis[(off + p) * 3 + 2] = 0.f;
-          }
-        } else {
-          const int y = p / W, x = p - y * W;
-          // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
-          const float px = (float)x + cur[k].flow.x;
-          const float py = (float)y + cur[k].flow.y;
-          // bilinear_sampler (tools/util.py:36-93)
-          const float x0 = floorf(px), x1 = x0 + 1.0f;
-          const float y0 = floorf(py), y1 = y0 + 1.0f;
-          const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
-          const float y0s = fminf(fmaxf(y0, 0.f), ymax), y1s = fminf(fmaxf(y1, 0.f), ymax);
-          const float wx0 = x1s - px, wx1 = px - x0s;
-          const float wy0 = y1s - py, wy1 = py - y0s;
-          const int ix0 = (int)x0s, ix1 = (int)x1s, iy0 = (int)y0s, iy1 = (int)y1s;
-          const f32x4 im00 = st[iy0 * W + ix0];
-          const f32x4 im01 = st[iy1 * W + ix0];
-          const f32x4 im10 = st[iy0 * W + ix1];
-          const f32x4 im11 = st[iy1 * W + ix1];
-          const float w00 = wx0 * wy0, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx1 * wy1;
-          const f32x4 g = ((w00 * im00 + w01 * im01) + w10 * im10) + w11 * im11;  // add_n order
-          // variance propagation (KFNet.py:393-401)
-          const float last_var = fmaxf(g.w * g.w, eps2);
-          const float trans_var = fmaxf(cur[k].st * cur[k].st, eps2);
-          const float temp_unc = sqrtf(trans_var + last_var);
-          // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
-          const float lv = temp_unc * temp_unc;
-          const float mv = z.w * z.w;
-          const float K = lv / (lv + mv);
-          const float om = fmaxf(1.0f - K, 0.0f);
-          nv.x = om * g.x + K * z.x;
-          nv.y = om * g.y + K * z.y;
-          nv.z = om * g.z + K * z.z;
-          nv.w = sqrtf(om * lv);
-          outv = nv;  // eval.py:103-104: the raw KF state (nv) is what is fed back
-          if (want_nis) {
-            // GetNIS (KFNet.py:164-184)
-            const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
-            const float iv = iu * iu;
-            const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
-            const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
-            if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
-              // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
-              outv.x = z.x; outv.y = z.y; outv.z = z.z;
-            }
-            if (a.opt_nis) {
-              a.opt_nis[(off + p) * 3 + 0] = n0;
-              a.opt_nis[(off + p) * 3 + 1] = n1;
-              a.opt_nis[(off + p) * 3 + 2] = n2;
-            }
-          }
-          if (a.opt_temp) {
-            f32x4 tv = {g.x, g.y, g.z, temp_unc};
-            a.opt_temp[off + p] = tv;
-          }
-        }
+        const f32x4 nv = fuse_pixel(a, st, cur[k], p, off, reset, W, xmax, ymax, eps2, want_nis);
         if (DBL) st_new[p] = nv; else newst[DBL ? 0 : k] = nv;
-        // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
-        f32x4 r;
-        if (a.d.has_transform) {
-          const float* M = a.d.transform;
-          r.x = ((M[0] * outv.x + M[1] * outv.y) + M[2] * outv.z) + M[3];
-          r.y = ((M[4] * outv.x + M[5] * outv.y) + M[6] * outv.z) + M[7];
-          r.z = ((M[8] * outv.x + M[9] * outv.y) + M[10] * outv.z) + M[11];
-        } else {
-          r.x = outv.x; r.y = outv.y; r.z = outv.z;
-        }
-        r.w = 1.0f / outv.w;
-        a.rec[off + p] = r;
       }
       // keep the unrolled pixels sequential: interleaving them only multiplies live
       // temporaries (the 128-VGPR budget of a 1024-thread workgroup is tight)
@@ -194,6 +204,28 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   }
   const f32x4* st_fin = DBL ? st_base + (T & 1) * HW : st_base;
   for (int p = tid; p < HW; p += KT) a.state[(size_t)s * HW + p] = st_fin[p];
+}
+
+// Grids whose state does not fit the LDS (more than 10 240 pixels): one launch per frame over
+// all sequences, the state ping-pongs between two global buffers (`prev` is only read, `next`
+// only written, so the 4-tap gather needs no synchronisation inside a launch).
+__global__ __launch_bounds__(256) void kalman_step_kernel(KalmanArgs a, const f32x4* __restrict__ prev,
+                                                          f32x4* __restrict__ next, int t) {
+  const int H = a.d.H, W = a.d.W, HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (p >= HW) return;
+  const size_t off = ((size_t)s * a.d.T + t) * HW;
+  PixIn in;
+  in.flow = a.flow[off + p];
+  in.st = a.sigma_t[off + p];
+  in.z = a.meas[off + p];
+  const int gi = a.d.t0 + t;
+  const bool reset = a.d.reset_period > 0 && (gi % a.d.reset_period) == 0;
+  const float eps2 = a.d.min_uncertainty * a.d.min_uncertainty;
+  const bool want_nis = (a.opt_nis != nullptr) || (a.d.nis_gate > 0.f);
+  next[(size_t)s * HW + p] = fuse_pixel(a, prev + (size_t)s * HW, in, p, off, reset, W, (float)(W - 1),
+                                        (float)(H - 1), eps2, want_nis);
 }
 
 // KFNet.BuildKFCoord alone (KFNet/KFNet.py:148-162), optional GetNIS (:164-184):
@@ -249,7 +281,6 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
   KFN_REQUIRE(d->S > 0 && d->T > 0 && d->H > 1 && d->W > 1, "kfn_kalman_scan: bad shape S=%d T=%d H=%d W=%d",
               d->S, d->T, d->H, d->W);
   const int HW = d->H * d->W;
-  KFN_REQUIRE((size_t)HW * 16 <= 160 * 1024, "kfn_kalman_scan: %dx%d state does not fit the 160 KB LDS", d->H, d->W);
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(flow_xy) & 7) | (reinterpret_cast<uintptr_t>(meas) & 15) |
                (reinterpret_cast<uintptr_t>(state) & 15) | (reinterpret_cast<uintptr_t>(records) & 15) |
                (reinterpret_cast<uintptr_t>(opt_temp) & 15)) == 0,
@@ -264,6 +295,21 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
   a.opt_nis = opt_nis;
   a.d = *d;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((size_t)HW * 16 > 160 * 1024) {
+    // state larger than the LDS: per-frame launches, state ping-pong in global memory (the
+    // second copy is stream-ordered scratch, the only allocation this library ever makes)
+    const size_t bytes = (size_t)d->S * HW * sizeof(f32x4);
+    f32x4* scratch = nullptr;
+    KFN_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s));
+    f32x4* buf[2] = {a.state, scratch};
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)d->S);
+    for (int t = 0; t < d->T; ++t)
+      hipLaunchKernelGGL(kalman_step_kernel, grid, dim3(256), 0, s, a, buf[t & 1], buf[(t + 1) & 1], t);
+    if (d->T & 1) KFN_HIP(hipMemcpyAsync(a.state, scratch, bytes, hipMemcpyDeviceToDevice, s));
+    KFN_HIP(hipFreeAsync(scratch, s));
+    KFN_LAUNCH_CHECK("kalman_step_kernel");
+    return KFN_OK;
+  }
   // 768 threads (12 wavefronts, 170-VGPR budget) x 7 pixels cover the 60x80 grid without
   // register spills; larger grids fall back to 1024 threads and the single-buffer form.
   const bool dbl = (size_t)HW * 32 <= 160 * 1024;  // two LDS copies of the state fit

@@ -313,3 +313,19 @@ def test_streamed_pipeline_is_bit_identical_to_resident(tmp_path):
                        verbose=False)
     assert np.array_equal(rec, ref)
     assert np.array_equal(np.load(out / 'coord_12.npy'), ref[12])
+
+
+def test_large_grid_uses_global_memory_scan():
+    """808x968 frames give a 101x121 grid (12 221 px): the Kalman state no longer fits the
+    LDS, so the scan runs frame by frame with the state in global memory -- same results."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    imgs = synthetic_sequence(3, 808, 968, seed=6)
+    T4 = O.get_transform(synthetic_transform())
+    ref = OT.eval_sequence(imgs, W, T4, reset_period=500)
+    eng = KFNetEngine(W, image_size=(808, 968), batch=1, transform=T4, reset_period=500, max_chunk=3)
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    assert rec.shape == (3, 101, 121, 4)
+    _check(rec, ref)

@@ -215,7 +215,9 @@ def _scan_ref(flow, sig, meas, state0, T4, t0, reset_period, nis_gate):
 
 
 @pytest.mark.parametrize('cfg', [(1, 3, 60, 80, 0, 500, 0.0, True), (3, 5, 17, 23, 498, 500, 7.815, True),
-                                 (2, 4, 68, 120, 1, 0, 0.0, False)])
+                                 (2, 4, 68, 120, 1, 0, 0.0, False),
+                                 # state larger than the LDS (> 10 240 px): per-frame kernel, global ping-pong
+                                 (2, 5, 101, 121, 2, 4, 7.815, True), (1, 4, 135, 240, 0, 500, 0.0, False)])
 def test_kalman_scan_vs_oracle(cfg):
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib
