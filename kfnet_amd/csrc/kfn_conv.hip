@@ -566,42 +566,69 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   // ---- epilogue: bias, ReLU, fused head ops, store ------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
-  const int rowh = 4 * lh;
+  // The fused head epilogues exist only in the 32-column instantiations (the host forces one
+  // of them); everything per element is branch-free: ReLU is a max + select, the store is
+  // a buffer store (lane offset + wave-uniform row offset) whose range check drops the rows
+  // past M of the last tile and the columns past Cout.  The output descriptor is re-based per tile (the
+  // Winograd workspace [tile][16][Cout] exceeds 4 GiB).
+  constexpr bool HEAD_EPI = (MODE == MODE_CONV) && TN == 1 && WN == 1;
+  const bool relu = p.relu != 0;
+  const int rowmul = WINO ? 16 : 1;
+  const unsigned row_bytes = (unsigned)(rowmul * p.ldy) * 4u;   // byte distance of consecutive GEMM rows
+  const int rows_left = p.M - m0;
+  const unsigned long long y_off = ((unsigned long long)m0 * rowmul + (WINO ? grp : 0)) * (unsigned long long)p.ldy * 4ull;
+  const unsigned long long y_span = (unsigned long long)(rows_left < BM ? rows_left : BM) * row_bytes;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.y) + (TRANSPOSED ? 0ull : y_off), 0,
+      TRANSPOSED ? 0 : (int)(y_span - (WINO ? (unsigned long long)grp * p.ldy * 4ull : 0ull)), 0x00020000);
+  auto epilogue = [&](auto epi_c) {
+    constexpr int EPI = decltype(epi_c)::value;
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int n = n0 + (wn * TN + ni) * 32 + li;
-    const bool n_ok = n < p.Cout;
-    const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + (wn * TN + ni) * 32 + li;
+      const bool n_ok = n < p.Cout;
+      const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+      const unsigned lane_off = n_ok ? (unsigned)(wm * TM * 32 + 4 * lh) * row_bytes + (unsigned)n * 4u : OOB;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+      for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + rowh;
-        float v = (X3 ? acc[mi][ni][e] * p.out_scale : acc[mi][ni][e]) + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.epilogue == KFN_EPI_L2NORM) {
-          float ss = n_ok ? v * v : 0.f;
-          ss += __shfl_xor(ss, 16);
-          ss += __shfl_xor(ss, 8);
-          ss += __shfl_xor(ss, 4);
-          ss += __shfl_xor(ss, 2);
-          ss += __shfl_xor(ss, 1);
-          v = v / sqrtf(fmaxf(ss, 1e-12f));
-        } else if (p.epilogue == KFN_EPI_EXP_CH3) {
-          if (n == 3) v = expf(v);
-        } else if (p.epilogue == KFN_EPI_EXP_1E2) {
-          v = expf(v) * 1e-2f;
-        }
-        if (TRANSPOSED) {
-          const int op = out_pix[m - m0];
-          if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
-        } else {
-          // Winograd workspace is [tile][16][Cout]: the 16 GEMMs of a tile run together
-          // (group-fastest order) and complete 16*Cout contiguous floats
-          if (n_ok && m < p.M) p.y[(WINO ? (size_t)m * 16 + grp : (size_t)m) * p.ldy + n] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int rloc = mi * 32 + (e & 3) + 8 * (e >> 2);   // + wm*TM*32 + 4*lh = row within the tile
+          float v = (X3 ? acc[mi][ni][e] * p.out_scale : acc[mi][ni][e]) + bv;
+          v = relu ? fmaxf(v, 0.f) : v;
+          if constexpr (EPI == KFN_EPI_L2NORM) {
+            float ss = n_ok ? v * v : 0.f;
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 8);
+            ss += __shfl_xor(ss, 4);
+            ss += __shfl_xor(ss, 2);
+            ss += __shfl_xor(ss, 1);
+            v = v / sqrtf(fmaxf(ss, 1e-12f));
+          } else if constexpr (EPI == KFN_EPI_EXP_CH3) {
+            if (n == 3) v = expf(v);
+          } else if constexpr (EPI == KFN_EPI_EXP_1E2) {
+            v = expf(v) * 1e-2f;
+          }
+          if constexpr (TRANSPOSED) {
+            const int op = out_pix[wm * TM * 32 + rloc + 4 * lh];
+            if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY,
+                                                  lane_off + (unsigned)rloc * row_bytes, 0, 0);
+          }
         }
       }
     }
+  };
+  if constexpr (HEAD_EPI) {
+    switch (p.epilogue) {
+      case KFN_EPI_L2NORM: epilogue(std::integral_constant<int, KFN_EPI_L2NORM>{}); break;
+      case KFN_EPI_EXP_CH3: epilogue(std::integral_constant<int, KFN_EPI_EXP_CH3>{}); break;
+      case KFN_EPI_EXP_1E2: epilogue(std::integral_constant<int, KFN_EPI_EXP_1E2>{}); break;
+      default: epilogue(std::integral_constant<int, KFN_EPI_NONE>{}); break;
+    }
+  } else {
+    epilogue(std::integral_constant<int, KFN_EPI_NONE>{});
   }
 }
 
@@ -749,7 +776,8 @@ void out_shape(const kfn_conv_desc* d, int* Ho, int* Wo, int* pad_t, int* pad_l)
 int pick_config(const kfn_conv_desc* d, int M) {
   int cfg = d->config;
   if (cfg == KFN_CFG_AUTO) cfg = auto_config(M, d->Cout, num_cu());
-  if (d->epilogue == KFN_EPI_L2NORM && cfg != KFN_CFG_256x32) cfg = KFN_CFG_128x32;  // BN must be 32
+  // the fused head epilogues are only compiled into the 32-column tiles (L2NORM needs BN == 32)
+  if (d->epilogue != KFN_EPI_NONE && cfg != KFN_CFG_256x32) cfg = KFN_CFG_128x32;
   return cfg;
 }
 
