@@ -29,6 +29,29 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0x80000000u;  // voffset that always fails the buffer range check
 
+// Exact unsigned division by an invariant (Granlund-Montgomery, branch-free form):
+// 5 VALU instructions instead of the ~30 of the emulated 32-bit divide.  The row -> pixel
+// decode runs once per tile and thread, which is a visible share of a short-K tile.
+struct FastDiv {
+  unsigned d, mul, sh;
+};
+inline FastDiv make_fastdiv(int d) {
+  FastDiv f{(unsigned)d, 0u, 0u};
+  if (d > 1) {
+    int L = 0;
+    while ((1u << L) < (unsigned)d) ++L;   // ceil(log2 d), d < 2^31
+    f.mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << L) - (unsigned)d)) / (unsigned)d + 1ull);
+    f.sh = (unsigned)(L - 1);
+  }
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  const unsigned un = (unsigned)n;
+  const unsigned t = __umulhi(f.mul, un);
+  const unsigned q = (t + ((un - t) >> 1)) >> f.sh;
+  return (int)(f.d == 1u ? un : q);
+}
+
 struct ConvArgs {
   const float* x;
   const float* x2;  // MODE_CVOL: f2 (x is f1)
@@ -46,6 +69,7 @@ struct ConvArgs {
   int rot_mode;  // K-chunk rotation: 0 off, 1 per (m,n) tile, 2 per (m,n,group)
   unsigned w_lo_bytes;  // f16x3: byte offset of the lo weight matrix behind the hi one
   float out_scale;      // f16x3: 2^-k undoing the weight pre-scale
+  FastDiv fd_cls, fd_img, fd_row;  // row index -> (parity class,) image, row, column (set by launch_cfg)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // The A descriptor is re-based at the first image this tile touches, so 32-bit byte
   // offsets only have to span the few images of ONE tile (activations may exceed 2 GiB).
   const int HoWo = p.Ho * p.Wo;
-  const int n_first = TRANSPOSED ? 0 : (CVOL ? (m0 >> 6) / (p.H * p.W) : m0 / HoWo);
+  const int n_first = TRANSPOSED ? 0 : fdiv(CVOL ? (m0 >> 6) : m0, p.fd_img);
   const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
   const unsigned long long a_rest = p.x_bytes - a_base;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -185,7 +209,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   unsigned a_w4[WINO ? AP : 1][4];  // WINO: byte offsets of the 4 signed source pixels (or OOB)
   unsigned a_off2[CVOL ? AP : 1];   // CVOL: byte offset of f2[p]
   unsigned a_msk2[CVOL ? AP : 1];   // CVOL: taps whose shifted f1 pixel is inside the image
-  const int ntaps = WINO ? 1 : p.kh * p.kw;
   // B^T rows of F(2x2,3x3): V[xi] = sa*d[ra] + sb*d[rb]
   const int w_xi = grp >> 2, w_nu = grp & 3;
   const int w_ra = (w_xi == 0) ? 0 : 1, w_rb = (w_xi == 3) ? 3 : 2;
@@ -206,10 +229,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // row = (pixel pp, window cell (wi, wj)); conv0 slides over the 8x8 window grid
         const int pp = m >> 6, pos = m & 63;
         const int HW = p.H * p.W;
-        const int n_abs = pp / HW;
+        const int n_abs = fdiv(pp, p.fd_img);
         const int rem = pp - n_abs * HW;
         n_img = n_abs - n_first;
-        oy = rem / p.W;          // pixel coordinates of pp in the feature map
+        oy = fdiv(rem, p.fd_row);  // pixel coordinates of pp in the feature map
         ox = rem - oy * p.W;
         const int wi = pos >> 3, wj = pos & 7;
         unsigned m1 = 0, m2 = 0;
@@ -233,18 +256,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // (2i + (cls>>1), 2j + (cls&1)).  All rows of a tile (bar 3 seams) then share a
         // parity class and hence the same 1/2/2/4 live taps -- the rest are skipped.
         const int NHW = p.N * p.H * p.W;
-        const int cls = m / NHW;
+        const int cls = fdiv(m, p.fd_cls);
         const int idx = m - cls * NHW;
-        n_img = idx / (p.H * p.W);
+        n_img = fdiv(idx, p.fd_img);
         const int rem = idx - n_img * (p.H * p.W);
-        const int ii = rem / p.W;
+        const int ii = fdiv(rem, p.fd_row);
         oy = 2 * ii + (cls >> 1);
         ox = 2 * (rem - ii * p.W) + (cls & 1);
       } else {
-        const int n_abs = m / HoWo;
+        const int n_abs = fdiv(m, p.fd_img);
         const int rem = m - n_abs * HoWo;
         n_img = n_abs - n_first;
-        oy = rem / p.Wo;
+        oy = fdiv(rem, p.fd_row);
         ox = rem - oy * p.Wo;
       }
       unsigned msk = 0;
@@ -266,21 +289,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         a_y[i] = by;
         a_x[i] = bx;
         a_off[i] = (unsigned)(n_img * p.H * p.W);
-        for (int t = 0; t < ntaps; ++t) {
-          const int ky = t / p.kw, kx = t - ky * p.kw;
-          const int ty = by - ky, tx = bx - kx;
-          const bool ok = (ty >= 0) && (tx >= 0) && (((ty | tx) & 1) == 0) && ((ty >> 1) < p.H) &&
-                          ((tx >> 1) < p.W);
-          if (ok) msk |= 1u << t;
+        // tap (ky,kx) is live iff by-ky and bx-kx are even, >= 0 and inside the input
+        unsigned colmask = 0;
+        for (int kx = 0; kx < p.kw; ++kx) {
+          const int tx = bx - kx;
+          if (tx >= 0 && !(tx & 1) && (tx >> 1) < p.W) colmask |= 1u << kx;
+        }
+        for (int ky = 0; ky < p.kh; ++ky) {
+          const int ty = by - ky;
+          if (ty >= 0 && !(ty & 1) && (ty >> 1) < p.H) msk |= colmask << (ky * p.kw);
         }
       } else {
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
         a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * 4u;
-        for (int t = 0; t < ntaps; ++t) {
-          const int ky = t / p.kw, kx = t - ky * p.kw;
-          const int iy = iy0 + ky, ix = ix0 + kx;
-          if (((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W)) msk |= 1u << t;
-        }
+        // valid taps = [ky_lo, ky_hi) x [kx_lo, kx_hi)
+        const int ky_lo = iy0 < 0 ? -iy0 : 0, ky_hi = (p.H - iy0 < p.kh) ? p.H - iy0 : p.kh;
+        const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = (p.W - ix0 < p.kw) ? p.W - ix0 : p.kw;
+        const unsigned colmask = (kx_hi > kx_lo) ? (((1u << (kx_hi - kx_lo)) - 1u) << kx_lo) : 0u;
+        for (int ky = ky_lo; ky < ky_hi; ++ky) msk |= colmask << (ky * p.kw);
       }
       a_msk[i] = msk;
     }
@@ -295,18 +321,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   // ---- which taps touch at least one in-range input pixel of this tile? -----------
   // (zero-padding taps of whole tiles are skipped: exact, they only add +0.)
-  unsigned tapmask;
-  {
+  unsigned tapmask = 1u;   // Winograd GEMMs: one "tap"
+  if constexpr (!WINO) {
+    // OR over the wave by shuffles, over the waves through a small static LDS array (one barrier)
+    __shared__ unsigned red[NT / 64];
     unsigned mine = 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) mine |= a_msk[i];
-    unsigned* red = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) red[0] = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
+    if (lane == 0) red[wave] = mine;
     __syncthreads();
-    if (mine) atomicOr(red, mine);
-    __syncthreads();
-    tapmask = red[0];
-    __syncthreads();
+    tapmask = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tapmask |= red[w];
   }
 
   f32x16 acc[TM][TN];
@@ -552,11 +580,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       int op = -1;
       if (m < p.M) {
         const int NHW = p.N * p.H * p.W;
-        const int cls = m / NHW;
+        const int cls = fdiv(m, p.fd_cls);
         const int idx = m - cls * NHW;
-        const int n_img = idx / (p.H * p.W);
+        const int n_img = fdiv(idx, p.fd_img);
         const int rem = idx - n_img * (p.H * p.W);
-        const int ii = rem / p.W;
+        const int ii = fdiv(rem, p.fd_row);
         op = (n_img * p.Ho + 2 * ii + (cls >> 1)) * p.Wo + 2 * (rem - ii * p.W) + (cls & 1);
       }
       out_pix[r] = op;
@@ -656,6 +684,9 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
+  a.fd_cls = make_fastdiv(MODE == MODE_DECONV ? a.N * a.H * a.W : 1);
+  a.fd_img = make_fastdiv((MODE == MODE_DECONV || MODE == MODE_CVOL) ? a.H * a.W : a.Ho * a.Wo);
+  a.fd_row = make_fastdiv((MODE == MODE_DECONV || MODE == MODE_CVOL) ? a.W : a.Wo);
   auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, MODE, F16>;
   static bool attr_done = false;  // benign race: idempotent attribute
   if (!attr_done) {
