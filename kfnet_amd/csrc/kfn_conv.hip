@@ -665,11 +665,11 @@ struct TileCfg {
   double prior;   // measured MFMA utilisation of the instantiation on large problems (direct)
   double wprior;  // same for the Winograd GEMMs (k-step 16: 128x128 keeps 3 workgroups per CU)
 };
-const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x128, 128, 128, 0.87, 0.77},
+const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x128, 128, 128, 0.885, 0.77},
                          {KFN_CFG_192x64, 192, 64, 0.78, 0.66},   {KFN_CFG_128x64, 128, 64, 0.76, 0.66},
                          {KFN_CFG_256x32, 256, 32, 0.70, 0.45},   {KFN_CFG_128x32, 128, 32, 0.60, 0.45},
                          {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0},
-                         {KFN_CFG_128x256, 128, 256, 0.0, 0.0}};
+                         {KFN_CFG_128x256, 128, 256, 0.0, 0.82}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)

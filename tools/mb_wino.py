@@ -18,7 +18,8 @@ for (N, H, W, ci, co) in [(17, 60, 80, 1024, 1024), (17, 120, 160, 512, 512), (1
     y = torch.empty(N * H * W * co, device='cuda')
     Mt = N * (H // 2) * (W // 2)
     ws = torch.empty(16 * Mt * co, device='cuda')
-    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1)
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1,
+                      config=int(os.environ.get('KFN_WINO_CFG', '0')))
     t_gemm = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, st), 'w'))
     t_out = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 2, st), 'w'))
     t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 'wf'))
