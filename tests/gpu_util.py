@@ -42,7 +42,8 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     xb = np.full((n * h * wd, ldx), 7.0, dtype=np.float32)
     xb[:, x_off:x_off + cin] = x.reshape(-1, cin)
     xd = dev(xb)
-    yd = torch.full((n * ho * wo, ldy), -123.0, dtype=torch.float32, device='cuda')
+    GUARD = 96   # rows behind the tensor: the last (partial) tile must not write past row M
+    yd = torch.full((n * ho * wo + GUARD, ldy), -123.0, dtype=torch.float32, device='cuda')
     if x3:
         m = wp * np.float32(1024.0)
         hi = m.astype(np.float16)
@@ -59,6 +60,8 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     _lib.check(rc, 'kfn_conv2d_nhwc')
     sync()
     yh = yd.cpu().numpy()
+    assert np.all(yh[n * ho * wo:] == -123.0), 'conv wrote past the last output row'
+    yh = yh[:n * ho * wo]
     out = yh[:, y_off:y_off + cout].reshape(n, ho, wo, cout)
     # untouched columns must keep the sentinel
     mask = np.ones(ldy, dtype=bool)

@@ -342,7 +342,7 @@ WINO_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (
 
 
 @pytest.mark.parametrize('case', WINO_CASES)
-@pytest.mark.parametrize('config', [0, 1, 3, 6])
+@pytest.mark.parametrize('config', [0, 1, 3, 6, 9])
 def test_winograd_conv_vs_oracle(case, config):
     """kfn_conv2d_winograd == kfn_conv2d_nhwc == oracle up to fp32 round-off (incl. odd sizes,
     where the last 2x2 tile overhangs, strided output, bias + ReLU)."""
@@ -361,13 +361,17 @@ def test_winograd_conv_vs_oracle(case, config):
                       stride=1, relu=1, config=config)
     nb = C.c_size_t()
     _lib.check(lib.kfn_winograd_workspace_bytes(C.byref(d), C.byref(nb)), 'ws')
-    ws = torch.empty(nb.value // 4, device='cuda')
-    y = torch.full((n * h * w, ldy), -5.0, device='cuda')
+    GUARD = 4096   # floats behind the workspace / rows behind the output: partial tiles must not spill
+    ws = torch.full((nb.value // 4 + GUARD,), -7.0, device='cuda')
+    y = torch.full((n * h * w + 64, ldy), -5.0, device='cuda')
     dx, du, db = dev(x), dev(pack_winograd_kernel(wt)), dev(b)
     _lib.check(lib.kfn_conv2d_winograd(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
                                        ws.data_ptr(), 3, stream()), 'wino')
     sync()
+    assert bool((ws[nb.value // 4:] == -7.0).all()), 'Winograd GEMMs wrote past the workspace'
     got = y.cpu().numpy()
+    assert np.all(got[n * h * w:] == -5.0), 'output transform wrote past the last pixel'
+    got = got[:n * h * w]
     assert np.all(got[:, co:] == -5.0)
     ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
     err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
