@@ -109,6 +109,8 @@ typedef struct kfn_conv_desc {
 #define KFN_CFG_192x64 7   /* 4 waves, wave tile 96x32 (Cout == 64 layers) */
 #define KFN_CFG_160x256 8  /* 8 waves, wave tile 160x32 (never chosen automatically) */
 #define KFN_CFG_128x256 9  /* 4 waves, wave tile 64x128: the Winograd GEMMs' tile (fewest loads per MFMA) */
+#define KFN_CFG_256x16 10  /* 16-column tiles on v_mfma_f32_16x16x4_f32 for the 16-channel layers */
+#define KFN_CFG_128x16 11  /* (fp32 operands, no fused head epilogue)                               */
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);

@@ -128,10 +128,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // exact power of two back).  Dropped lo*lo term and fp16 rounding of lo: ~2^-21 relative
 // per product, i.e. fp32-class accuracy.
 constexpr int PREC_F32 = 0, PREC_F16 = 1, PREC_F16X3 = 2;
+// PREC_F32_N16: fp32 with 16-column sub-tiles on v_mfma_f32_16x16x4_f32 (same FLOP rate as
+// 32x32x2).  For the 16-channel layers of OFlowNet (conv6, upconv0) a 32-wide tile wastes
+// half of every MFMA; here a 32-row block is two 16-row MFMAs per 4 k, the two k-chunks of
+// a stage become the two row halves, and everything else (staging, schedule) is unchanged.
+constexpr int PREC_F32_N16 = 3;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  constexpr bool F16 = (PREC != PREC_F32);   // operands live in LDS as halfs
+  constexpr bool F16 = (PREC == PREC_F16 || PREC == PREC_F16X3);   // operands live in LDS as halfs
+  constexpr bool N16 = (PREC == PREC_F32_N16);
+  constexpr int CB = N16 ? 16 : 32;          // columns per MFMA sub-tile
+  static_assert(!N16 || BK == 16, "the 16-column variant maps the two k-chunks of a 16-deep stage to row halves");
   constexpr bool X3 = (PREC == PREC_F16X3);  // ... as separate hi and lo tiles
   constexpr int NPART = X3 ? 2 : 1;
   constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr int QCH = F16 ? 8 : 4;                           // channels per 16-byte LDS quad
   constexpr int KCH = F16 ? 2 * BK : BK;                     // channels per stage
   constexpr int BM = 32 * TM * WM;
-  constexpr int BN = 32 * TN * WN;
+  constexpr int BN = CB * TN * WN;
   constexpr int NT = 64 * WM * WN;
   constexpr int QPR = BK / 4;       // float4 quads per tile row
   constexpr int RPP = NT / QPR;     // tile rows covered per pass of the whole block
@@ -338,12 +346,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   }
 
   f32x16 acc[TM][TN];
+  f32x4 acc4[N16 ? TM : 1][N16 ? TN : 1][2];   // N16: two 16-row halves per 32-row block
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
+    for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      if constexpr (N16) {
+        acc4[mi][ni][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc4[mi][ni][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
 
   f32x4 ga[AP * NSRC], gb[BP * NPART];
 
@@ -464,12 +478,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int c = 0; c < NCH; ++c) rdq[c] = (((2 * c + lh) ^ swz<BK>(li)) * 4);
   const int a_rd = (wm * TM * 32 + li) * BK;
   const int b_rd = (wn * TN * 32 + li) * BK;
+  // N16: lane (i = lane & 15, kq = lane >> 4) reads quad kq of row i of a 16-row half
+  const int l16 = lane & 15, kq16 = lane >> 4;
 
   // double-buffered fragments: [A hi (TM) | B hi (TN)] and, for f16x3, [A lo | B lo] behind them
   f32x4 fr[2][(TM + TN) * NPART];
   auto read_one = [&](int k, int slot, int buf, int c) {
     const int part = k / (TM + TN), kk = k % (TM + TN);
-    if (kk < TM)
+    if constexpr (N16) {
+      // chunk c = row half c of every 32-row block; the B fragment is the same for both halves
+      const int row = (kk < TM) ? (wm * TM + kk) * 32 + 16 * c + l16 : (wn * TN + (kk - TM)) * 16 + l16;
+      const float* base = (kk < TM) ? As + buf * A_ELEMS : Bs + buf * B_ELEMS;
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(base + row * BK + ((kq16 ^ swz<BK>(row)) * 4));
+    } else if (kk < TM)
       fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + part * A_PART + a_rd + kk * 32 * BK + rdq[c]);
     else
       fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + part * B_PART + b_rd + (kk - TM) * 32 * BK + rdq[c]);
@@ -553,7 +574,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[slot][ia]),
                                                                  __builtin_bit_cast(f16x8, fr[slot][ib]),
                                                                  acc[mi][ni], 0, 0, 0);
-          } else
+          } else if constexpr (N16)
+            acc4[mi][ni][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc4[mi][ni][c], 0, 0, 0);
+          else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[slot][mi][t], fr[slot][TM + ni][t], acc[mi][ni], 0, 0, 0);
           // side ops k with floor(k*jspan/n_side) == j ride behind MFMA j
           constexpr int kb = n_side ? (j * n_side + jspan - 1) / jspan : 0;
@@ -599,7 +622,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // a buffer store (lane offset + wave-uniform row offset) whose range check drops the rows
   // past M of the last tile and the columns past Cout.  The output descriptor is re-based per tile (the
   // Winograd workspace [tile][16][Cout] exceeds 4 GiB).
-  constexpr bool HEAD_EPI = (MODE == MODE_CONV) && TN == 1 && WN == 1;
+  constexpr bool HEAD_EPI = (MODE == MODE_CONV) && TN == 1 && WN == 1 && !N16;
   const bool relu = p.relu != 0;
   const int rowmul = WINO ? 16 : 1;
   const unsigned row_bytes = (unsigned)(rowmul * p.ldy) * 4u;   // byte distance of consecutive GEMM rows
@@ -611,6 +634,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       TRANSPOSED ? 0 : (int)(y_span - (WINO ? (unsigned long long)grp * p.ldy * 4ull : 0ull)), 0x00020000);
   auto epilogue = [&](auto epi_c) {
     constexpr int EPI = decltype(epi_c)::value;
+    if constexpr (N16) {
+      // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + e
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + (wn * TN + ni) * 16 + l16;
+        const bool n_ok = n < p.Cout;
+        const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+        const unsigned lane_off = n_ok ? (unsigned)(wm * TM * 32 + 4 * kq16) * row_bytes + (unsigned)n * 4u : OOB;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int rloc = mi * 32 + 16 * c + e;
+              float v = acc4[mi][ni][c][e] + bv;
+              v = relu ? fmaxf(v, 0.f) : v;
+              if constexpr (TRANSPOSED) {
+                const int op = out_pix[wm * TM * 32 + rloc + 4 * kq16];
+                if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY,
+                                                      lane_off + (unsigned)rloc * row_bytes, 0, 0);
+              }
+            }
+      }
+      return;
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int n = n0 + (wn * TN + ni) * 32 + li;
@@ -669,7 +720,8 @@ const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x1
                          {KFN_CFG_192x64, 192, 64, 0.78, 0.66},   {KFN_CFG_128x64, 128, 64, 0.76, 0.66},
                          {KFN_CFG_256x32, 256, 32, 0.70, 0.45},   {KFN_CFG_128x32, 128, 32, 0.60, 0.45},
                          {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0},
-                         {KFN_CFG_128x256, 128, 256, 0.0, 0.82}};
+                         {KFN_CFG_128x256, 128, 256, 0.0, 0.82},
+                         {KFN_CFG_256x16, 256, 16, 0.50, 0.0},    {KFN_CFG_128x16, 128, 16, 0.45, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -679,7 +731,7 @@ const TileCfg* find_cfg(int cfg) {
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int F16 = PREC_F32>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = (F16 == PREC_F32_N16 ? 16 : 32) * TN * WN, NT = 64 * WM * WN;
   constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
@@ -712,15 +764,25 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, TR, F16>(a, s);
     case KFN_CFG_160x256: return launch_cfg<5, 1, 1, 8, BK, TR, F16>(a, s);
     case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, BK, TR, F16>(a, s);
+    case KFN_CFG_256x16:
+    case KFN_CFG_128x16:
+      // 16-column tiles: fp32 operands, k-step 16, direct and transposed convolutions
+      if constexpr (F16 == PREC_F32 && BK == 16 && (TR == MODE_CONV || TR == MODE_DECONV)) {
+        return cfg == KFN_CFG_256x16 ? launch_cfg<2, 1, 4, 1, 16, TR, PREC_F32_N16>(a, s)
+                                     : launch_cfg<1, 1, 4, 1, 16, TR, PREC_F32_N16>(a, s);
+      } else {
+        return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: the 16-column tiles need fp32 operands and k-step 16");
+      }
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: unknown config %d", cfg);
   }
 }
 
 // Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) over the CUs.
-int auto_config(int M, int Cout, int num_cu, bool wino = false) {
+int auto_config(int M, int Cout, int num_cu, bool wino = false, bool n16 = false) {
   double best = -1.0;
   int best_cfg = KFN_CFG_128x32;
   for (const TileCfg& c : kCfgs) {
+    if (c.bn == 16 && (!n16 || Cout > 16)) continue;   // 16-column tiles: fp32 direct/transposed convs with <= 16 channels
     const long groups = wino ? 16 : 1;  // the 16 Winograd GEMMs are one launch
     long tiles = (long)kfn::ceil_div(M, c.bm) * kfn::ceil_div(Cout, c.bn) * groups;
     long rounds = (tiles + num_cu - 1) / num_cu;
@@ -805,8 +867,11 @@ void out_shape(const kfn_conv_desc* d, int* Ho, int* Wo, int* pad_t, int* pad_l)
 }
 
 int pick_config(const kfn_conv_desc* d, int M) {
+  // the 16-column tiles exist for fp32 operands at k-step 16 without fused head epilogue
+  const bool n16_ok = d->operand_dtype == KFN_OPERAND_F32 && d->epilogue == KFN_EPI_NONE &&
+                      pick_bk(d->Cin, d->transposed ? MODE_DECONV : MODE_CONV) == 16;
   int cfg = d->config;
-  if (cfg == KFN_CFG_AUTO) cfg = auto_config(M, d->Cout, num_cu());
+  if (cfg == KFN_CFG_AUTO) cfg = auto_config(M, d->Cout, num_cu(), false, n16_ok);
   // the fused head epilogues are only compiled into the 32-column tiles (L2NORM needs BN == 32)
   if (d->epilogue != KFN_EPI_NONE && cfg != KFN_CFG_256x32) cfg = KFN_CFG_128x32;
   return cfg;

@@ -300,7 +300,8 @@ class ConvOp(Op):
         return 2.0 * n * ho * wo * cout * self.kh * self.kw * self.x.shape[3]
 
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
-                6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2)}
+                6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2),
+                10: (2, 1, 4, 1), 11: (1, 1, 4, 1)}   # 10/11: 16-column variants (PREC tag 3)
 
     def kernel_name(self, lib):
         """Template instantiation this op launches, spelled like rocprofv3 prints it."""
@@ -312,7 +313,8 @@ class ConvOp(Op):
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, 1>' % (t + (1 if self.transposed else 0,))
         if self.operand_dtype == _lib.OPERAND_F16X3:
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, 0, 2>' % t
-        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, 0>' % (t + (bk.value, 1 if self.transposed else 0))
+        return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d>' % (t + (bk.value, 1 if self.transposed else 0,
+                                                                      3 if cfg.value in (10, 11) else 0))
 
     def launch(self, lib, stream):
         d = self.desc()

@@ -35,7 +35,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('config', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_conv_vs_oracle(case, config):
     from tests.gpu_util import run_conv
     n, h, w, ci, co, k, s, relu = case
@@ -62,14 +62,15 @@ def test_conv_strided_views():
 
 @pytest.mark.parametrize('shape', [(3, 1, 1, 128, 64), (2, 2, 2, 64, 32), (2, 4, 4, 32, 16), (1, 5, 7, 16, 40),
                                    (300, 2, 2, 64, 32), (70, 4, 4, 32, 16)])
-def test_deconv_vs_oracle(shape):
+@pytest.mark.parametrize('config', [0, 4, 10, 11])
+def test_deconv_vs_oracle(shape, config):
     from tests.gpu_util import run_conv
     n, h, w, ci, co = shape
     rng = np.random.default_rng(11)
     x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
     wt = (rng.normal(size=(3, 3, co, ci)) / np.sqrt(9 * ci)).astype(np.float32)
     b = rng.normal(size=co).astype(np.float32)
-    y = run_conv(x, wt, b, 2, True, transposed=True)
+    y = run_conv(x, wt, b, 2, True, transposed=True, config=config)
     ref = O.conv2d_transpose_same(x.astype(np.float64), wt, b, 2, True)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() <= _conv_tol(x, wt, True)
