@@ -478,8 +478,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int c = 0; c < NCH; ++c) rdq[c] = (((2 * c + lh) ^ swz<BK>(li)) * 4);
   const int a_rd = (wm * TM * 32 + li) * BK;
   const int b_rd = (wn * TN * 32 + li) * BK;
-  // N16: lane (i = lane & 15, kq = lane >> 4) reads quad kq of row i of a 16-row half
-  const int l16 = lane & 15, kq16 = lane >> 4;
+  // N16: lane (i = lane & 15, kq = lane >> 4) reads one quad of row i of a 16-row half.
+  // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... ;
+  // with the staging swizzle (r>>2)&3 the k-quad order 0,3,1,2 over kq makes every group
+  // touch 16 distinct 16-byte slots (A and B use the same order, so the sum is unchanged).
+  const int l16 = lane & 15, kq16 = (0x9C >> (2 * (lane >> 4))) & 3;
 
   // double-buffered fragments: [A hi (TM) | B hi (TN)] and, for f16x3, [A lo | B lo] behind them
   f32x4 fr[2][(TM + TN) * NPART];
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         const int n = n0 + (wn * TN + ni) * 16 + l16;
         const bool n_ok = n < p.Cout;
         const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
-        const unsigned lane_off = n_ok ? (unsigned)(wm * TM * 32 + 4 * kq16) * row_bytes + (unsigned)n * 4u : OOB;
+        const unsigned lane_off = n_ok ? (unsigned)(wm * TM * 32 + 4 * (lane >> 4)) * row_bytes + (unsigned)n * 4u : OOB;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
               float v = acc4[mi][ni][c][e] + bv;
               v = relu ? fmaxf(v, 0.f) : v;
               if constexpr (TRANSPOSED) {
-                const int op = out_pix[wm * TM * 32 + rloc + 4 * kq16];
+                const int op = out_pix[wm * TM * 32 + rloc + 4 * (lane >> 4)];
                 if (n_ok && op >= 0) p.y[(size_t)op * p.ldy + n] = v;
               } else {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY,
