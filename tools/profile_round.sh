@@ -12,6 +12,10 @@ python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
 SHORT="--steps 68 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err )
 python tools/rocpd_stats.py "$(finddb $OUT/kt)" $OUT/${TAG}_kernel_stats.csv > /dev/null
+# same trace with the two towers serialised on one stream: kernel durations without the
+# overlap of the two-stream schedule, directly comparable with bench.py's isolated launches
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt1 -- python $R/bench.py --one-stream --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof_one_stream.json 2> $OUT/kt1.err )
+python tools/rocpd_stats.py "$(finddb $OUT/kt1)" $OUT/${TAG}_kernel_stats_one_stream.csv > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -- python $R/bench.py $SHORT > /dev/null 2> $OUT/$C.err )
 done
@@ -23,5 +27,5 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 done
 python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)"
 # the second un-profiled bench line picks up the fresh traffic numbers if they were copied in place
-rm -rf $OUT/kt $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
+rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
 ls -la $OUT
