@@ -174,18 +174,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int nwg = p.tiles_m * p.tiles_n * (WINO ? 16 : 1);
   int tile = xcd_remap(blockIdx.x, nwg);
   int grp = 0;
+  int tn, tm;
   if (WINO) {
-    if ((p.rot_mode & 3) == 3) {  // experiment: group slowest
-      const int per = p.tiles_m * p.tiles_n;
-      grp = tile / per;
-      tile -= grp * per;
-    } else {  // group fastest: the 16 GEMMs of one (m,n) tile run together and share the
-      grp = tile & 15;  // same source pixels through the XCD's L2
-      tile >>= 4;
-    }
+    // Order inside an XCD's run: blocks of 8 M-tiles; within a block the (group, n-tile)
+    // combination is the slow index and the M-tile the fast one.  The ~64 workgroups resident
+    // on an XCD are then 8 M-tiles x 8 combinations: 8 workgroups share each U slice and 8
+    // share each M-tile's source pixels through the L2 (measured: all-combinations-of-one-
+    // M-tile-together 19.7-19.8 ms of GEMM phase per batch, blocks of 4 / 8 / 16: 19.53 /
+    // 19.48 / 19.96; one group at a time over all M-tiles: 3-15 % slower).
+    constexpr int MBk = 8;
+    const int NC = 16 * p.tiles_n;
+    const int blk = tile / (MBk * NC);
+    const int first = blk * MBk;
+    const int size = (p.tiles_m - first < MBk) ? p.tiles_m - first : MBk;
+    const int r = tile - blk * MBk * NC;
+    const int combo = r / size;
+    tm = first + (r - combo * size);
+    grp = combo & 15;
+    tn = combo >> 4;
+  } else {
+    tn = tile % p.tiles_n;
+    tm = tile / p.tiles_n;
   }
-  const int tn = tile % p.tiles_n;
-  const int tm = tile / p.tiles_n;
   const int m0 = tm * BM;
   const int n0 = tn * BN;
 
