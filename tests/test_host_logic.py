@@ -124,3 +124,32 @@ def test_dataspec_matches_reference_table():
     s = KFNetDataSpec()
     assert s.scene == 'stairs' and s.sequence_length == 500 and s.image_num == 2000
     assert KFNetDataSpec(scene='heads').sequence_length == 1000
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++, and a C program
+    must link against libkfnet_hip.so and reach the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, 'include', 'kfnet_hip.h')
+    lib = os.path.join(root, 'kfnet_amd', 'libkfnet_hip.so')
+    if shutil.which('gcc') is None or not os.path.exists(lib):
+        pytest.skip('needs gcc and the built library')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-x', 'c', hdr])
+    subprocess.check_call(['g++', '-std=c++17', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c++', hdr])
+    src = tmp_path / 'host.c'
+    src.write_text('#include "kfnet_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  kfn_conv_desc d = {0};\n'
+                   '  int ho = 0, wo = 0;\n'
+                   '  d.N = 1; d.H = 480; d.W = 640; d.Cin = 64; d.ldx = 64; d.Cout = 256; d.cout_pad = 256; d.ldy = 256;\n'
+                   '  d.kh = 3; d.kw = 3; d.stride = 2;\n'
+                   '  if (kfn_conv2d_out_shape(&d, &ho, &wo) != KFN_OK) return 1;\n'
+                   '  printf("%d %d %d\\n", kfn_abi_version(), ho, wo);\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / 'host'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe),
+                           '-L', os.path.dirname(lib), '-lkfnet_hip', '-Wl,-rpath,' + os.path.dirname(lib)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out == ['2', '240', '320']          # ABI version, TF-SAME output size of conv2a
