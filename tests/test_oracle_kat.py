@@ -120,3 +120,53 @@ def test_conv_vs_torch_random():
         yt = OT.conv_same(OT._t(x).permute(0, 3, 1, 2), w, b, s, True).permute(0, 2, 3, 1).numpy()
         assert y.shape == yt.shape
         assert np.allclose(y, yt, atol=1e-4)
+
+
+def _tiny_sequence(T=4):
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(3)
+    imgs = synthetic_sequence(T, 32, 48, seed=5)
+    return W, imgs, O.get_transform(synthetic_transform())
+
+
+def test_reset_step_emits_the_measurement():  # App. E.12, KFNet/eval.py:94-101
+    """At i % reset_period == 0 the record is concat(T.z, 1/sigma_z) whatever happened before,
+    and the recursion restarts from the measurement: frames after a reset equal the frames of
+    a sequence that STARTS there."""
+    W, imgs, T4 = _tiny_sequence(4)
+    rec, dbg = O.eval_sequence(imgs, W, T4, reset_period=2, dtype=np.float32, return_debug=True)
+    for i in (0, 2):
+        z, sz = dbg[i]['z'], dbg[i]['sz']
+        want = np.concatenate([O.apply_transform(z, T4)[0], 1.0 / sz[0]], -1).astype(np.float32)
+        assert np.array_equal(rec[i], want)
+    # the reset frame's record does not depend on history; the next frame only on the pair
+    # (its flow features come from frame 2, which the restarted sequence sees as frame 0)
+    rec_restart = O.eval_sequence(imgs[2:], W, T4, reset_period=2, dtype=np.float32)
+    assert np.array_equal(rec[2], rec_restart[0])
+    assert np.array_equal(rec[3], rec_restart[1])
+
+
+def test_nis_gate_touches_the_output_only():  # App. E.13, KFNet/eval.py:87-92,103-104
+    from kfnet_amd.synth import synthetic_sequence
+    W, imgs, T4 = _tiny_sequence(3)
+    # confident measurements (sigma_z = exp(-4 + ...)) of a scene that jumps at frame 2, so
+    # that the innovation test fails for many pixels
+    W = dict(W)
+    b = W['ScoreNet/prediction/bias'].copy()
+    b[3] = -4.0
+    W['ScoreNet/prediction/bias'] = b
+    imgs = np.concatenate([imgs[:2], synthetic_sequence(1, 32, 48, seed=99)])
+    plain, d0 = O.eval_sequence(imgs, W, T4, reset_period=500, nis_gate=False, dtype=np.float32, return_debug=True)
+    gated, d1 = O.eval_sequence(imgs, W, T4, reset_period=500, nis_gate=True, dtype=np.float32, return_debug=True)
+    changed = 0
+    for i in (1, 2):
+        # the state that is fed forward is the raw KF estimate in both runs
+        assert np.array_equal(d0[i]['kf_x'], d1[i]['kf_x']) and np.array_equal(d0[i]['kf_s'], d1[i]['kf_s'])
+        over = d1[i]['nis'].sum(-1)[0] > 7.815
+        tz = O.apply_transform(d1[i]['z'], T4)[0].astype(np.float32)
+        assert np.array_equal(gated[i][..., :3][over], tz[over])          # gated pixels show T.z
+        assert np.array_equal(gated[i][..., :3][~over], plain[i][..., :3][~over])
+        assert np.array_equal(gated[i][..., 3], plain[i][..., 3])         # confidence stays the KF one
+        changed += int(over.sum())
+    assert changed > 0, 'the synthetic sequence should trip the gate somewhere'
