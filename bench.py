@@ -92,14 +92,15 @@ def per_kernel_profile(eng, dev_frames):
         ms = timed(lambda: op.launch(eng.lib, stream))
         tag = op.kernel_name(eng.lib) if hasattr(op, 'kernel_name') else op.name.split('[')[0] + '_kernel'
         fl = op.flops() if hasattr(op, 'flops') else 0.0
-        rows.append((op.name, tag, fl, ms, fl))
+        rows.append((op.name, tag, fl, ms, op.mfma_flops() if hasattr(op, 'mfma_flops') else fl))
     return rows
 
 
 def pipeline_io_bytes(eng):
     """Algorithmic HBM bytes of one batch if every launch reads its input tensor(s) and weights
     once and writes its output once (layer-by-layer execution, fp32 activations)."""
-    from kfnet_amd.graph import (ConvOp, CostVolumeConvOp, FirstConvOp, FlowHeadOp, WinogradConvOp)
+    from kfnet_amd.graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, FirstConvOp, FlowHeadOp, PadOp,
+                                 WinogradConvOp)
     def tb(t):
         n, h, w, c = t.shape
         return n * h * w * c * (4 if t.dtype == 'f32' else 1)
@@ -109,6 +110,10 @@ def pipeline_io_bytes(eng):
             total += tb(op.img) + sum(tb(hd[1]) for hd in op.heads)
         elif isinstance(op, CostVolumeConvOp):
             total += 2 * tb(op.f2) + tb(op.y)
+        elif isinstance(op, CostVolumeGatherOp):
+            total += tb(op.t) + tb(op.gp) + tb(op.y)
+        elif isinstance(op, PadOp):
+            total += tb(op.x) + tb(op.y)
         elif isinstance(op, ConvOp):
             total += tb(op.x) + tb(op.y) + int(np.prod(op.kernel.shape)) * 4
             if isinstance(op, WinogradConvOp):

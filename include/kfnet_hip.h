@@ -164,6 +164,18 @@ int kfn_cost_volume_conv(const float* f1, const float* f2, const float* w_packed
                          float* y, int N, int H, int W, int C, int Cout, int cout_pad, int ldy,
                          int relu, int config, void* stream);
 
+/* ---- factored cost volume + conv0 ---------------------------------------------------------
+ * conv0 (cnn_wrapper/OFlowNet.py:19) is linear and V[p,cell] = f2[p] - f1[p+cell-4]
+ * (KFNet/KFNet.py:343-359), hence conv0(V)[p,ci,cj] = b + S_k f2[p] - G_k(p+(ci-4,cj-4)) with
+ * k = 3*rowclass(ci) + colclass(cj) (which taps stay inside the 8x8 window), S_k the sum of
+ * those taps and G_k the 3x3 SAME conv of the zero-extended f1 with them.  T = b + S f2
+ * [N,H,W,9*C] and Gp = G on the map extended by 2 [N,H+4,W+4,9*C] come from kfn_conv2d_nhwc
+ * (kfn_pad_nhwc pads f1 by 2); this launch gathers, subtracts and applies the ReLU into the
+ * [(N*H*W),8,8,C] tensor conv0 used to produce (pixel stride ldy). */
+int kfn_pad_nhwc(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+int kfn_cost_volume_gather(const float* T, const float* Gp, float* y, int N, int H, int W, int C,
+                           int ldy, int relu, void* stream);
+
 /* ---- softmax over the window cells + soft-argmax flow ---------------------------------
  * OFlowNet.GetOutput softmax (OFlowNet.py:45-47) + KFNet.BuildOFlowNet flow
  * (KFNet/KFNet.py:381-385): flow[p] = sum_k softmax(logits[p])_k * (j-w/2, i-w/2).

@@ -17,8 +17,8 @@ from .. import _lib
 from ..cnn_wrapper.network import Network
 from ..cnn_wrapper.OFlowNet import OFlowNet
 from ..cnn_wrapper.SCoordNet import SCoordNet
-from ..graph import (ConvOp, CostVolumeConvOp, CostVolumeOp, Graph, KalmanScanOp, MemcpyOp, Tensor,
-                     variable_scope)
+from ..graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, CostVolumeOp, DerivedConvOp, Graph, KalmanScanOp, MemcpyOp,
+                     PadOp, Tensor, pack_cvol_bias, pack_cvol_g_kernel, pack_cvol_t_kernel, variable_scope)
 
 
 class KFNetDataSpec():
@@ -258,10 +258,37 @@ class KFNet():
         conv0 = c0[0]
         if conv0.operand_dtype != _lib.OPERAND_F32:
             return   # the loader-generated volume exists for the fp32 kernel only
+        net_ops = self.oflownet.ops
+        if g.factor_cost_volume and conv0.bias is not None:
+            # conv0 is linear and V[p,cell] = f2[p] - f1[p+cell-4]: two per-pixel convolutions
+            # with the 9 border-class kernels + one gather replace the per-cell 3x3 conv
+            n, h, w, c = feat_map2.shape
+            co = conv0.y.shape[3]
+            f1p = g.tensor((n, h + 4, w + 4, c), name='feat_map1_padded')
+            gp = g.tensor((n, h + 4, w + 4, 9 * co), name='conv0_G')
+            tt = g.tensor((n, h, w, 9 * co), name='conv0_T')
+            wg = g.derived_variable(conv0.kernel, 'cvol_G', pack_cvol_g_kernel)
+            wt = g.derived_variable(conv0.kernel, 'cvol_T', pack_cvol_t_kernel)
+            b9 = g.derived_variable(conv0.bias, 'cvol_b9', pack_cvol_bias)
+            new_ops = [PadOp(feat_map1, f1p, 2),
+                       DerivedConvOp('conv0[G]', f1p, gp, wg, None, 3, 3, 1, False),
+                       DerivedConvOp('conv0[T]', feat_map2, tt, wt, b9, 1, 1, 1, False),
+                       CostVolumeGatherOp(tt, gp, conv0.y, conv0.relu, c)]
+            i = g.ops.index(conv0)
+            g.ops[i:i + 1] = new_ops
+            g.ops.remove(cv[0])
+            j = net_ops.index(conv0)
+            net_ops[j:j + 1] = new_ops
+            # the TF-layout copies conv0 itself would have used are not needed
+            for prm in (conv0.kernel, conv0.bias):
+                if not any(getattr(op, 'kernel', None) is prm or getattr(op, 'bias', None) is prm for op in g.ops):
+                    g.params.pop(prm.name, None)
+            if vol.storage in g.storages:
+                g.storages.remove(vol.storage)
+            return
         fused = CostVolumeConvOp(feat_map1, feat_map2, conv0.y, conv0.kernel, conv0.bias, conv0.relu, window_size)
         g.ops[g.ops.index(conv0)] = fused
         g.ops.remove(cv[0])
-        net_ops = self.oflownet.ops
         net_ops[net_ops.index(conv0)] = fused
         if vol.storage in g.storages:
             g.storages.remove(vol.storage)

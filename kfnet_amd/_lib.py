@@ -61,6 +61,8 @@ SYMBOLS = {
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'kfn_cost_volume_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'kfn_pad_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'kfn_cost_volume_gather': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'kfn_flow_head': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

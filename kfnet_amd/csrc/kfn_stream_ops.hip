@@ -110,6 +110,66 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------
+// Factored cost volume + conv0 (KFNet/KFNet.py:343-359,372 + cnn_wrapper/OFlowNet.py:19).
+// conv0 is linear and every volume entry is f2[p] - f1[p + cell - 4], so for window cell
+// (ci,cj) of pixel p
+//     conv0(V)[p,ci,cj] = b + S_k f2[p] - G_k(p + (ci-4, cj-4)),   k = class(ci,cj),
+// where S_k = sum of the 3x3 taps that stay inside the 8x8 window for that cell (conv0's own
+// SAME padding: 3 row classes x 3 column classes) and G_k = 3x3 SAME convolution of the
+// zero-extended f1 with the same taps.  T_k = b + S_k f2 (a 1x1 conv) and G_k (a 3x3 conv on
+// the feature MAP, 9*C channels) are computed once per pixel instead of once per cell; this
+// kernel gathers, subtracts and applies the ReLU: 64x less MFMA work than the per-cell conv.
+//   T  [N,H,W,9*C]           class-major channels
+//   Gp [N,H+4,W+4,9*C]       G on the map extended by 2 (conv of f1 zero-padded by 2)
+//   y  [(N*H*W),8,8,C]       pixel stride ldy floats
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        int N, int H, int W, int C, int pad) {
+  const int C4 = C >> 2, Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const long total = (long)N * Hp * Wp * C4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    long t = idx / C4;
+    const int b = (int)(t % Wp); t /= Wp;
+    const int a = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int sy = a - pad, sx = b - pad;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + sy) * W + sx) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(y + idx * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void cost_volume_gather_kernel(const float* __restrict__ T,
+                                                                  const float* __restrict__ Gp,
+                                                                  float* __restrict__ y, int N, int H, int W,
+                                                                  int C, int ldy, int relu) {
+  const int C4 = C >> 2, Hp = H + 4, Wp = W + 4, C9 = 9 * C;
+  const long total = (long)N * H * W * 64 * C4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    long t = idx / C4;
+    const int cell = (int)(t & 63);
+    const long p = t >> 6;                 // pixel index over N*H*W
+    const int ci = cell >> 3, cj = cell & 7;
+    const int x = (int)(p % W);
+    const long t2 = p / W;
+    const int yy = (int)(t2 % H);
+    const int n = (int)(t2 / H);
+    const int cls = ((ci == 0) ? 0 : (ci == 7 ? 2 : 1)) * 3 + ((cj == 0) ? 0 : (cj == 7 ? 2 : 1));
+    f32x4 v = *reinterpret_cast<const f32x4*>(T + p * C9 + cls * C + c4 * 4);
+    const int a = yy + ci - 2, b = x + cj - 2;   // position in the map extended by 2
+    if ((unsigned)a < (unsigned)Hp && (unsigned)b < (unsigned)Wp)
+      v -= *reinterpret_cast<const f32x4*>(Gp + (((long)n * Hp + a) * Wp + b) * C9 + cls * C + c4 * 4);
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + t * ldy + c4 * 4) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // softmax over the window cells (OFlowNet.py:45-47) + soft-argmax flow
 // (KFNet/KFNet.py:381-385).  One 64-lane wavefront per pixel == one lane per cell of the
 // 8x8 window; max / sum / weighted sums by wave shuffles.
@@ -269,6 +329,33 @@ extern "C" int kfn_cost_volume(const float* f1, const float* f2, float* vol, int
   hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      f1, f2, vol, N, H, W, C, window);
   KFN_LAUNCH_CHECK("cost_volume_kernel");
+  return KFN_OK;
+}
+
+extern "C" int kfn_pad_nhwc(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream) {
+  KFN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && pad >= 0, "kfn_pad_nhwc: bad argument");
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "kfn_pad_nhwc: misaligned buffer");
+  long total = (long)N * (H + 2 * pad) * (W + 2 * pad) * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256L * 32) blocks = 256L * 32;
+  hipLaunchKernelGGL(pad_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, pad);
+  KFN_LAUNCH_CHECK("pad_nhwc_kernel");
+  return KFN_OK;
+}
+
+extern "C" int kfn_cost_volume_gather(const float* T, const float* Gp, float* y, int N, int H, int W, int C,
+                                      int ldy, int relu, void* stream) {
+  KFN_REQUIRE(T && Gp && y, "kfn_cost_volume_gather: null argument");
+  KFN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldy >= C && ldy % 4 == 0,
+              "kfn_cost_volume_gather: bad shape N=%d H=%d W=%d C=%d ldy=%d", N, H, W, C, ldy);
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(Gp) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+              "kfn_cost_volume_gather: misaligned buffer");
+  long total = (long)N * H * W * 64 * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256L * 64) blocks = 256L * 64;
+  hipLaunchKernelGGL(cost_volume_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, Gp,
+                     y, N, H, W, C, ldy, relu);
+  KFN_LAUNCH_CHECK("cost_volume_gather_kernel");
   return KFN_OK;
 }
 

@@ -172,8 +172,9 @@ class Param(object):
     """A weight variable: TF name + logical shape; `pack` turns the TF-layout ndarray
     into the device layout the kernels read."""
 
-    def __init__(self, graph, name, shape, pack):
+    def __init__(self, graph, name, shape, pack, source=None):
         self.name = name
+        self.source = source or name   # TF variable it is filled from (derived layouts share one)
         self.shape = tuple(shape)
         self.pack = pack
         self.storage = None
@@ -438,6 +439,65 @@ class CostVolumeConvOp(Op):
         _lib.check(rc, 'kfn_cost_volume_conv')
 
 
+class DerivedConvOp(ConvOp):
+    """A convolution that exists only because of an algebraic rewrite (e.g. the class
+    convolutions of the factored cost volume): it executes MFMA work but carries none of the
+    reference's nominal FLOPs -- those stay with the op that finishes the rewritten layer."""
+
+    def flops(self):
+        return 0.0
+
+    def mfma_flops(self):
+        return ConvOp.flops(self)
+
+
+class PadOp(Op):
+    """Zero-pad an NHWC map by `pad` pixels on every side (kfn_pad_nhwc)."""
+
+    def __init__(self, x, y, pad):
+        self.name = 'pad[%s]' % (x.name or '?')
+        self.x, self.y, self.pad = x, y, pad
+
+    def kernel_name(self, lib):
+        return 'pad_nhwc_kernel'
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.x.shape
+        n = _scaled(n, self.x.graph)
+        assert self.x.ld == c and self.y.ld == c
+        _lib.check(lib.kfn_pad_nhwc(self.x.ptr, self.y.ptr, n, h, w, c, self.pad, stream), 'kfn_pad_nhwc')
+
+
+class CostVolumeGatherOp(Op):
+    """Last step of the factored cost volume + conv0 (kfn_cost_volume_gather):
+    y[p,ci,cj] = act(T_k[p] - G_k[p + (ci-4, cj-4)])."""
+
+    def __init__(self, t, gp, y, relu, cin):
+        self.cin = cin   # channels of the feature maps (conv0's Cin)
+        self.name = 'conv0[cost_volume gather]'
+        self.t, self.gp, self.y, self.relu = t, gp, y, relu
+
+    def kernel_name(self, lib):
+        return 'cost_volume_gather_kernel'
+
+    def flops(self):
+        """The nominal FLOPs of the layer this op completes: conv0 on every window cell."""
+        n, h, w, c9 = self.t.shape
+        co = self.y.shape[3]
+        return 2.0 * n * h * w * 64 * 9 * self.cin * co
+
+    def mfma_flops(self):
+        return 0.0
+
+    def launch(self, lib, stream):
+        n, h, w, c9 = self.t.shape
+        n = _scaled(n, self.t.graph)
+        c = self.y.shape[3]
+        assert c9 == 9 * c and self.t.ld == c9 and self.gp.ld == c9
+        _lib.check(lib.kfn_cost_volume_gather(self.t.ptr, self.gp.ptr, self.y.ptr, n, h, w, c, self.y.ld,
+                                              int(self.relu), stream), 'kfn_cost_volume_gather')
+
+
 class FlowOp(Op):
     def __init__(self, logits, flow, prob, window):
         self.name = 'flow_softargmax'
@@ -448,6 +508,45 @@ class FlowOp(Op):
         rc = lib.kfn_flow_softargmax(self.logits.ptr, self.flow.ptr,
                                      self.prob.ptr if self.prob is not None else None, P, self.window, stream)
         _lib.check(rc, 'kfn_flow_softargmax')
+
+
+def _cvol_tap_valid(r, k):
+    """Does tap k (0..2) of a 3-tap axis stay inside the 8-cell window for a cell of border
+    class r (0 = first cell, 1 = interior, 2 = last cell)?  (conv0's own SAME padding)"""
+    return not ((r == 0 and k == 0) or (r == 2 and k == 2))
+
+
+def cvol_class_kernels(w):
+    """conv0's TF kernel [3,3,C,Co] -> (W9 [3,3,C,9*Co], S9 [1,1,C,9*Co]) for the factored cost
+    volume (include/kfnet_hip.h, kfn_cost_volume_gather): class k = 3*rowclass + colclass keeps
+    the taps that stay inside the window; S9 is their sum (the f2 term), W9 the masked kernel
+    (the f1 term).  Sums in fp64, like the Winograd weight transform."""
+    w = np.asarray(w, dtype=np.float64)
+    kh, kw, c, co = w.shape
+    assert kh == 3 and kw == 3
+    w9 = np.zeros((3, 3, c, 9 * co))
+    s9 = np.zeros((1, 1, c, 9 * co))
+    for ry in range(3):
+        for rx in range(3):
+            k = ry * 3 + rx
+            for ky in range(3):
+                for kx in range(3):
+                    if _cvol_tap_valid(ry, ky) and _cvol_tap_valid(rx, kx):
+                        w9[ky, kx, :, k * co:(k + 1) * co] = w[ky, kx]
+                        s9[0, 0, :, k * co:(k + 1) * co] += w[ky, kx]
+    return w9.astype(np.float32), s9.astype(np.float32)
+
+
+def pack_cvol_g_kernel(w):
+    return pack_conv_kernel(cvol_class_kernels(w)[0])
+
+
+def pack_cvol_t_kernel(w):
+    return pack_conv_kernel(cvol_class_kernels(w)[1])
+
+
+def pack_cvol_bias(b):
+    return np.tile(np.asarray(b, dtype=np.float32), 9)
 
 
 def pack_flow_head_kernel(w):
@@ -562,6 +661,9 @@ class Graph(object):
         self.winograd_min_channels = 128
         self.winograd_ws = None
         self.winograd_fused = False  # single-kernel Winograd (all 16 groups per workgroup, no workspace)
+        # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
+        # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
+        self.factor_cost_volume = True
         # 'f32': exact fp32 MFMA everywhere (the parity path).  'f16': convolutions with
         # Cin % 32 == 0 round their operands to fp16 while staging (fp32 accumulate, fp32
         # activations in memory) -- BASELINE config 5 "fp16 convs + fp32 Kalman", own tolerance.
@@ -598,6 +700,13 @@ class Graph(object):
             return self.params[full]
         return Param(self, full, shape, pack)
 
+    def derived_variable(self, source_param, tag, pack):
+        """A second device layout of an existing variable (same TF name in the container)."""
+        key = source_param.source + '#' + tag
+        if key in self.params:
+            return self.params[key]
+        return Param(self, key, source_param.shape, pack, source=source_param.source)
+
     # -- execution ----------------------------------------------------------------------
     def finalize(self, device='cuda:0'):
         import torch
@@ -615,7 +724,8 @@ class Graph(object):
         import torch
         if self.device is None:
             raise _lib.KfnError('call Graph.finalize(device) before load_weights')
-        for name, p in self.params.items():
+        for key, p in self.params.items():
+            name = p.source
             if name not in W:
                 if strict:
                     raise KeyError('weight %s missing from the container' % name)

@@ -492,3 +492,46 @@ def test_winograd_fused_vs_oracle(case):
     ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
     err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
     assert err <= 3 * _conv_tol(x, wt), err
+
+
+@pytest.mark.parametrize('shape', [(2, 7, 9, 32, 32), (1, 60, 80, 32, 32), (3, 5, 4, 16, 48), (2, 3, 2, 32, 32)])
+def test_cost_volume_factored_vs_oracle(shape):
+    """pad(f1) -> 3x3 conv with the 9 class kernels, 1x1 conv of f2 with the class sums,
+    kfn_cost_volume_gather == conv0(BuildCoordVolume(f1, f2)) of the oracle (same borders:
+    window-border SAME padding of conv0 and zero fill of the shifted f1 outside the image)."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_cvol_bias, pack_cvol_g_kernel, pack_cvol_t_kernel
+    lib = _lib.load()
+    N, H, W, Cc, co = shape
+    rng = np.random.default_rng(78)
+    f = rng.normal(size=(N + 1, H, W, Cc)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, Cc, co)) / np.sqrt(9 * Cc)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    c9 = 9 * co
+    fd = dev(f)
+    wg, wtt, b9 = dev(pack_cvol_g_kernel(wt)), dev(pack_cvol_t_kernel(wt)), dev(pack_cvol_bias(b))
+    f1p = torch.empty(N * (H + 4) * (W + 4) * Cc, device='cuda')
+    Gp = torch.empty(N * (H + 4) * (W + 4) * c9, device='cuda')
+    T = torch.empty(N * H * W * c9, device='cuda')
+    ldy, off = co + 16, 16
+    y = torch.full((N * H * W * 64, ldy), -9.0, device='cuda')
+    st = stream()
+    _lib.check(lib.kfn_pad_nhwc(fd.data_ptr(), f1p.data_ptr(), N, H, W, Cc, 2, st), 'pad')
+    cp = -(-c9 // 32) * 32
+    dg = _lib.ConvDesc(N=N, H=H + 4, W=W + 4, Cin=Cc, ldx=Cc, Cout=c9, cout_pad=cp, ldy=c9, kh=3, kw=3, stride=1)
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(dg), f1p.data_ptr(), wg.data_ptr(), None, Gp.data_ptr(), st), 'G')
+    dt = _lib.ConvDesc(N=N, H=H, W=W, Cin=Cc, ldx=Cc, Cout=c9, cout_pad=cp, ldy=c9, kh=1, kw=1, stride=1)
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(dt), fd.data_ptr() + H * W * Cc * 4, wtt.data_ptr(), b9.data_ptr(),
+                                   T.data_ptr(), st), 'T')
+    _lib.check(lib.kfn_cost_volume_gather(T.data_ptr(), Gp.data_ptr(), y.data_ptr() + off * 4, N, H, W, co, ldy, 1, st),
+               'gather')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, :off] == -9.0)
+    for n in range(N):
+        vol, _ = O.coord_volume(f[n:n + 1].astype(np.float64), f[n + 1:n + 2].astype(np.float64), 8)
+        ref = O.conv2d_same(vol, wt, b, 1, True).reshape(H * W * 64, co)
+        g = got[n * H * W * 64:(n + 1) * H * W * 64, off:off + co]
+        assert np.abs(g - ref).max() < 2e-5
