@@ -145,27 +145,32 @@ __global__ __launch_bounds__(256) void cost_volume_gather_kernel(const float* __
                                                                   const float* __restrict__ Gp,
                                                                   float* __restrict__ y, int N, int H, int W,
                                                                   int C, int ldy, int relu) {
+  // one workgroup per pixel (grid-stride): the pixel decode is wave-uniform (scalar unit), a
+  // thread handles (cell, channel quad) items; consecutive lanes = consecutive quads of a cell
   const int C4 = C >> 2, Hp = H + 4, Wp = W + 4, C9 = 9 * C;
-  const long total = (long)N * H * W * 64 * C4;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    long t = idx / C4;
-    const int cell = (int)(t & 63);
-    const long p = t >> 6;                 // pixel index over N*H*W
-    const int ci = cell >> 3, cj = cell & 7;
-    const int x = (int)(p % W);
-    const long t2 = p / W;
-    const int yy = (int)(t2 % H);
-    const int n = (int)(t2 / H);
-    const int cls = ((ci == 0) ? 0 : (ci == 7 ? 2 : 1)) * 3 + ((cj == 0) ? 0 : (cj == 7 ? 2 : 1));
-    f32x4 v = *reinterpret_cast<const f32x4*>(T + p * C9 + cls * C + c4 * 4);
-    const int a = yy + ci - 2, b = x + cj - 2;   // position in the map extended by 2
-    if ((unsigned)a < (unsigned)Hp && (unsigned)b < (unsigned)Wp)
-      v -= *reinterpret_cast<const f32x4*>(Gp + (((long)n * Hp + a) * Wp + b) * C9 + cls * C + c4 * 4);
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  const int items = 64 * C4;
+  const int P = N * H * W;
+  for (int p = blockIdx.x; p < P; p += gridDim.x) {
+    const int x = p % W;
+    const int t2 = p / W;
+    const int yy = t2 % H;
+    const int n = t2 / H;
+    const float* Tp = T + (size_t)p * C9;
+    const float* Gn = Gp + (size_t)n * Hp * Wp * C9;
+    float* yp = y + (size_t)p * 64 * ldy;
+    for (int item = threadIdx.x; item < items; item += 256) {
+      const int cell = item / C4, c4 = item - cell * C4;
+      const int ci = cell >> 3, cj = cell & 7;
+      const int cls = ((ci == 0) ? 0 : (ci == 7 ? 2 : 1)) * 3 + ((cj == 0) ? 0 : (cj == 7 ? 2 : 1));
+      f32x4 v = *reinterpret_cast<const f32x4*>(Tp + cls * C + c4 * 4);
+      const int a = yy + ci - 2, b = x + cj - 2;   // position in the map extended by 2
+      if ((unsigned)a < (unsigned)Hp && (unsigned)b < (unsigned)Wp)
+        v -= *reinterpret_cast<const f32x4*>(Gn + ((size_t)a * Wp + b) * C9 + cls * C + c4 * 4);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<f32x4*>(yp + cell * ldy + c4 * 4) = v;
     }
-    *reinterpret_cast<f32x4*>(y + t * ldy + c4 * 4) = v;
   }
 }
 
@@ -350,9 +355,9 @@ extern "C" int kfn_cost_volume_gather(const float* T, const float* Gp, float* y,
               "kfn_cost_volume_gather: bad shape N=%d H=%d W=%d C=%d ldy=%d", N, H, W, C, ldy);
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(Gp) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
               "kfn_cost_volume_gather: misaligned buffer");
-  long total = (long)N * H * W * 64 * (C / 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 256L * 64) blocks = 256L * 64;
+  KFN_REQUIRE((long)N * H * W < (1L << 31), "kfn_cost_volume_gather: too many pixels");
+  long blocks = (long)N * H * W;
+  if (blocks > 256L * 256) blocks = 256L * 256;
   hipLaunchKernelGGL(cost_volume_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, Gp,
                      y, N, H, W, C, ldy, relu);
   KFN_LAUNCH_CHECK("cost_volume_gather_kernel");
