@@ -170,3 +170,34 @@ def test_nis_gate_touches_the_output_only():  # App. E.13, KFNet/eval.py:87-92,1
         assert np.array_equal(gated[i][..., 3], plain[i][..., 3])         # confidence stays the KF one
         changed += int(over.sum())
     assert changed > 0, 'the synthetic sequence should trip the gate somewhere'
+
+
+def test_cost_volume_factorisation_identity():
+    """The algebra behind kfn_cost_volume_gather, checked on the CPU with the oracle's own
+    convolution: conv0(BuildCoordVolume(f1,f2))[p,ci,cj] == b + S_k f2[p] - G_k(p+(ci-4,cj-4))
+    with the class kernels of kfnet_amd.graph.cvol_class_kernels (KFNet/KFNet.py:343-359,
+    cnn_wrapper/OFlowNet.py:19), including image borders and window borders."""
+    from kfnet_amd.graph import cvol_class_kernels
+    rng = np.random.default_rng(5)
+    H, W, Cc, co = 5, 7, 8, 6
+    f1 = rng.normal(size=(1, H, W, Cc))
+    f2 = rng.normal(size=(1, H, W, Cc))
+    wt = rng.normal(size=(3, 3, Cc, co)) / 8
+    b = rng.normal(size=co)
+    vol, _ = O.coord_volume(f1, f2, 8)                               # [H*W, 8, 8, Cc]
+    ref = O.conv2d_same(vol, wt, b, 1, False).reshape(H, W, 8, 8, co)
+    w9, s9 = cvol_class_kernels(wt)
+    f1p = np.pad(f1, ((0, 0), (2, 2), (2, 2), (0, 0)))
+    Gp = O.conv2d_same(f1p, w9.astype(np.float64), None, 1, False)[0]      # [H+4, W+4, 9*co]
+    T = O.conv2d_same(f2, s9.astype(np.float64), np.tile(b, 9), 1, False)[0]  # [H, W, 9*co]
+    cls = lambda c: 0 if c == 0 else (2 if c == 7 else 1)
+    got = np.zeros_like(ref)
+    for y in range(H):
+        for x in range(W):
+            for ci in range(8):
+                for cj in range(8):
+                    k = cls(ci) * 3 + cls(cj)
+                    a, bb = y + ci - 2, x + cj - 2
+                    g = Gp[a, bb, k * co:(k + 1) * co] if 0 <= a < H + 4 and 0 <= bb < W + 4 else 0.0
+                    got[y, x, ci, cj] = T[y, x, k * co:(k + 1) * co] - g
+    assert np.abs(got - ref).max() < 1e-5     # the class kernels are stored in fp32
