@@ -12,9 +12,18 @@ sharded into contiguous K-frame chunks (weak scaling).  Every rank runs the
 state-independent heavy phase for its chunk at once; the recurrent Kalman state (76.8 KB)
 is handed rank r -> r+1 with RCCL send/recv just before the rank's scan launch.
 
+Timing: W untimed warm-up steps, then the K-step pass is REPEATED until at least
+--min-seconds (2 s) have been timed; every repetition is exactly K steps bracketed by a
+barrier + torch.cuda.synchronize() on both sides, timed per rank, MAX over ranks; the line
+reports the MEDIAN repetition (`ms_per_step`, `value`), the repetition count and the spread.
+
 One JSON line on rank 0; extra objects: roofline (dominant kernel = the fp32 MFMA
 implicit-GEMM conv), roofline_kalman (batched persistent scan, HBM), cpu_baseline
 (reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
+
+`--config c2` / `--config c5` print the line of BASELINE configs[1] (SCoordNet-only single
+480x640 frame, latency) / configs[4] (960x540, batch of sequences, fp16 convs + fp32 Kalman)
+instead; the default (`c3`, configs[2]) is the headline the driver records.
 """
 import argparse
 import json
@@ -30,6 +39,7 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s achievable)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA (measured 2495)
 
 
 def parse():
@@ -38,8 +48,15 @@ def parse():
     ap.add_argument('--steps', type=int, default=256,
                     help='frames per GPU in the timed region (BASELINE config 3: a 256-frame sequence)')
     ap.add_argument('--warmup', type=int, default=17)
-    ap.add_argument('--batch', type=int, default=17,
-                    help='frames per tower launch (17*240 tiles = 4080 ~ 8 x 512 resident workgroups)')
+    ap.add_argument('--config', choices=['c3', 'c2', 'c5'], default='c3',
+                    help='BASELINE.json config: c3 = full KFNet 480x640 sequence (headline), c2 = SCoordNet-only '
+                         'single-frame latency, c5 = 960x540 batch-of-sequences, fp16 convs + fp32 Kalman')
+    ap.add_argument('--batch', type=int, default=0,
+                    help='frames per tower launch; 0 = auto: the size in 15..32 that splits --steps with the least '
+                         'ragged tail (the rate is flat over that range; 17 when --steps is a multiple of 17)')
+    ap.add_argument('--min-seconds', type=float, default=2.0,
+                    help='repeat the K-step pass until this much time has been measured (median reported)')
+    ap.add_argument('--sequences', type=int, default=4, help='c5: independent sequences per scan launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-streamed', action='store_true',
                     help='skip the PCIe-inclusive run (frames from pinned host memory)')
@@ -49,7 +66,8 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the heavy phase of full batches from a captured hipGraph')
     ap.add_argument('--autotune', action='store_true',
                     help='time every tile config per layer at start-up (the heuristic is within ~2%% of it)')
-    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-steps', type=int, default=16,
+                    help='frames of the CPU baseline (BASELINE config 1 is a 16-frame 480x640 sequence)')
     ap.add_argument('--no-kalman-roofline', action='store_true')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
                     help="f16 = BASELINE config 5's fp16-operand convs (fp32 accumulate, fp32 Kalman); NOT the headline")
@@ -160,13 +178,26 @@ def kalman_roofline(device, S=256, T=64, H=60, W=80):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     bytes_alg = float(S) * T * hw * 76.0
+    bytes_hbm = float(S) * T * hw * 44.0 + 2.0 * S * hw * 16.0   # + state load / store-back once per launch
     gbs = bytes_alg / (ms * 1e-3) / 1e9
+    gbs_hbm = bytes_hbm / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get('kalman_scan_kernel@S=%d,T=%d' % (S, T))
+        if t:
+            traffic = t
     return {'kernel': 'kalman_scan_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
-            'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+            'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic,
             'shape': 'S=%d sequences x T=%d frames x %dx%d px; algorithmic 76 B/px (44 read incl. 16 state + 32 '
                      'written incl. 16 state)' % (S, T, H, W),
-            'hbm_actual_GBs': round(float(S) * T * hw * 44.0 / (ms * 1e-3) / 1e9, 1),
-            'hbm_actual_note': 'state stays in LDS: real HBM traffic is 28 B/px in + 16 B/px out',
+            'algorithmic_bytes_per_launch': int(bytes_alg),
+            'hbm_actual_bytes_per_launch': int(bytes_hbm),
+            'hbm_actual_GBs': round(gbs_hbm, 1),
+            'frac_on_actual_hbm_bytes': round(gbs_hbm / PEAK_HBM_GBS, 4),
+            'hbm_actual_note': 'the state stays in LDS for the whole scan, so the bytes that really cross HBM are '
+                               '28 B/px in + 16 B/px out (+ the state once per launch); `frac` uses SURVEY 8(d)\'s '
+                               '76 B/px definition, `frac_on_actual_hbm_bytes` what the memory system moves',
             'avg_launch_ms': round(ms, 4)}
 
 
@@ -257,6 +288,173 @@ def cpu_baseline(frames, W, T4, steps):
             'deduplicated_sample': '%d frames, towers once per frame, %.1f s' % (nd, dt_d)}, np.stack(recs)
 
 
+def auto_batch(K, lo=15, hi=32, prefer=17):
+    """Tower batch for a K-frame pass: the size in [lo, hi] with the least ragged tail (the
+    measured rate is flat over that range), ties to the size closest to `prefer`."""
+    if K <= hi:
+        return max(1, K)
+    best = None
+    for b in range(lo, hi + 1):
+        launched = -(-K // b) * b
+        key = (launched - K, abs(b - prefer))
+        if best is None or key < best[0]:
+            best = (key, b)
+    return best[1]
+
+
+def timed_repetitions(run_once, dist, device, backend, min_seconds, max_reps=400):
+    """Repeat `run_once` (exactly K steps) until >= min_seconds are timed.  Every repetition is
+    bracketed by barrier + synchronize on both sides and timed on every rank; returns the
+    per-repetition MAX-over-ranks times (seconds)."""
+    import torch
+    times = []
+    total = 0.0
+    while True:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_once()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())      # identical on every rank -> identical stop decision
+        times.append(dt)
+        total += dt
+        if total >= min_seconds or len(times) >= max_reps:
+            return times
+
+
+def bench_c2(args, device):
+    """BASELINE configs[1]: SCoordNet alone on ONE 480x640 frame (batch 1, no recurrence) --
+    a latency number: ms per frame, eager launches and hipGraph replay."""
+    import torch
+    from kfnet_amd import _lib
+    from kfnet_amd.cnn_wrapper.SCoordNet import SCoordNet
+    from kfnet_amd.graph import Graph, variable_scope
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    g = Graph()
+    g.conv_operands = args.conv_operands
+    img = g.placeholder((1, args.height, args.width, 3), 'u8', name='images')
+    with variable_scope('ScoreNet'):
+        net = SCoordNet({'input': img}, is_training=False, focal_x=525., focal_y=525., u=320., v=240.)
+    coord, unc = net.GetOutput()
+    g.finalize(str(device))
+    g.load_weights(synthetic_weights(1234))
+    frame = synthetic_sequence(1, args.height, args.width, seed=0)
+    img.upload(frame)
+    stream = torch.cuda.current_stream(device)
+    for _ in range(max(args.warmup, 3)):
+        g.run(stream.cuda_stream)
+    torch.cuda.synchronize()
+
+    def time_loop(fn, min_s):
+        lat = []
+        t_all = time.perf_counter()
+        while time.perf_counter() - t_all < min_s or len(lat) < args.steps:
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        return np.array(lat)
+    eager = time_loop(lambda: g.run(stream.cuda_stream), args.min_seconds)
+    cap = torch.cuda.Stream(device=device)
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(cg, stream=cap):
+            g.run(torch.cuda.current_stream(device).cuda_stream)
+    graph = time_loop(cg.replay, args.min_seconds)
+    # device-side time of one frame (events; excludes host launch gaps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        cg.replay()
+    e1.record()
+    e1.synchronize()
+    dev_ms = e0.elapsed_time(e1) / 20
+    flops = g.total_flops()
+    med = float(np.median(graph))
+    out = {'metric': 'frames/sec on 480x640 seq', 'value': round(1.0 / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
+           'steps': int(len(graph)), 'warmup': max(args.warmup, 3), 'ms_per_step': round(med * 1e3, 4),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_operands,
+           'data': 'synthetic (one seeded uint8 frame, seeded random weights)',
+           'config': {'workload': 'BASELINE configs[1]: SCoordNet-only single %dx%d frame, batch 1, no recurrence '
+                                  '(latency)' % (args.height, args.width)},
+           'latency_ms': {'hipgraph_replay_median': round(med * 1e3, 4),
+                          'hipgraph_replay_p90': round(float(np.percentile(graph, 90)) * 1e3, 4),
+                          'eager_launches_median': round(float(np.median(eager)) * 1e3, 4),
+                          'device_time_per_frame': round(dev_ms, 4)},
+           'roofline': {'kernel': 'SCoordNet, all launches of one frame', 'bound': 'mfma',
+                        'achieved': round(flops / (dev_ms * 1e-3) / 1e12, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        'traffic': None,
+                        'note': 'algorithmic (nominal dense) FLOPs of the 12 layers = %.3f GFLOP / device time; '
+                                'the Winograd layers execute 16/36 of theirs, so this can exceed 1' % (flops / 1e9)}}
+    print(json.dumps(out))
+
+
+def bench_c5(args, device):
+    """BASELINE configs[4]: 960x540 input (68x120 grid), S independent sequences of T frames,
+    fp16 conv operands (fp32 accumulate) + fp32 Kalman scan advancing all sequences in one
+    launch.  A step = one 540x960 frame."""
+    import torch
+    from kfnet_amd.KFNet.eval import get_transform  # noqa: F401  (package's own; no oracle import here)
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    H, W = 540, 960
+    S, T = args.sequences, min(args.steps, 64)
+    B = args.batch or auto_batch(T, 8, 16, 16)
+    Wt = synthetic_weights(1234)
+    T4 = np.linalg.inv(synthetic_transform())
+    eng = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * T,
+                      device=str(device), conv_operands='f16')
+    seqs = np.stack([synthetic_sequence(T, H, W, seed=3 + s) for s in range(S)])
+    dev = torch.from_numpy(seqs).to(device)
+    eng.process_sequences(dev)
+    torch.cuda.synchronize()
+    times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, args.min_seconds)
+    med = float(np.median(times))
+    rec16 = eng.process_sequences(dev)[:, :4].cpu().numpy().copy()
+    rows = per_kernel_profile(eng, dev[0])
+    conv = [r for r in rows if r[1].startswith('conv_mfma_kernel') and r[1].rstrip('>').endswith(' 1')]
+    ms16 = sum(r[3] for r in conv)
+    fl16 = sum(r[2] for r in conv)
+    out = {'metric': 'frames/sec on 960x540 seq', 'value': round(S * T / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
+           'steps': S * T, 'warmup': S * T, 'ms_per_step': round(med * 1e3 / (S * T), 4), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f16 conv operands (f32 accumulate), f32 first layer / flow head / Kalman',
+           'data': 'synthetic (rolled random texture uint8 frames, seeded random weights)',
+           'repetitions': len(times),
+           'config': {'workload': 'BASELINE configs[4]: %d sequences x %d frames of %dx%d (grid 68x120), fp16 convs + '
+                                  'fp32 Kalman, one batched scan launch' % (S, T, H, W), 'tower_batch': B},
+           'roofline': {'kernel': 'conv_mfma_kernel<..., PREC=1> (all fp16-operand conv launches of a batch)',
+                        'bound': 'mfma', 'achieved': round(fl16 / (ms16 * 1e-3) / 1e12, 1),
+                        'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None},
+           'tolerance': 'own tolerance (tests/test_gpu_e2e.py::test_config5_fp16_convs_fp32_kalman): coord max-abs '
+                        '<= 2e-2, confidence max-rel <= 5e-2 vs the fp32 oracle'}
+    if not args.no_cpu_baseline:
+        # parity of the fp16 path against the fp32 HIP path on the same frames (the fp32 path is
+        # itself checked against the oracle in tests/)
+        del eng
+        torch.cuda.empty_cache()
+        eng32 = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * 4,
+                            device=str(device))
+        r32 = eng32.process_sequences(dev[:, :4].contiguous()).cpu().numpy()
+        out['parity_vs_fp32_path'] = {
+            'frames': int(S * 4), 'coord_max_abs': float(np.abs(rec16[..., :3] - r32[..., :3]).max()),
+            'conf_max_rel': float((np.abs(rec16[..., 3] - r32[..., 3]) / np.abs(r32[..., 3])).max())}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     import torch
@@ -271,6 +469,10 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    if args.config == 'c2':
+        return bench_c2(args, device)
+    if args.config == 'c5':
+        return bench_c5(args, device)
     dist = None
     backend = None
     if world > 1:
@@ -284,20 +486,20 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from kfnet_amd.KFNet.eval import get_transform  # noqa: F401
     from kfnet_amd.engine import KFNetEngine
     from kfnet_amd.synth import synthetic_sequence, synthetic_transform
     from kfnet_amd.weights import synthetic_weights
-    from kfnet_amd.dist import run_chunk
-    from oracle import kfnet_oracle as O
+    from kfnet_amd.dist import make_link, needs_state, run_chunk
 
     K, Wm = args.steps, args.warmup
-    B = max(1, min(args.batch, K))
+    B = max(1, min(args.batch, K)) if args.batch > 0 else auto_batch(K)
     Wt = synthetic_weights(1234)
-    T4 = O.get_transform(synthetic_transform())
+    T4 = np.linalg.inv(synthetic_transform())      # = get_transform(transform.txt) (KFNet/train.py:49-58)
     # the whole job is one N*K-frame sequence; rank r owns frames [r*K, (r+1)*K)
     # (synthetic frames are generated per rank from the global frame index)
     lo = rank * K
-    need_prev = 1 if lo > 0 else 0
+    need_prev = 1 if needs_state(lo, 500) else 0
     frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
                       max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune,
@@ -306,28 +508,19 @@ def main():
     dev_all = eng.upload_frames(frames_all)
     dev_prev = dev_all[0] if need_prev else None
     dev_frames = dev_all[need_prev:]
+    link = make_link(dist, rank, world, dev_index, prefer=os.environ.get('KFN_STATE_LINK', 'auto'))
 
-    # warm-up: W untimed steps
+    # warm-up: W untimed steps (+ one untimed sharded pass that opens the p2p channels)
     if Wm > 0:
         eng.process(dev_frames[:min(Wm, K)], t0=lo)
     torch.cuda.synchronize()
     if dist is not None:
-        # warm the p2p channels used by the state hand-off
-        run_chunk(eng, dev_frames[:B], lo, rank, world, dist, dev_prev)
+        # (the full chunk: the send/recv pairing rule is a function of the chunk boundaries)
+        run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev)
         torch.cuda.synchronize()
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    run_chunk(eng, dev_frames, lo, rank, world, dist, dev_prev)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    times = timed_repetitions(lambda: run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev),
+                              dist, device, backend, args.min_seconds)
+    elapsed = float(np.median(times))
     total_frames = K * world
     fps = total_frames / elapsed
 
@@ -338,11 +531,15 @@ def main():
         'dtype': {'f32': 'f32', 'f16': 'f16 conv operands (f32 accumulate, f32 activations, f32 Kalman)',
                   'f16x3': 'f32 emulated by 3 fp16 MFMA products of hi/lo-split operands (f32 accumulate)'}[args.conv_operands],
         'data': 'synthetic (rolled random texture uint8 frames, seeded He-uniform random weights)',
+        'repetitions': len(times), 'timed_seconds': round(float(np.sum(times)), 3),
+        'ms_per_step_min_max': [round(min(times) * 1e3 / K, 4), round(max(times) * 1e3 / K, 4)],
+        'timing': 'each repetition = exactly %d steps bracketed by barrier+synchronize, MAX over ranks; value and '
+                  'ms_per_step are the MEDIAN repetition' % K,
         'config': {'workload': 'full KFNet (SCoordNet+OFlowNet+Kalman) %d-frame %dx%d seq per GPU, random weights'
                                % (K, args.height, args.width),
                    'frames_total': total_frames, 'tower_batch': B, 'reset_period': 500,
-                   'parallelism': 'frame-sharded x%d, Kalman state rank->rank via %s send/recv'
-                                  % (world, 'RCCL' if backend in (None, 'nccl') else backend + ' (ranks share a GPU: functional test only)')},
+                   'parallelism': 'frame-sharded x%d, Kalman state rank->rank via %s'
+                                  % (world, link.name if link is not None else 'nothing (single GPU)')},
     }
     if rank == 0:
         rows = per_kernel_profile(eng, dev_frames)
@@ -407,6 +604,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames_all[need_prev:need_prev + max(args.cpu_steps, 2)]
             cb, cpu_recs = cpu_baseline(host_frames, Wt, T4, args.cpu_steps)
+            cb['sample_is_config1'] = bool(args.cpu_steps == 16)
             out['cpu_baseline'] = cb
             gpu_recs = eng.process(dev_frames[:args.cpu_steps], t0=0).cpu().numpy()
             out['parity_vs_cpu_restatement'] = {
@@ -436,6 +634,8 @@ def main():
                     'conf_max_rel_vs_cpu': float((np.abs(g2[..., 3] - cpu_recs[..., 3]) / np.abs(cpu_recs[..., 3])).max()),
                     'note': 'opt-in (KFNetEngine(conv_operands="f16x3")); reported beside, never as, the fp32 headline value'}
         print(json.dumps(out))
+    if link is not None:
+        link.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,7 +12,8 @@
  *   - All tensors are device pointers to fp32, NHWC, unless the name says otherwise.
  *     The caller owns every buffer; the library never allocates or frees tensor memory
  *     behind the caller's back and keeps no per-call state (re-entrant; any number of
- *     host threads may call with distinct streams).
+ *     host threads may call with distinct streams, on any device: launches go to the
+ *     calling thread's current device, kernel attributes are set per device).
  *   - `stream` is a hipStream_t (NULL = the default stream).  All work is asynchronous
  *     on that stream and is hipGraph-capturable (no allocation / sync inside a launch).
  *   - A "pixel stride" (ldx / ldy) is the distance in floats between consecutive
@@ -34,7 +35,7 @@ extern "C" {
 #define KFN_ERR_HIP (-2)
 #define KFN_ERR_UNSUPPORTED (-3)
 
-#define KFN_ABI_VERSION 2
+#define KFN_ABI_VERSION 3
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -235,6 +236,29 @@ int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt
 /* ---- Network.concat fallback (cnn_wrapper/network.py:316-318): strided channel copy -- */
 int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int P, int C,
                       void* stream);
+
+/* ---- multi-GPU: rank -> rank hand-off of the recurrent state (RCCL point-to-point) ----
+ * No reference counterpart (the reference is single-device: KFNet/train.py:375 is its only
+ * device placement).  BASELINE config 4 / SURVEY.md §8(e): a T-frame sequence is cut into
+ * contiguous chunks, one per rank = GPU; everything but the scan depends on images only, so
+ * the one exchange is the [H,W,4] fp32 state (what KFNet/eval.py:103-104 feeds back through
+ * SetVariableByName) from the rank that finished chunk r to the rank that owns chunk r+1.
+ * ncclSend / ncclRecv on `stream`, i.e. ordered behind/before the kfn_kalman_scan launches
+ * on that stream; no host synchronisation.  librccl is bound at run time (dlopen).
+ *   kfn_comm_unique_id  rank 0 creates the 128-byte id and distributes it out of band
+ *                       (torch.distributed / MPI / a file);
+ *   kfn_comm_init       collective over all ranks; binds `device` to the calling thread;
+ *   kfn_send_state /    count = H*W*4 floats; a send must be matched by the peer's recv of
+ *   kfn_recv_state      the same size (kfnet_amd/dist.py pairs them by the reset rule: a
+ *                       chunk that starts on a reset frame receives nothing). */
+#define KFN_COMM_ID_BYTES 128
+typedef struct kfn_comm kfn_comm;
+int kfn_comm_unique_id(void* id, size_t bytes /* == KFN_COMM_ID_BYTES */);
+int kfn_comm_init(kfn_comm** comm, int rank, int nranks, const void* unique_id, int device);
+int kfn_comm_destroy(kfn_comm* comm);
+int kfn_comm_rank(const kfn_comm* comm, int* rank, int* nranks);
+int kfn_send_state(kfn_comm* comm, int peer, const float* state /* [H,W,4] */, int H, int W, void* stream);
+int kfn_recv_state(kfn_comm* comm, int peer, float* state /* [H,W,4] */, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -210,9 +210,7 @@ class KFNet():
         feat7.base = ring
         feat7.rel_off = 0
         feat7.rel_batch = 1
-        for op in tower.ops:
-            if op.name == 'feat7':
-                op.epilogue = _lib.EPI_L2NORM
+        tower.set_epilogue('feat7', _lib.EPI_L2NORM)     # tf.nn.l2_normalize (KFNet/KFNet.py:340)
         self.feat_tower = tower
         self.frame_ops += [op for op in g.ops[n0:] if op not in self.frame_ops]
         return ring

@@ -8,6 +8,12 @@ I holds image_list.txt (+ optional label_list.txt) and transform.txt; for every 
 `--synthetic T` replaces the image list by a seeded synthetic sequence (no dataset is
 reachable from the build environment); `--random_weights` replaces the checkpoint.
 
+Launched under `python -m torch.distributed.run --nproc-per-node N -m kfnet_amd.KFNet.eval ...`
+the sequence is frame-sharded (BASELINE config 4): rank r processes its contiguous chunk on
+GPU LOCAL_RANK (falling back to sharing GPUs over gloo when there are fewer GPUs than ranks),
+receives the Kalman state from rank r-1 just before its scan and writes its own
+coord_<i>.npy files -- bit-identical to a single-process run (kfnet_amd/dist.py).
+
 Host loop semantics kept from eval.py: sequence_length = 500 irrespective of --scene
 (KFNetDataSpec() is built with the default scene), reset at i % 500 == 0,
 raw (untransformed, ungated) KF state fed back, NIS gate on the output only.
@@ -45,9 +51,42 @@ def load_images(paths, image_size):
     return out
 
 
+def eval_sharded(image_paths, transform, weights, output_folder, rank, world, link, nis=False,
+                 image_size=(480, 640), batch=4, frames=None, sequence_length=500, verbose=True,
+                 device=None, decode_workers=8):
+    """Frame-sharded prediction (BASELINE config 4): this rank owns the contiguous chunk
+    `chunk_bounds(T, world, rank)`, runs the state-independent heavy phase for it at once,
+    receives the [h,w,4] Kalman state from rank-1 (unless its chunk starts on a reset
+    frame), scans, sends the state on and writes coord_<i>.npy for its own frames.
+    Returns (first_frame, records [n,h,w,4])."""
+    import torch
+    from ..dist import chunk_bounds, needs_state, run_chunk
+    from ..engine import KFNetEngine
+    T = len(image_paths) if frames is None else frames.shape[0]
+    lo, hi = chunk_bounds(T, world, rank)
+    dev = device if device is not None else 'cuda:%d' % torch.cuda.current_device()
+    eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
+                      reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=max(hi - lo, 1),
+                      device=dev)
+    need_prev = 1 if (hi > lo and needs_state(lo, sequence_length)) else 0
+    if frames is not None:
+        host = np.ascontiguousarray(frames[lo - need_prev:hi])
+    else:
+        host = load_images(image_paths[lo - need_prev:hi], image_size)
+    dev_all = eng.upload_frames(host) if host.shape[0] else torch.empty((0, eng.H, eng.W, 3), dtype=torch.uint8, device=dev)
+    rec = run_chunk(eng, dev_all[need_prev:], lo, rank, world, link, dev_all[0] if need_prev else None)
+    rec = rec.cpu().numpy().copy()
+    if output_folder and os.path.isdir(output_folder):
+        for k in range(rec.shape[0]):
+            np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
+    if verbose:
+        print('rank %d/%d: frames %d~%d done' % (rank, world, lo, hi - 1))
+    return lo, rec
+
+
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None,
-         decode_workers=8):
+         decode_workers=8, device=None):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
@@ -57,9 +96,12 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     from ..pipeline import ChunkLoader, StreamedSequence
     T = len(image_paths) if frames is None else frames.shape[0]
     want_metrics = label_paths is not None or labels is not None
+    if device is None:   # --gpu N: everything (buffers, streams, launches) lives on the CURRENT device
+        import torch
+        device = 'cuda:%d' % torch.cuda.current_device()
     eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
                       reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk,
-                      emit_debug=want_metrics)
+                      emit_debug=want_metrics, device=device)
     records, all_metrics = [], []
 
     def label(i):
@@ -117,6 +159,8 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--synthetic', type=int, default=0, help='use a seeded synthetic sequence of this many frames')
     ap.add_argument('--random_weights', action='store_true')
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
     a = ap.parse_args(argv)
     if a.scene not in SCENES:
         print('Invalid scene:', a.scene)   # KFNet/train.py:142-144
@@ -130,12 +174,18 @@ def main(argv=None):
             return 1
         W = load_npz(snapshot)
     import torch
+    size = (a.height, a.width)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        return _main_sharded(a, W, size, rank, world)
     torch.cuda.set_device(a.gpu)
+    device = 'cuda:%d' % a.gpu
     if a.synthetic > 0:
         from ..synth import synthetic_sequence, synthetic_transform
-        frames = synthetic_sequence(a.synthetic)
+        frames = synthetic_sequence(a.synthetic, a.height, a.width)
         transform = np.linalg.inv(synthetic_transform())
-        eval(None, transform, W, a.output_folder, a.NIS, frames=frames, batch=a.batch)
+        eval(None, transform, W, a.output_folder, a.NIS, image_size=size, frames=frames, batch=a.batch, device=device)
         return 0
     image_list = os.path.join(a.input_folder, 'image_list.txt')
     transform_file = os.path.join(a.input_folder, 'transform.txt')
@@ -148,8 +198,60 @@ def main(argv=None):
     label_paths = read_lines(label_list) if os.path.exists(label_list) else None
     if label_paths is not None:
         assert len(image_paths) == len(label_paths)   # KFNet/eval.py:37
-    eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, batch=a.batch, label_paths=label_paths)
+    eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, image_size=size, batch=a.batch,
+         label_paths=label_paths, device=device)
     return 0
+
+
+def _main_sharded(a, W, size, rank, world):
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE)."""
+    import torch
+    import torch.distributed as dist
+    from ..dist import make_link
+    ndev = torch.cuda.device_count()
+    dev_index = int(os.environ.get('LOCAL_RANK', '0')) % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = os.environ.get('KFN_DIST_BACKEND', 'nccl' if ndev >= world else 'gloo')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    link = make_link(dist, rank, world, dev_index, prefer=os.environ.get('KFN_STATE_LINK', 'auto'))
+    try:
+        if a.synthetic > 0:
+            from ..synth import synthetic_sequence, synthetic_transform
+            from ..dist import chunk_bounds, needs_state
+            lo, hi = chunk_bounds(a.synthetic, world, rank)
+            # every rank generates only the frames it needs (frame t depends on (seed, t) alone)
+            first = lo - (1 if (hi > lo and needs_state(lo, 500)) else 0)
+            part = synthetic_sequence(hi - first, a.height, a.width, start=first)
+            frames = _ShiftedFrames(part, first, a.synthetic)
+            transform = np.linalg.inv(synthetic_transform())
+            eval_sharded(None, transform, W, a.output_folder, rank, world, link, a.NIS, image_size=size,
+                         batch=a.batch, frames=frames)
+        else:
+            image_paths = read_lines(os.path.join(a.input_folder, 'image_list.txt'))
+            eval_sharded(image_paths, get_transform(os.path.join(a.input_folder, 'transform.txt')), W,
+                         a.output_folder, rank, world, link, a.NIS, image_size=size, batch=a.batch)
+        torch.cuda.synchronize()
+        dist.barrier()
+    finally:
+        if link is not None:
+            link.close()
+        dist.destroy_process_group()
+    return 0
+
+
+class _ShiftedFrames(object):
+    """A window [first, first+n) of a T-frame sequence that indexes like the whole sequence
+    (so a rank holds only its own frames)."""
+
+    def __init__(self, part, first, total):
+        self.part, self.first, self.shape = part, first, (total,) + part.shape[1:]
+
+    def __getitem__(self, sl):
+        return self.part[sl.start - self.first:sl.stop - self.first]
 
 
 if __name__ == '__main__':

@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
+ABI_VERSION = 3
+COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
@@ -68,6 +70,12 @@ SYMBOLS = {
     'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    'kfn_comm_unique_id': (_i, [_vp, _sz]),
+    'kfn_comm_init': (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),
+    'kfn_comm_destroy': (_i, [_vp]),
+    'kfn_comm_rank': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'kfn_send_state': (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    'kfn_recv_state': (_i, [_vp, _i, _vp, _i, _i, _vp]),
 }
 
 _lib = None
@@ -86,7 +94,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.kfn_abi_version() != 2:
+    if lib.kfn_abi_version() != ABI_VERSION:
         raise KfnError('libkfnet_hip.so ABI version mismatch')
     _lib = lib
     return lib

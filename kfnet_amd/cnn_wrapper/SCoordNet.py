@@ -59,8 +59,6 @@ class SCoordNet(Network):
         epilogue, so after this call channel 3 of the 'prediction' buffer already holds sigma;
         both results are zero-copy channel views of that buffer."""
         head_name = HEAD[0]
-        for op in self.ops:
-            if op.name == head_name:
-                op.epilogue = _lib.EPI_EXP_CH3
+        self.set_epilogue(head_name, _lib.EPI_EXP_CH3)
         packed = self.get_output_by_name(head_name)
         return packed.channels(0, 3, name='coord'), packed.channels(3, 1, name='uncertainty')

@@ -144,6 +144,32 @@ class Network(object):
         self.ops.append(op)
         return op
 
+    def set_epilogue(self, layer_name, epilogue):
+        """Fuse a head operation (KFN_EPI_*: l2_normalize, exp on channel 3, exp * 1e-2) into the
+        launch that produces `layer_name`.  Only the direct MFMA convolution carries these
+        epilogues; a layer that was routed to the Winograd path is re-routed to the direct
+        kernel here (its weights are then packed for that kernel), so that a routing heuristic
+        can never silently drop e.g. tf.nn.l2_normalize (KFNet/KFNet.py:340)."""
+        from ..graph import pack_conv_kernel as _direct_pack
+        hits = [op for op in self.ops if op.name == layer_name and isinstance(op, ConvOp)]
+        if len(hits) != 1:
+            raise KeyError('set_epilogue: %d convolution launches are named %r' % (len(hits), layer_name))
+        op = hits[0]
+        if isinstance(op, WinogradConvOp):
+            if op.kernel.storage is not None:
+                raise RuntimeError('set_epilogue(%r): weights are already packed for the Winograd kernel' % layer_name)
+            # in place (the op object may already sit in other launch lists): same tensors and
+            # variables, direct-kernel weight layout
+            op.kernel.pack = _direct_pack
+            op.__class__ = ConvOp
+            op.workspace = None
+            op.epilogue = epilogue
+            return op
+        if op.operand_dtype == _lib.OPERAND_F32 and op.y.shape[3] > 32 and epilogue == _lib.EPI_L2NORM:
+            raise ValueError('the l2_normalize epilogue needs <= 32 output channels (one MFMA column block)')
+        op.epilogue = epilogue
+        return op
+
     # ---- hot-path layers -----------------------------------------------------------
     @layer
     def conv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING,

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <atomic>
+#include <cstdint>
 #include "../../include/kfnet_hip.h"
 
 namespace kfn {
@@ -33,6 +35,20 @@ inline int check_hip(hipError_t e, const char* what) {
   do {                                                             \
     if (!(cond)) return ::kfn::fail(KFN_ERR_ARG, __VA_ARGS__);     \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: `done`
+// (one static per kernel instantiation) holds a bit per device it has been applied on, so a
+// process that drives several GPUs (or host threads on different devices) sets it once on
+// each.  Thread-safe: the attribute is idempotent, the bit set is atomic.
+inline int set_max_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  KFN_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return KFN_OK;
+  KFN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.fetch_or(bit, std::memory_order_release);
+  return KFN_OK;
+}
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

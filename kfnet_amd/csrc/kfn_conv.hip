@@ -753,11 +753,10 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   a.fd_img = make_fastdiv((MODE == MODE_DECONV || MODE == MODE_CVOL) ? a.H * a.W : a.Ho * a.Wo);
   a.fd_row = make_fastdiv((MODE == MODE_DECONV || MODE == MODE_CVOL) ? a.W : a.Wo);
   auto kern = conv_mfma_kernel<TM, TN, WM, WN, BK, MODE, F16>;
-  static bool attr_done = false;  // benign race: idempotent attribute
-  if (!attr_done) {
-    KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
+  static std::atomic<uint64_t> attr_done{0};   // per kernel instantiation: bit per device
+  {
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem, attr_done);
+    if (rc != KFN_OK) return rc;
   }
   dim3 grid(a.tiles_m * a.tiles_n * (MODE == MODE_WINO ? 16 : 1)), block(NT);
   hipLaunchKernelGGL(kern, grid, block, smem, stream, a);

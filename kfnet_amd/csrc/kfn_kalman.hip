@@ -261,11 +261,10 @@ template <int KT, int PPT, bool DBL, bool PREFETCH>
 int launch_scan(const KalmanArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
   auto kern = kalman_scan_kernel<KT, PPT, DBL, PREFETCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+  static std::atomic<uint64_t> attr_done{0};   // per instantiation: bit per device
+  {
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done);
+    if (rc != KFN_OK) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(a.d.S), dim3(KT), smem, stream, a);
   KFN_LAUNCH_CHECK("kalman_scan_kernel");
@@ -303,12 +302,16 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
     KFN_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s));
     f32x4* buf[2] = {a.state, scratch};
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)d->S);
-    for (int t = 0; t < d->T; ++t)
+    int rc = KFN_OK;
+    for (int t = 0; t < d->T && rc == KFN_OK; ++t) {
       hipLaunchKernelGGL(kalman_step_kernel, grid, dim3(256), 0, s, a, buf[t & 1], buf[(t + 1) & 1], t);
-    if (d->T & 1) KFN_HIP(hipMemcpyAsync(a.state, scratch, bytes, hipMemcpyDeviceToDevice, s));
-    KFN_HIP(hipFreeAsync(scratch, s));
-    KFN_LAUNCH_CHECK("kalman_step_kernel");
-    return KFN_OK;
+      rc = kfn::check_hip(hipGetLastError(), "kalman_step_kernel");
+    }
+    if (rc == KFN_OK && (d->T & 1))
+      rc = kfn::check_hip(hipMemcpyAsync(a.state, scratch, bytes, hipMemcpyDeviceToDevice, s), "state copy-back");
+    // the scratch copy is released on every path (stream-ordered: after the launches above)
+    const int rc_free = kfn::check_hip(hipFreeAsync(scratch, s), "hipFreeAsync(scratch)");
+    return rc != KFN_OK ? rc : rc_free;
   }
   // 768 threads (12 wavefronts, 170-VGPR budget) x 7 pixels cover the 60x80 grid without
   // register spills; larger grids fall back to 1024 threads and the single-buffer form.

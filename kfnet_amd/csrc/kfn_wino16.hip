@@ -298,11 +298,10 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   a.x_bytes = (unsigned long long)x_bytes;
   a.u_bytes = (unsigned)u_bytes;
   constexpr size_t smem = (size_t)2 * (V_ELEMS + U_ELEMS) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    KFN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino16_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
+  static std::atomic<uint64_t> attr_done{0};
+  {
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino16_kernel), (int)smem, attr_done);
+    if (rc != KFN_OK) return rc;
   }
   hipLaunchKernelGGL(wino16_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, (hipStream_t)stream, a);
   KFN_LAUNCH_CHECK("wino16_kernel");

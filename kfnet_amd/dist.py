@@ -1,13 +1,26 @@
-"""Frame-sharded multi-GPU execution (one process per GPU, torch.distributed; backend
-'nccl' is RCCL over xGMI on ROCm, 'gloo' on CPU for tests).
+"""Frame-sharded multi-GPU execution (one process per GPU).
 
-The reference has no parallelism at all.  The path shards naturally
-(F7): everything heavy depends on images only, so a T-frame stream is cut into `world`
-contiguous chunks; the only exchange is the recurrent Kalman state -- one [h,w,4] fp32
-message (76.8 KB at 60x80) from rank r to rank r+1, sent when r has finished its scan.
-A chunk that starts on a reset boundary (global index % reset_period == 0) needs no
-message at all.  There is no collective on the data path.
+The reference has no parallelism at all (its only device placement is
+KFNet/train.py:375).  The path shards naturally (F7): everything heavy depends on images
+only, so a T-frame stream is cut into `world` CONTIGUOUS chunks, rank r owning chunk r; the
+only exchange is the recurrent Kalman state -- one [h,w,4] fp32 message (76.8 KB at 60x80,
+what KFNet/eval.py:103-104 feeds back through SetVariableByName) from rank r to rank r+1,
+sent when r has finished its scan.  There is no collective on the data path.
+
+Pairing rule (both sides evaluate it on the same frame index, so no message is ever
+unmatched): the chunk that starts at global frame f receives iff `needs_state(f)`; the
+chunk that ends at f (exclusive) sends iff rank+1 exists and `needs_state(f)`.  A chunk that
+starts on a reset boundary (f % reset_period == 0, KFNet/eval.py:94) is independent of its
+predecessor: it posts no receive and its predecessor no send, so it never waits.
+
+Transports (`StateLink`): `RcclLink` = the C ABI (kfn_comm_init / kfn_send_state /
+kfn_recv_state: ncclSend/ncclRecv over xGMI, stream-ordered with the scan, device to device);
+`TorchLink` = torch.distributed send/recv (backend 'nccl' is RCCL too; 'gloo' stages the
+message through the host -- CPU tests, or several ranks sharing one GPU).
 """
+import ctypes as C
+
+from . import _lib
 
 
 def needs_state(first_frame, reset_period):
@@ -24,46 +37,152 @@ def chunk_bounds(total_frames, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def run_chunk(eng, dev_frames, first_frame, rank, world, dist=None, dev_prev_frame=None):
-    """Process this rank's chunk.  `dist` is the initialised torch.distributed module (or
-    None for a single process)."""
-    T = dev_frames.shape[0]
-    dep = needs_state(first_frame, eng.reset_period)
-    if dep:
-        if dev_prev_frame is None:
-            raise ValueError('chunk starting at frame %d needs the preceding frame' % first_frame)
-        eng.prime(dev_prev_frame)          # flow features of frame first_frame-1, recomputed locally
-    eng.heavy(dev_frames, T)               # state-independent: no waiting on other ranks
-    # RCCL ('nccl') moves the device tensor directly over xGMI; with the 'gloo' backend (CPU
-    # tests, or several ranks sharing one GPU) the 76.8 KB message is staged through the host.
-    via_host = dist is not None and world > 1 and dist.get_backend() != 'nccl'
-    if dist is not None and world > 1 and rank > 0:
-        state = eng.get_state()
-        buf = state.cpu() if via_host else (state if dep else state.clone())
-        dist.recv(buf, src=rank - 1)       # the 76.8 KB hand-off
-        if dep and via_host:
+def handoff_plan(first_frame, n_frames, rank, world, reset_period):
+    """(recv_from_prev, send_to_next) for the chunk [first_frame, first_frame + n_frames)."""
+    recv = world > 1 and rank > 0 and needs_state(first_frame, reset_period)
+    send = world > 1 and rank + 1 < world and needs_state(first_frame + n_frames, reset_period)
+    return recv, send
+
+
+class TorchLink(object):
+    """State hand-off through an initialised torch.distributed process group."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.via_host = dist.get_backend() != 'nccl'
+        self.name = 'torch.distributed/' + dist.get_backend()
+
+    def recv(self, state, src, eng=None):
+        if self.via_host:
+            buf = state.cpu()
+            self.dist.recv(buf, src=src)
             state.copy_(buf)
-        # (a chunk that resets on its first frame still receives, to keep the send/recv
-        #  pairing uniform, but ignores the message)
-    eng.scan(T, first_frame)
-    if dist is not None and world > 1 and rank + 1 < world:
-        state = eng.get_state()
-        dist.send(state.cpu() if via_host else state, dst=rank + 1)
+        else:
+            self.dist.recv(state, src=src)
+
+    def send(self, state, dst, eng=None):
+        self.dist.send(state.cpu() if self.via_host else state, dst=dst)
+
+    def close(self):
+        pass
+
+
+class RcclLink(object):
+    """State hand-off through the C ABI (include/kfnet_hip.h: kfn_comm_*, kfn_send_state,
+    kfn_recv_state).  `dist` (any initialised backend) is used once, to distribute rank 0's
+    128-byte RCCL unique id; the data path never touches torch.distributed."""
+
+    def __init__(self, rank, world, device_index, dist=None, unique_id=None, grid_hw=None):
+        self.lib = _lib.load()
+        self.rank, self.world = rank, world
+        self.name = 'C-ABI kfn_send_state/kfn_recv_state (RCCL ncclSend/ncclRecv)'
+        if unique_id is None:
+            ids = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+                _lib.check(self.lib.kfn_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'kfn_comm_unique_id')
+                ids[0] = bytes(buf.raw)
+            if world > 1:
+                if dist is None:
+                    raise ValueError('RcclLink needs torch.distributed (or an explicit unique_id) to share the id')
+                dist.broadcast_object_list(ids, src=0)
+            unique_id = ids[0]
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError('unique id must be %d bytes' % _lib.COMM_ID_BYTES)
+        self.comm = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        _lib.check(self.lib.kfn_comm_init(C.byref(self.comm), rank, world, idbuf, int(device_index)), 'kfn_comm_init')
+        self.grid_hw = grid_hw
+
+    def _hw(self, eng):
+        return (eng.h, eng.w) if eng is not None else self.grid_hw
+
+    def recv(self, state, src, eng=None):
+        h, w = self._hw(eng)
+        stream = eng._stream() if eng is not None else None
+        _lib.check(self.lib.kfn_recv_state(self.comm, src, state.data_ptr(), h, w, stream), 'kfn_recv_state')
+
+    def send(self, state, dst, eng=None):
+        h, w = self._hw(eng)
+        stream = eng._stream() if eng is not None else None
+        _lib.check(self.lib.kfn_send_state(self.comm, dst, state.data_ptr(), h, w, stream), 'kfn_send_state')
+
+    def close(self):
+        if self.comm:
+            _lib.check(self.lib.kfn_comm_destroy(self.comm), 'kfn_comm_destroy')
+            self.comm = C.c_void_p()
+
+
+class LoopbackLink(object):
+    """N "ranks" inside ONE process (SURVEY.md §4.2 'multi-GPU without a cluster'): the ranks'
+    chunks are run one after the other and the state travels through a dict -- the same
+    run_chunk code path and pairing rule as the real transports, used to check that a sharded
+    run is bit-identical to a single pass."""
+
+    def __init__(self, mailbox, rank):
+        self.mailbox, self.rank = mailbox, rank
+        self.name = 'in-process loopback'
+
+    def recv(self, state, src, eng=None):
+        state.copy_(self.mailbox.pop((src, self.rank)))   # KeyError = unmatched receive
+
+    def send(self, state, dst, eng=None):
+        assert (self.rank, dst) not in self.mailbox, 'unmatched send'
+        self.mailbox[(self.rank, dst)] = state.clone()
+
+    def close(self):
+        pass
+
+
+def make_link(dist, rank, world, device_index, prefer='auto'):
+    """The transport for this process group: the C-ABI RCCL link when every rank owns a GPU
+    (backend 'nccl'), torch.distributed otherwise.  prefer = 'auto' | 'cabi' | 'torch'."""
+    if dist is None or world <= 1:
+        return None
+    if prefer != 'torch' and dist.get_backend() == 'nccl':
+        try:
+            return RcclLink(rank, world, device_index, dist=dist)
+        except (_lib.KfnError, OSError):
+            if prefer == 'cabi':
+                raise
+    return TorchLink(dist)
+
+
+def run_chunk(eng, dev_frames, first_frame, rank, world, link=None, dev_prev_frame=None):
+    """Process this rank's chunk [first_frame, first_frame + T).  `link` is a StateLink (or an
+    initialised torch.distributed module, wrapped on the fly; None for a single process)."""
+    if link is not None and hasattr(link, 'get_backend'):   # the torch.distributed module itself
+        link = TorchLink(link)
+    T = int(dev_frames.shape[0])
+    recv, send = handoff_plan(first_frame, T, rank, world if link is not None else 1, eng.reset_period)
+    if T > 0:
+        if needs_state(first_frame, eng.reset_period):
+            if dev_prev_frame is None:
+                raise ValueError('chunk starting at frame %d needs the preceding frame' % first_frame)
+            eng.prime(dev_prev_frame)      # flow features of frame first_frame-1, recomputed locally
+        eng.heavy(dev_frames, T)           # state-independent: no waiting on other ranks
+    if recv:
+        link.recv(eng.get_state(), rank - 1, eng)      # the 76.8 KB hand-off, into the live state
+    if T > 0:
+        eng.scan(T, first_frame)
+    if send:                               # an empty chunk just forwards what it received
+        link.send(eng.get_state(), rank + 1, eng)
     return eng.records(T)
 
 
-def scan_sharded_host(states_in, chunk_scan_fn, rank, world, dist, state_buf, first_frame, reset_period):
+def scan_sharded_host(states_in, chunk_scan_fn, rank, world, dist, state_buf, first_frame, reset_period,
+                      n_frames=None):
     """Backend-agnostic skeleton of the hand-off used by the gloo CPU tests: receive the
     state if the chunk depends on it, run `chunk_scan_fn(state_buf)` (which updates
-    state_buf in place), then send it on."""
-    dep = needs_state(first_frame, reset_period)
-    if world > 1 and rank > 0:
-        if dep:
-            dist.recv(state_buf, src=rank - 1)
-        else:
-            tmp = state_buf.clone()
-            dist.recv(tmp, src=rank - 1)
-    chunk_scan_fn(state_buf)
-    if world > 1 and rank + 1 < world:
+    state_buf in place), then send it on if the next chunk depends on it.  `n_frames` is
+    this chunk's length (needed for the send rule)."""
+    if n_frames is None:
+        raise ValueError('scan_sharded_host needs the chunk length to apply the pairing rule')
+    recv, send = handoff_plan(first_frame, n_frames, rank, world, reset_period)
+    if recv:
+        dist.recv(state_buf, src=rank - 1)
+    if n_frames > 0:
+        chunk_scan_fn(state_buf)
+    if send:
         dist.send(state_buf, dst=rank + 1)
     return state_buf

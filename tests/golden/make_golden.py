@@ -7,7 +7,9 @@ no golden vectors (F4), so these fixtures pin the build's OWN oracle -- parity i
 synthetic weights (regenerated from the seed; only a checksum is stored), a seeded rigid
 transform, reset_period 4.  Outputs: per-frame records and the stage outputs of frame 1.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py           (kfnet_small.npz, 64x96)
+    python tests/golden/make_golden.py --full    (kfnet_full.npz: a 4-frame 480x640 sequence, records only;
+                                                  frame 0 is the single-frame case = pure measurement)
 """
 import hashlib
 import os
@@ -33,7 +35,24 @@ def weights_digest(W):
     return h.hexdigest()
 
 
+def main_full():
+    """Full-size fixture: 4 frames 480x640 of the seed-1 stream through the numpy
+    fp64 gold (about 40 s of CPU); only the fp32 [4,60,80,4] records and the seeds are stored."""
+    W = synthetic_weights(SEED_W)
+    imgs = synthetic_sequence(4, 480, 640, seed=SEED_IMG)
+    T4 = O.get_transform(synthetic_transform())
+    rec = O.eval_sequence(imgs, W, T4, reset_period=500, dtype=np.float64)
+    out = dict(records=rec.astype(np.float32), transform=T4, weights_sha256=np.array(weights_digest(W)),
+               images_sha256=np.array(hashlib.sha256(imgs.tobytes()).hexdigest()),
+               seed_w=SEED_W, seed_img=SEED_IMG, reset_period=500, frames=4, height=480, width=640)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'kfnet_full.npz')
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), 'bytes')
+
+
 def main():
+    if '--full' in sys.argv:
+        return main_full()
     W = synthetic_weights(SEED_W)
     imgs = synthetic_sequence(5, 64, 96, seed=SEED_IMG)
     T4 = O.get_transform(synthetic_transform())

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from kfnet_amd.dist import chunk_bounds, needs_state, scan_sharded_host
+from kfnet_amd.dist import chunk_bounds, handoff_plan, needs_state, scan_sharded_host
 
 
 def _inputs(T, H, W, seed=0):
@@ -59,8 +59,8 @@ def _worker(rank, world, port, T, H, W, reset_period, out_dir):
         buf.copy_(torch.from_numpy(s))
         recs['r'] = r
 
-    scan_sharded_host(None, chunk_fn, rank, world, dist, state, lo, reset_period)
-    np.save(os.path.join(out_dir, 'rec_%d.npy' % rank), recs['r'])
+    scan_sharded_host(None, chunk_fn, rank, world, dist, state, lo, reset_period, n_frames=hi - lo)
+    np.save(os.path.join(out_dir, 'rec_%d.npy' % rank), recs.get('r', np.zeros((0, H, W, 4), np.float32)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,9 +73,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('T,reset_period', [(11, 500), (12, 6), (9, 4)])
-def test_sharded_scan_equals_serial(tmp_path, T, reset_period):
-    H, W, world = 6, 9, 2
+@pytest.mark.parametrize('T,reset_period,world', [(11, 500, 2), (12, 6, 2), (9, 4, 2), (3, 500, 4),
+                                                  (2048, 500, 8)])   # last = BASELINE config 4's chunking
+def test_sharded_scan_equals_serial(tmp_path, T, reset_period, world):
+    """(2048, 500, 8): eight contiguous 256-frame chunks, resets at 500/1000/1500/2000 fall INSIDE
+    chunks 1, 3, 5 and 7; chunk 4 starts at 1024 (needs the state), no chunk starts on a reset.
+    (3, 500, 4): an empty trailing chunk."""
+    H, W = 6, 9
     mp.spawn(_worker, args=(world, _free_port(), T, H, W, reset_period, str(tmp_path)), nprocs=world, join=True)
     flow, sig, meas = _inputs(T, H, W)
     ref, _ = _scan(flow, sig, meas, np.zeros((H, W, 4), np.float32), 0, reset_period)
@@ -88,3 +92,22 @@ def test_chunking_rules():
     assert chunk_bounds(2048, 8, 3) == (768, 1024)
     assert not needs_state(0, 500) and not needs_state(1000, 500) and needs_state(256, 500)
     assert needs_state(256, 0)
+
+
+def test_handoff_pairing_is_symmetric():
+    """Every send has exactly one matching recv, for any chunking and reset period; a chunk
+    that starts on a reset frame neither receives nor makes its predecessor send."""
+    for total, world, period in [(2048, 8, 500), (2000, 4, 500), (12, 2, 6), (3, 4, 500), (1000, 3, 0), (7, 7, 2)]:
+        plans = []
+        for r in range(world):
+            lo, hi = chunk_bounds(total, world, r)
+            plans.append((lo, hi, handoff_plan(lo, hi - lo, r, world, period)))
+        assert plans[0][2][0] is False and plans[-1][2][1] is False
+        for r in range(world - 1):
+            assert plans[r][2][1] == plans[r + 1][2][0], (total, world, period, r)
+            assert plans[r][1] == plans[r + 1][0]
+    # 2000 frames over 4 ranks with period 500: every chunk starts on a reset -> no message at all
+    assert all(handoff_plan(500 * r, 500, r, 4, 500) == (False, False) for r in range(4))
+    # config 4: all 7 messages are needed
+    assert [handoff_plan(256 * r, 256, r, 8, 500) for r in range(8)] == \
+        [(False, True)] + [(True, True)] * 6 + [(True, False)]

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     lib = _lib.load()
-    assert lib.kfn_abi_version() == 2
+    assert lib.kfn_abi_version() == _lib.ABI_VERSION
 
 
 def test_no_gpu_means_loud_failure():
@@ -154,4 +154,63 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe),
                            '-L', os.path.dirname(lib), '-lkfnet_hip', '-Wl,-rpath,' + os.path.dirname(lib)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    assert out == ['2', '240', '320']          # ABI version, TF-SAME output size of conv2a
+    assert out == ['3', '240', '320']          # ABI version, TF-SAME output size of conv2a
+
+
+def test_comm_entry_points_validate_arguments_without_a_gpu():
+    """kfn_comm_* / kfn_send_state / kfn_recv_state (the RCCL hand-off of include/kfnet_hip.h) are
+    exported and reject bad arguments before touching RCCL or the device."""
+    import ctypes as C
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    for name in ('kfn_comm_unique_id', 'kfn_comm_init', 'kfn_comm_destroy', 'kfn_comm_rank', 'kfn_send_state',
+                 'kfn_recv_state'):
+        assert hasattr(lib, name)
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    comm = C.c_void_p()
+    assert lib.kfn_comm_unique_id(None, _lib.COMM_ID_BYTES) == -1
+    assert lib.kfn_comm_unique_id(buf, 64) == -1 and b'128-byte' in lib.kfn_last_error()
+    assert lib.kfn_comm_init(None, 0, 1, buf, 0) == -1
+    assert lib.kfn_comm_init(C.byref(comm), 0, 1, None, 0) == -1
+    assert lib.kfn_comm_init(C.byref(comm), 2, 2, buf, 0) == -1 and b'bad rank' in lib.kfn_last_error()
+    assert lib.kfn_comm_init(C.byref(comm), 0, 1, buf, -1) == -1
+    assert not comm.value
+    x = (C.c_float * 16)()
+    assert lib.kfn_send_state(None, 1, x, 2, 2, None) == -1 and b'null communicator' in lib.kfn_last_error()
+    assert lib.kfn_recv_state(None, 0, x, 2, 2, None) == -1
+    assert lib.kfn_comm_destroy(None) == 0      # destroying nothing is fine
+    assert lib.kfn_comm_rank(None, None, None) == -1
+
+
+def test_handoff_links_share_one_interface():
+    from kfnet_amd import dist as D
+    for cls in (D.TorchLink, D.RcclLink, D.LoopbackLink):
+        for m in ('recv', 'send', 'close'):
+            assert callable(getattr(cls, m))
+    box = {}
+    import torch
+    a, b = D.LoopbackLink(box, 0), D.LoopbackLink(box, 1)
+    s = torch.arange(8.0)
+    a.send(s, 1)
+    r = torch.zeros(8)
+    b.recv(r, 0)
+    assert torch.equal(r, s) and not box
+
+
+def test_epilogue_on_a_winograd_routed_layer_reroutes_to_the_direct_kernel():
+    """with winograd_min_channels <= 32, feat7 (3x3, 128 -> 32) would take the Winograd
+    path, which has no fused epilogue -- tf.nn.l2_normalize must not be dropped silently."""
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import ConvOp, Graph, WinogradConvOp, pack_conv_kernel
+    from kfnet_amd.KFNet.KFNet import KFNet, KFNetDataSpec
+    g = Graph()
+    g.winograd_min_channels = 32
+    images = g.placeholder((2, 64, 96, 3), 'u8', name='images')
+    net = KFNet(images, KFNetDataSpec(batch_size=2, image_size=(64, 96)))
+    feat7 = [op for op in net.feat_tower.ops if op.name == 'feat7']
+    assert len(feat7) == 1 and type(feat7[0]) is ConvOp and feat7[0].epilogue == _lib.EPI_L2NORM
+    assert feat7[0].kernel.pack is pack_conv_kernel and feat7[0] in net.frame_ops and feat7[0] in g.ops
+    # the other wide stride-1 layers of the tower did go to Winograd with this setting
+    assert any(isinstance(op, WinogradConvOp) for op in net.feat_tower.ops)
+    with pytest.raises(KeyError):
+        net.feat_tower.set_epilogue('no_such_layer', _lib.EPI_L2NORM)

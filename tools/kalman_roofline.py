@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Runs ONLY the roofline shape of the Kalman scan (S=256 sequences x T=64 frames x 60x80 px per
+launch, bench.py's `roofline_kalman`) so that a rocprofv3 PMC pass samples exactly that launch:
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -- python tools/kalman_roofline.py
+
+Expected HBM traffic per launch: 28 B/px in + 16 B/px out = 44 B x 256 x 64 x 4800 px = 3.46 GB
+(+ 39 MB of state load/store), against 5.98 GB of algorithmic traffic (76 B/px)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+if __name__ == '__main__':
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    print(json.dumps({'scan': bench.kalman_roofline(dev), 'fuse': bench.kalman_fuse_roofline(dev)}))

@@ -2,14 +2,13 @@
 # Regenerates the judged profile summaries of a round on the GPU box:
 #   bash tools/profile_round.sh r01        (writes gpurun_out/prof/<tag>_*; copy into profiles/)
 # Kernel trace and every PMC group are separate rocprofv3 runs (never combined with sys traces).
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 finddb() { find "$1" -name '*.db' | head -1; }
-python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
-SHORT="--steps 68 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline"
+SHORT="--steps 68 --min-seconds 0 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err )
 python tools/rocpd_stats.py "$(finddb $OUT/kt)" $OUT/${TAG}_kernel_stats.csv > /dev/null
 # same trace with the two towers serialised on one stream: kernel durations without the
@@ -20,12 +19,22 @@ for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -- python $R/bench.py $SHORT > /dev/null 2> $OUT/$C.err )
 done
 python tools/pmc_traffic.py "$(finddb $OUT/FETCH_SIZE)" "$(finddb $OUT/WRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json > /dev/null
+# the Kalman-scan ROOFLINE launch (S=256 x T=64, the shape bench.py's roofline_kalman times) in its own PMC passes
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/k$C -- python $R/tools/kalman_roofline.py > $OUT/${TAG}_kalman_roofline_under_pmc_$C.json 2> $OUT/k$C.err )
+done
+python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json \
+    --only kalman_scan_kernel --suffix '@S=256,T=64' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
+python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json \
+    --only kalman_fuse_kernel --suffix '@P=78643200' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/pmc_traffic.json   # the bench line below quotes these numbers
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/sq$i -- python $R/bench.py $SHORT > /dev/null 2> $OUT/sq$i.err )
 done
 python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)"
-# the second un-profiled bench line picks up the fresh traffic numbers if they were copied in place
-rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
+# the un-profiled bench line (quotes the fresh PMC traffic copied to profiles/pmc_traffic.json above)
+python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
+rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
 ls -la $OUT
