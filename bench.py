@@ -449,9 +449,15 @@ def bench_c5(args, device):
         eng32 = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * 4,
                             device=str(device))
         r32 = eng32.process_sequences(dev[:, :4].contiguous()).cpu().numpy()
+        dc = np.abs(rec16[..., :3] - r32[..., :3])
+        dr = np.abs(rec16[..., 3] - r32[..., 3]) / np.abs(r32[..., 3])
         out['parity_vs_fp32_path'] = {
-            'frames': int(S * 4), 'coord_max_abs': float(np.abs(rec16[..., :3] - r32[..., :3]).max()),
-            'conf_max_rel': float((np.abs(rec16[..., 3] - r32[..., 3]) / np.abs(r32[..., 3])).max())}
+            'frames': int(S * 4), 'coord_max_abs': float(dc.max()), 'conf_max_rel': float(dr.max()),
+            'coord_abs_p999': float(np.quantile(dc, 0.999)), 'conf_rel_p999': float(np.quantile(dr, 0.999)),
+            'pixels_outside_tolerance': float(np.mean((dc.max(-1) > 2e-2) | (dr > 5e-2))),
+            'note': 'max is dominated by isolated pixels whose warped sample lands on the clamped-weight border of '
+                    'tools/util.py:36-93 (a 1e-3 change of the flow toggles the sample between the neighbour value '
+                    'and 0); p999 = 99.9th percentile over all pixels'}
     print(json.dumps(out))
 
 
