@@ -134,11 +134,18 @@ int kfn_winograd_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tile
 int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* u_packed,
                         const float* bias, float* y, float* workspace, int phases, void* stream);
 
-/* Single-kernel variant of the above: one workgroup computes all 16 (xi,nu) GEMMs of its
- * 64-tile x 64-channel block and applies A^T M A in registers -- no workspace, every source
- * pixel fetched once per workgroup.  Same arguments/result as kfn_conv2d_winograd
- * (Cin % 8 == 0; fp32 only). */
-int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const float* u_packed,
+/* Single-kernel variant of the above (csrc/kfn_wino2.hip): one wavefront = one workgroup owns a
+ * block of 8x4 Winograd tiles x 32 output channels x all 16 (xi,nu) positions (16 accumulators
+ * of 32x32 in registers), evaluates B^T d B on raw input patches staged once through LDS and
+ * A^T M A in registers -- no workspace, no second kernel, every input pixel fetched once per
+ * workgroup.  Same result as kfn_conv2d_winograd up to fp32 summation order.
+ * u2_packed = [Cin/8][16][cout_pad][8]: the (G g G^T)[xi][nu] of kfn_conv2d_winograd, re-packed so
+ * that the 32-channel fragment of one (8-channel k-chunk, position) is one contiguous 1 KiB read:
+ *   u2[((ci/8)*16 + 4*xi+nu)*cout_pad + co][ci%8].
+ * Needs Cin % 16 == 0, (H+1)/2 >= 4, cout_pad % 32 == 0, fp32, no fused head epilogue
+ * (kfn_winograd_fused_supported() == 1); KFN_ERR_UNSUPPORTED otherwise. */
+int kfn_winograd_fused_supported(const kfn_conv_desc* desc);
+int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const float* u2_packed,
                               const float* bias, float* y, void* stream);
 
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------

@@ -60,6 +60,7 @@ SYMBOLS = {
     'kfn_winograd_workspace_bytes': (_i, [C.POINTER(ConvDesc), C.POINTER(_sz)]),
     'kfn_conv2d_winograd': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_conv2d_winograd_fused': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    'kfn_winograd_fused_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'kfn_cost_volume_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -12,9 +12,9 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, as_f16, as_f16x3,
-                     pack_bias,
-                     pack_conv_kernel, pack_deconv_kernel, pack_first_kernel, pack_winograd_kernel)
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp, as_f16,
+                     as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
+                     pack_winograd_fused_kernel, pack_winograd_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -155,7 +155,7 @@ class Network(object):
         if len(hits) != 1:
             raise KeyError('set_epilogue: %d convolution launches are named %r' % (len(hits), layer_name))
         op = hits[0]
-        if isinstance(op, WinogradConvOp):
+        if isinstance(op, (WinogradConvOp, WinogradFusedConvOp)):
             if op.kernel.storage is not None:
                 raise RuntimeError('set_epilogue(%r): weights are already packed for the Winograd kernel' % layer_name)
             # in place (the op object may already sit in other launch lists): same tensors and
@@ -209,6 +209,16 @@ class Network(object):
         if g.conv_operands == 'f16x3' and cin % 32 == 0 and cin >= g.f16x3_min_channels:
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16x3(pack_conv_kernel))
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16X3))
+            return y
+        fmin = g.winograd_fused_min_channels
+        # (measured, 17-frame batch: the single-kernel form wins for Cin <= 512 -- conv1b 2.2 vs 3.3 ms direct,
+        #  conv2b 5.9 vs 7.0, conv3b 5.6 vs 5.9, conv6 0.70 vs 0.76 -- and ties at Cin = 1024, where the
+        #  two-kernel form's 128x256 tiles re-use the 64 MB of transformed weights better)
+        if (k == 3 and strides == 1 and g.winograd_fused and fmin and cin >= fmin and filters >= fmin
+                and cin <= g.winograd_fused_max_channels
+                and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters)):
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_fused_kernel)
+            self._emit(WinogradFusedConvOp(name, input, y, kern, bias, relu))
             return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):

@@ -229,6 +229,16 @@ def pack_winograd_kernel(w):
     return out
 
 
+def pack_winograd_fused_kernel(w):
+    """TF HWIO [3,3,Cin,Cout] -> U2 [Cin/8][16][cout_pad][8] for kfn_conv2d_winograd_fused: the same
+    (G g G^T)[xi][nu] as pack_winograd_kernel, laid out so that the 32-channel fragment of one
+    (8-channel k-chunk, position 4*xi+nu) is one contiguous 1 KiB run."""
+    u = pack_winograd_kernel(w)                       # [16][cout_pad][Cin]
+    g, cp, ci = u.shape
+    assert ci % 8 == 0
+    return np.ascontiguousarray(u.reshape(g, cp, ci // 8, 8).transpose(2, 0, 1, 3))
+
+
 def as_f16(pack):
     """Wrap a weight packer so that the packed matrix is stored as IEEE halfs (fp16-operand convs)."""
     def f(w):
@@ -348,16 +358,40 @@ class WinogradConvOp(ConvOp):
 
     def launch(self, lib, stream, phases=3):
         d = self.desc()
-        if self.x.graph.winograd_fused:
-            if phases & 1:
-                rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
-                                                   self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
-                _lib.check(rc, 'kfn_conv2d_winograd_fused[%s]' % self.name)
-            return
         rc = lib.kfn_conv2d_winograd(C.byref(d), self.x.ptr, self.kernel.ptr,
                                      self.bias.ptr if self.bias is not None else None, self.y.ptr,
                                      self.workspace.ptr, phases, stream)
         _lib.check(rc, 'kfn_conv2d_winograd[%s]' % self.name)
+
+
+class WinogradFusedConvOp(ConvOp):
+    """3x3 stride-1 SAME conv through kfn_conv2d_winograd_fused: all 16 Winograd positions of a tile
+    block in one wavefront, input and output transforms in registers -- one launch, no workspace."""
+
+    def __init__(self, name, x, y, kernel, bias, relu):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+
+    @staticmethod
+    def supported(x_shape, cin, cout):
+        n, h, w, _ = x_shape
+        return cin % 16 == 0 and (h + 1) // 2 >= 4
+
+    def kernel_name(self, lib):
+        return 'wino2_kernel'
+
+    def mfma_flops(self):
+        """FLOPs the MFMAs execute: 16 positions x (tile blocks padded to 8x4 tiles, batch rows packed)."""
+        n, ho, wo, cout = self.y.shape
+        n = _scaled(n, self.x.graph)
+        th, tw = (ho + 1) // 2, (wo + 1) // 2
+        tiles = (-(-tw // 8) * 8) * (-(-(n * th) // 4) * 4)
+        return 2.0 * 16 * tiles * (-(-cout // 32) * 32) * self.x.shape[3]
+
+    def launch(self, lib, stream, phases=3):
+        d = self.desc()
+        rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                           self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        _lib.check(rc, 'kfn_conv2d_winograd_fused[%s]' % self.name)
 
 
 class FirstConvOp(Op):
@@ -660,7 +694,12 @@ class Graph(object):
         # the 2.25x MFMA saving.
         self.winograd_min_channels = 128
         self.winograd_ws = None
-        self.winograd_fused = False  # single-kernel Winograd (all 16 groups per workgroup, no workspace)
+        # single-kernel Winograd (kfn_conv2d_winograd_fused: no workspace, no output-transform launch)
+        # for 3x3 stride-1 layers with at least winograd_fused_min_channels in/out channels; layers it
+        # cannot take (Cin % 16, fewer than 4 tile rows) fall back to the two-kernel form above
+        self.winograd_fused = True
+        self.winograd_fused_min_channels = 64
+        self.winograd_fused_max_channels = 512
         # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
         # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
         self.factor_cost_volume = True

@@ -465,14 +465,24 @@ def test_conv_f16x3_split_operands(case, config):
     assert err <= 4 * _conv_tol(x, wt)
 
 
-@pytest.mark.parametrize('case', WINO_CASES + [(2, 30, 40, 64, 96), (1, 9, 70, 8, 32)])
-def test_winograd_fused_vs_oracle(case):
-    """kfn_conv2d_winograd_fused (all 16 groups in one workgroup, inverse transform in
-    registers, no workspace) == oracle."""
+# (N, H, W, Cin, Cout): multiples of the 8x4 tile block and ragged ones, blocks that straddle two
+# images of the batch (Th % 4 != 0), a single image shorter than the batch packing, odd sizes where
+# the last 2x2 tile overhangs, Cout not a multiple of 32, wide K
+FUSED_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (3, 12, 16, 64, 36),
+               (2, 10, 6, 48, 64), (2, 30, 40, 64, 96), (5, 60, 80, 32, 32), (3, 9, 70, 16, 32),
+               (4, 14, 33, 32, 40), (1, 64, 96, 64, 64), (17, 10, 12, 16, 8), (2, 16, 30, 1024, 32)]
+
+
+@pytest.mark.parametrize('relu', [1, 0])
+@pytest.mark.parametrize('case', FUSED_CASES)
+def test_winograd_fused_vs_oracle(case, relu):
+    """kfn_conv2d_winograd_fused (one wavefront = 8x4 tiles x 32 channels x all 16 positions, both
+    transforms in registers, no workspace) == oracle up to fp32 round-off; strided output window,
+    guard rows behind the tensor untouched."""
     import torch
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib
-    from kfnet_amd.graph import pack_winograd_kernel
+    from kfnet_amd.graph import pack_winograd_fused_kernel
     lib = _lib.load()
     n, h, w, ci, co = case
     rng = np.random.default_rng(n * 1000 + h * 10 + ci + 5)
@@ -481,17 +491,49 @@ def test_winograd_fused_vs_oracle(case):
     b = rng.normal(size=co).astype(np.float32)
     ldy = co + 8
     d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
-                      stride=1, relu=1)
-    y = torch.full((n * h * w, ldy), -5.0, device='cuda')
-    dx, du, db = dev(x), dev(pack_winograd_kernel(wt)), dev(b)
+                      stride=1, relu=relu)
+    assert lib.kfn_winograd_fused_supported(C.byref(d)) == 1
+    GUARD = 64
+    y = torch.full((n * h * w + GUARD, ldy), -5.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_fused_kernel(wt)), dev(b)
     _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
-                                             stream()), 'wino16')
+                                             stream()), 'wino2')
     sync()
     got = y.cpu().numpy()
-    assert np.all(got[:, co:] == -5.0)
-    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
-    err = np.abs(got[:, :co].reshape(ref.shape) - ref).max()
+    assert np.all(got[:, co:] == -5.0) and np.all(got[n * h * w:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, bool(relu))
+    err = np.abs(got[:n * h * w, :co].reshape(ref.shape) - ref).max()
     assert err <= 3 * _conv_tol(x, wt), err
+
+
+def test_winograd_fused_strided_input_and_unsupported_shapes():
+    """Input living in a wider buffer (ldx > Cin, the concat case) and the shapes the single-kernel path
+    declines (Cin % 16, fewer than 4 tile rows): the host must be told, not handed wrong numbers."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_fused_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    n, h, w, ci, co, ldx, off = 2, 12, 20, 32, 64, 48, 8
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    xb = np.full((n * h * w, ldx), 9.0, np.float32)
+    xb[:, off:off + ci] = x.reshape(-1, ci)
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=64, ldy=co, kh=3, kw=3, stride=1, relu=0)
+    y = torch.zeros((n * h * w, co), device='cuda')
+    dx, du = dev(xb), dev(pack_winograd_fused_kernel(wt))
+    _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr() + 4 * off, du.data_ptr(), None, y.data_ptr(),
+                                             stream()), 'wino2')
+    sync()
+    ref = O.conv2d_same(x.astype(np.float64), wt, None, 1, False)
+    assert np.abs(y.cpu().numpy().reshape(ref.shape) - ref).max() <= 3 * _conv_tol(x, wt)
+    for bad in (dict(Cin=8, ldx=8), dict(H=5), dict(Cin=24, ldx=24)):
+        kw = dict(N=1, H=16, W=16, Cin=32, ldx=32, Cout=32, cout_pad=32, ldy=32, kh=3, kw=3, stride=1)
+        kw.update(bad)
+        db = _lib.ConvDesc(**kw)
+        assert lib.kfn_winograd_fused_supported(C.byref(db)) == 0
+        assert lib.kfn_conv2d_winograd_fused(C.byref(db), dx.data_ptr(), du.data_ptr(), None, y.data_ptr(), stream()) == -3
 
 
 @pytest.mark.parametrize('shape', [(2, 7, 9, 32, 32), (1, 60, 80, 32, 32), (3, 5, 4, 16, 48), (2, 3, 2, 32, 32)])
