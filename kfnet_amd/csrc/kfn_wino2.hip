@@ -27,6 +27,7 @@
 // slotted behind the MFMAs of the current chunk.
 #include "kfn_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -68,6 +69,7 @@ struct Wino2Args {
   int bw;             // ceil(Tw / BW) column blocks
   int tiles_m, tiles_n;
   int relu;
+  int dbg;            // timing experiments only (KFN_WINO2_DBG): 1 = every A row read from row 0, 2 = every B fragment = fragment 0
   unsigned long long x_bytes;
   unsigned long long y_bytes;
   unsigned u_bytes;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
     const int sc = s < n_stages ? s : n_stages - 1;
     if constexpr (k < NMAIN) {
       const bool ok = (rowmask >> k) & 1u;
-      const int soff = (k < first_rows ? base_first : base_second) + k * row_stride + sc * (KS * 4);
+      const int soff = (p.dbg & 1) ? sc * (KS * 4) : (k < first_rows ? base_first : base_second) + k * row_stride + sc * (KS * 4);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a_ptr, 0, ok ? a_records : 0, 0x00020000);
       ra[k % NHALF] = bload(rs, voff_main, ok ? (unsigned)soff : 0u);
     } else {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
   auto b_load = [&](auto gc, int qidx) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
     const int qc = qidx < q_last ? qidx : q_last;     // past the end: re-read the last slice (never used)
-    bq[g % NB] = bload(rsU, voff_b, (unsigned)qc * b_step);
+    bq[g % NB] = bload(rsU, voff_b, (p.dbg & 2) ? 0u : (unsigned)qc * b_step);
   };
   // patch read (r, c) of chunk `chunk` from buffer `buf` into v[4*r + c]
   auto v_read = [&](auto ic, f32x2 (&v)[32], auto buf_c, auto chunk_c) __attribute__((always_inline)) {
@@ -451,6 +453,10 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
+  {
+    static const int dbg = getenv("KFN_WINO2_DBG") ? atoi(getenv("KFN_WINO2_DBG")) : 0;
+    a.dbg = dbg;
+  }
   a.x_bytes = (unsigned long long)x_bytes;
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)u_bytes;
