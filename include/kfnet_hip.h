@@ -234,6 +234,34 @@ int kfn_kalman_scan(const kfn_kalman_desc* desc,
                     float* opt_nis,           /* [S,T,H*W,3] or NULL */
                     void* stream);
 
+/* The same scan with the extra debug outputs eval.py's log line is computed from:
+ *   opt_kf [S,T,H*W,4]  the raw KF estimate (x, sigma) of every frame BEFORE the NIS gate, the reset
+ *                        override and ApplyTransform (what KF_loss / KF_accuracy see, KFNet/train.py:256-257);
+ *   raw_on_reset != 0   on a reset step opt_temp / opt_nis / opt_kf hold what the GRAPH computes there from
+ *                        the incoming state (KFNet/eval.py:78-83 runs before the host override of :94-101);
+ *                        with 0 they hold (z, 0, z) as kfn_kalman_scan writes them.
+ * State, records and the NIS gate are unaffected.  kfn_kalman_scan == kfn_kalman_scan_ex(.., NULL, 0, ..). */
+int kfn_kalman_scan_ex(const kfn_kalman_desc* desc, const float* flow_xy, const float* sigma_trans,
+                       const float* meas, float* state, float* records, float* opt_temp, float* opt_nis,
+                       float* opt_kf, int raw_on_reset, void* stream);
+
+/* ---- evaluation numbers of eval.py, reduced on the device --------------------------------
+ * KFNet.CoordLossWithUncertainty(downsample=True) x3 (KFNet/KFNet.py:192-232 via KFNet/train.py:252-257),
+ * the NIS band count (KFNet/eval.py:10-15) and the distance maps of dist_error (eval.py:17-29) for T
+ * frames, one workgroup per frame.  Inputs are the scan's buffers [T,H*W,.] (meas, temp, kf_raw, records,
+ * nis as written with raw_on_reset = 1) and `labels` [L,H*W,4] = (gt xyz, mask) already nearest-down-sampled
+ * (tf.image.resize_nearest_neighbor: source pixel (8y, 8x)); label_pair [T,2] = label rows of the step's
+ * frame pair (KFNet/train.py:67-71: the losses see BOTH, the distances the second); reset_flags [T].
+ * stats [T,16]: [0..2] masked loss sums (measure, temporal, KF), [3..5] "inaccurate" pixel counts,
+ * [6] valid_pixel = sum(mask_a) + sum(mask_b) + 1, [7] NIS values > 0, [8] of those inside (0.0157, 2.706);
+ * loss = stats[k]/stats[6], accuracy = (stats[6] - stats[3+k])/stats[6].  dist_maps [T,3,H*W] in cm
+ * (0 where masked); the host takes the medians of the positive entries. */
+int kfn_eval_metrics(const float* meas, const float* temp, const float* kf_raw, const float* records,
+                     const float* nis, const float* labels, const int32_t* label_pair,
+                     const uint8_t* reset_flags, const float* transform12 /* 3x4 row-major or NULL */,
+                     int T, int HW, float dist_threshold /* 0.05 */, float min_uncertainty /* 1e-5 */,
+                     float* stats, float* dist_maps, void* stream);
+
 /* KFNet.BuildKFCoord on its own (KFNet/KFNet.py:148-162) + optional KFNet.GetNIS
  * (:164-184): pred = (x^-, sigma^-), meas = (z, sigma_z), out = (x, sigma), all [P,4];
  * opt_nis [P,3] or NULL.  48 B/pixel of HBM traffic (32 read + 16 written). */

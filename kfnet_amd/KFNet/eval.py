@@ -31,6 +31,9 @@ from ..tools.io import get_snapshot, read_lines
 from ..weights import load_npz, synthetic_weights
 
 SCENES = ('chess', 'fire', 'heads', 'office', 'pumpkin', 'redkitchen', 'stairs')
+# first frames of the test sequences per scene (get_indexes(False), KFNet/train.py:82-141)
+M_TEST_SEQUENCE_LENGTH = {'chess': 1000, 'fire': 1000, 'heads': 1000, 'office': 1000, 'pumpkin': 1000,
+                          'redkitchen': 1000, 'stairs': 500}
 
 
 def get_transform(transform_file=None):
@@ -86,7 +89,7 @@ def eval_sharded(image_paths, transform, weights, output_folder, rank, world, li
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None,
-         decode_workers=8, device=None):
+         decode_workers=8, device=None, metrics_sequence_length=1000):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
@@ -101,11 +104,8 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         device = 'cuda:%d' % torch.cuda.current_device()
     eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
                       reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk,
-                      emit_debug=want_metrics, device=device)
+                      emit_metrics=want_metrics, device=device)
     records, all_metrics = [], []
-
-    def label(i):
-        return labels[i] if labels is not None else M.read_label(label_paths[i], image_size)
 
     def emit(lo, rec):
         records.append(rec)
@@ -113,34 +113,42 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
             for k in range(rec.shape[0]):
                 np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
 
-    # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239)
+    # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239);
+    # uploads / compute / downloads overlapped on three streams -- with or without labels
     loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
                          workers=decode_workers)
+    dm = M.DeviceMetrics(eng) if want_metrics else None
+    plan = {}     # chunk index -> (first, n, global pairs)
+
+    def label_grid(i):
+        if labels is not None:
+            return M.resize_nearest(labels[i], (eng.h, eng.w))
+        return M.read_label_grid(label_paths[i], image_size, (eng.h, eng.w))
+
+    def after_process(k, lo, n):
+        """Right behind the scan of chunk k: label grids of the frames its pairs refer to -> device,
+        kfn_eval_metrics, results -> pinned host slot k & 1."""
+        pairs = M.pair_schedule(lo, n, T, metrics_sequence_length)
+        base, top = max(min(int(pairs.min()), lo), 0), min(max(int(pairs.max()), lo + n - 1) + 1, T)
+        rows = np.stack([label_grid(i) for i in range(base, top)])
+        dm.launch(k & 1, lo, n, rows, np.clip(pairs, base, top - 1) - base)
+        plan[k] = (lo, n, pairs)
+
+    k = 0
+    for lo, rec in StreamedSequence(eng, chunk).run(loader, after_process=after_process if want_metrics else None):
+        emit(lo, rec.copy())
+        if want_metrics:
+            first, n, pairs = plan.pop(k)
+            for m in dm.collect(k & 1, first, n, pairs):
+                all_metrics.append(m)
+                if verbose:
+                    print(M.format_line(m))
+        elif verbose:
+            print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
+        k += 1
+    records = np.concatenate(records) if records else np.zeros((0, eng.h, eng.w, 4), np.float32)
     if not want_metrics:
-        # uploads / compute / downloads overlapped on three streams
-        for lo, rec in StreamedSequence(eng, chunk).run(loader):
-            emit(lo, rec.copy())
-            if verbose:
-                print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
-        return np.concatenate(records) if records else np.zeros((0, eng.h, eng.w, 4), np.float32)
-    # with labels: per-frame metrics need the intermediate maps of every chunk on the host
-    for lo, host in loader:
-        hi = lo + int(host.shape[0])
-        dev = eng.upload_frames(host.numpy())
-        rec = eng.process(dev, t0=lo).cpu().numpy()   # state and feature ring carry over
-        emit(lo, rec)
-        dbg = eng.debug(hi - lo)
-        for k in range(hi - lo):
-            i = lo + k
-            # pair schedule of KFNet/train.py:67-71: step 0 = (1, 0), step i = (i-1, i)
-            pair = (1, 0) if i == 0 else (i - 1, i)
-            reset = sequence_length > 0 and i % sequence_length == 0
-            m = M.frame_metrics(i, pair, dbg['meas'][k], dbg['temp'][k], rec[k], dbg['nis'][k],
-                                (label(min(pair[0], T - 1)), label(pair[1])), transform, reset, (eng.h, eng.w))
-            all_metrics.append(m)
-            if verbose:
-                print(M.format_line(m))
-    records = np.concatenate(records)
+        return records
     if verbose and all_metrics:
         for name, fn in (('Median dist error: ', np.median), ('Mean dist error: ', np.mean), ('stddev error: ', np.std)):
             print(name, fn([m['d_m'] for m in all_metrics]), fn([m['d_t'] for m in all_metrics]),
@@ -199,7 +207,8 @@ def main(argv=None):
     if label_paths is not None:
         assert len(image_paths) == len(label_paths)   # KFNet/eval.py:37
     eval(image_paths, get_transform(transform_file), W, a.output_folder, a.NIS, image_size=size, batch=a.batch,
-         label_paths=label_paths, device=device)
+         label_paths=label_paths, device=device,
+         metrics_sequence_length=M_TEST_SEQUENCE_LENGTH.get(a.scene, 1000))
     return 0
 
 

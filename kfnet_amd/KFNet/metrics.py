@@ -1,24 +1,41 @@
-"""Per-frame evaluation metrics of KFNet/eval.py.
+"""Per-frame evaluation numbers of KFNet/eval.py, reduced on the device.
 
-These are not on the GPU hot path: the reference itself evaluates `dist_error` and the NIS
-band on the host with Python lists (KFNet/eval.py:10-29) and the three
-`CoordLossWithUncertainty` reductions are 4800-element sums.  They are evaluated here with
-numpy on the [60,80] maps the engine already returns.
+eval.py prints for every step `l_m, l_t, l_kf, a_m, a_t, a_kf` (three CoordLossWithUncertainty results,
+KFNet/KFNet.py:192-232 via KFNet/train.py:252-257), `d_m, d_t, d_kf` (median distance errors in cm,
+KFNet/eval.py:17-29) and `nis` (share of NIS values inside (0.0157, 2.706), eval.py:10-15).  Everything that
+is a sum or a count over the label grid is reduced by kfn_eval_metrics (one workgroup per frame) from the
+buffers the Kalman scan wrote -- nothing but [T,16] numbers and the [T,3,h,w] distance maps crosses PCIe;
+the host takes the medians (as the reference does, np.median over the positive entries) and formats the
+line.  The host side here reads labels and builds the step schedule:
 
-Quirks reproduced on purpose:
-  * `loss_map = tf.minimum(loss_map, -2.0)` (KFNet/KFNet.py:216): the per-pixel NLL is
-    capped from ABOVE at -2;
-  * in eval.py the ground truth fed to the losses is the PAIR batch [2,h,w,3] while the
-    prediction is [1,h,w,3], so both frames of the pair are compared with the same
-    prediction (broadcast) and `valid_pixel` sums both masks (+1);
-  * `dist_error` and the log line use the second frame of the pair only.
+  * labels are raw float32 [H,W,4] dumps (3 scene coordinates + validity mask, KFNet/train.py:219-222),
+    nearest-down-sampled like tf.image.resize_nearest_neighbor: source pixel (8y, 8x) --
+    done while READING (a strided view of the file), so 76.8 KB per frame are uploaded, not 4.9 MB;
+  * the frame pair of step i is (i-1, i), and (s+1, s) at the first frame s of every test sequence of the
+    scene (KFNet/train.py:67-71, :82-141): the losses compare the prediction with BOTH labels of the pair
+    (the [2,h,w,.] ground-truth batch broadcasts against the [1,h,w,.] prediction), the distance errors
+    use the second one.
+
+Known deviation: at a later sequence start the reference also feeds the IMAGE pair reversed, which changes
+the (discarded, because the step is a reset) prediction its l_t / l_kf / nis are computed from; here the
+prediction of that step comes from the forward pair.  The coord_<i>.npy outputs are unaffected.
 """
+import ctypes as C
+
 import numpy as np
+
+from .. import _lib
+
+FORMAT = ("%d, frame %d~%d, l_m = %.3f, l_t = %.3f, l_kf = %.3f, a_m = %.3f, a_t = %.3f, a_kf = %.3f, "
+          "d_m = %.3f, d_t = %.3f, d_kf = %.3f, nis = %.3f")   # KFNet/eval.py:113-118
+
+# first frames of the test sequences per scene (get_indexes(is_training=False), KFNet/train.py:82-141)
+TEST_SEQUENCE_LENGTH = {'chess': 1000, 'fire': 1000, 'heads': 1000, 'office': 1000, 'pumpkin': 1000,
+                        'redkitchen': 1000, 'stairs': 500}
 
 
 def read_label(path, image_size=(480, 640)):
-    """tf.decode_raw(float32) + reshape [H,W,4] (KFNet/train.py:219-222): 3 scene
-    coordinates + 1 validity mask per full-resolution pixel."""
+    """tf.decode_raw(float32) + reshape [H,W,4] (KFNet/train.py:219-222)."""
     H, W = image_size
     a = np.fromfile(path, dtype=np.float32)
     if a.size != H * W * 4:
@@ -26,84 +43,113 @@ def read_label(path, image_size=(480, 640)):
     return a.reshape(H, W, 4)
 
 
-def resize_nearest(x, out_hw):
-    """tf.image.resize_nearest_neighbor(align_corners=False): src = floor(dst*in/out)
-     -> picks pixel (8y, 8x) for 480x640 -> 60x80."""
-    H, W = x.shape[-3], x.shape[-2]
-    h, w = out_hw
+def nearest_rows_cols(image_size, grid_hw):
+    """Source rows / columns of tf.image.resize_nearest_neighbor(align_corners=False):
+    src = min(floor(dst * in / out), in - 1)."""
+    H, W = image_size
+    h, w = grid_hw
     ys = np.minimum((np.arange(h) * (H / float(h))).astype(np.int64), H - 1)
     xs = np.minimum((np.arange(w) * (W / float(w))).astype(np.int64), W - 1)
+    return ys, xs
+
+
+def resize_nearest(x, out_hw):
+    ys, xs = nearest_rows_cols(x.shape[-3:-1], out_hw)
     return x[..., ys[:, None], xs[None, :], :]
 
 
-def coord_loss_with_uncertainty(pred_coord, uncertainty, gt_coords, mask, dist_threshold=0.05,
-                                min_uncertainty=1e-5):
-    """KFNet.CoordLossWithUncertainty (KFNet/KFNet.py:192-232) on already transformed,
-    already down-sampled inputs.  pred_coord [1,h,w,3], uncertainty [1,h,w,1], gt_coords
-    [B,h,w,3], mask [B,h,w,1] (B = 2 in eval.py).  Returns (loss, accuracy)."""
-    pred = np.asarray(pred_coord, np.float32)
-    unc = np.maximum(np.asarray(uncertainty, np.float32), np.float32(min_uncertainty))
-    gt = np.asarray(gt_coords, np.float32)
-    m = (np.asarray(mask, np.float32) == 1.0).astype(np.float32)
-    diff = np.sum(np.square(pred - gt), axis=-1, keepdims=True)
-    loss_map = 3.0 * np.log(unc) + diff / (2.0 * np.square(unc))
-    loss_map = np.minimum(loss_map, np.float32(-2.0))
-    valid_pixel = m.sum() + 1.0
-    diff = m * diff
-    loss_map = m * loss_map
-    loss = loss_map.sum() / valid_pixel
-    thres = np.maximum(diff - dist_threshold * dist_threshold, 0)
-    num_accurate = valid_pixel - np.count_nonzero(thres)
-    return float(loss), float(num_accurate / valid_pixel)
+def read_label_grid(path, image_size, grid_hw):
+    """The [h,w,4] nearest-down-sampled label of one frame, read through a memory map so that only
+    the pixels that are kept are touched."""
+    H, W = image_size
+    m = np.memmap(path, dtype=np.float32, mode='r')
+    if m.size != H * W * 4:
+        raise ValueError('%s holds %d floats, expected %d' % (path, m.size, H * W * 4))
+    ys, xs = nearest_rows_cols(image_size, grid_hw)
+    return np.ascontiguousarray(m.reshape(H, W, 4)[ys[:, None], xs[None, :], :])
 
 
-def get_NIS_measurement(out_NIS):
-    """KFNet/eval.py:10-15: fraction of positive NIS values inside (0.0157, 2.706)."""
-    a = np.asarray(out_NIS).reshape(-1)
-    a = a[a > 0.0]
-    if a.size == 0:
-        return 0.0
-    return float(np.count_nonzero((a > 0.0157) & (a < 2.706))) / float(a.size)
+def pair_schedule(first, count, total, sequence_length):
+    """Frame pairs (a, b) of steps first .. first+count-1 (KFNet/train.py:67-71): (s+1, s) at a sequence
+    start s, (i-1, i) otherwise; indices are clamped to the list like tf.gather would fail to be."""
+    out = np.empty((count, 2), dtype=np.int64)
+    for k in range(count):
+        i = first + k
+        if sequence_length > 0 and i % sequence_length == 0:
+            out[k] = (min(i + 1, total - 1), i)
+        else:
+            out[k] = (i - 1, i)
+    return out
 
 
-def dist_error(coords, gt_coords, mask):
-    """KFNet/eval.py:17-29: median Euclidean error in cm over valid pixels, and the map."""
-    d = np.sqrt(np.sum(np.square(coords - gt_coords), axis=-1)) * mask[:, :, 0]
-    pos = d[d > 0]
-    med = float(np.median(pos)) * 100.0 if pos.size else float('nan')
-    return med, d * 100
+def dist_median(dmap):
+    """np.median over the positive entries of a distance map in cm (KFNet/eval.py:27-29)."""
+    pos = dmap[dmap > 0]
+    return float(np.median(pos)) if pos.size else float('nan')
 
 
-def apply_transform(coords, T):
-    """KFNet/util.py:12-40 on host: x' = (T [x;1])[0:3]."""
-    T = np.asarray(T, np.float32)
-    return coords @ T[:3, :3].T + T[:3, 3]
+class DeviceMetrics(object):
+    """kfn_eval_metrics on the buffers of a KFNetEngine built with emit_metrics=True."""
 
+    def __init__(self, eng, dist_threshold=0.05):
+        if not getattr(eng, 'emit_metrics', False):
+            raise ValueError('the engine must be built with emit_metrics=True')
+        torch = eng.torch
+        self.eng, self.torch = eng, torch
+        self.dist_threshold = float(dist_threshold)
+        T = eng.max_chunk
+        dev = eng.device
+        # two result slots: the reduction of chunk k+1 is enqueued before chunk k's numbers are consumed
+        self.stats = [torch.zeros((T, 16), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.dist = [torch.zeros((T, 3, eng.h, eng.w), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.h_stats = [torch.zeros((T, 16), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.h_dist = [torch.zeros((T, 3, eng.h, eng.w), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.done = [None, None]
+        self.labels = torch.zeros((T + 2, eng.h, eng.w, 4), dtype=torch.float32, device=dev)
+        self.pairs = torch.zeros((T, 2), dtype=torch.int32, device=dev)
+        self.resets = torch.zeros((T,), dtype=torch.uint8, device=dev)
+        tr = eng.transform
+        self.t12 = None if tr is None else (C.c_float * 12)(*[float(v) for v in np.asarray(tr, np.float32)[:3, :4].reshape(-1)])
 
-FORMAT = ("%d, frame %d~%d, l_m = %.3f, l_t = %.3f, l_kf = %.3f, a_m = %.3f, a_t = %.3f, a_kf = %.3f, "
-          "d_m = %.3f, d_t = %.3f, d_kf = %.3f, nis = %.3f")   # KFNet/eval.py:113-118
+    def launch(self, slot, first, count, label_rows, pairs):
+        """Enqueue (on the engine's stream, right behind the scan) the reduction for the `count` frames just
+        scanned (global indices first..) and the download of its results into pinned host slot `slot`.
+        label_rows [L,h,w,4] host float32 = the label grids this chunk refers to, pairs [count,2] = rows of it."""
+        eng, torch = self.eng, self.torch
+        L = int(label_rows.shape[0])
+        if L > self.labels.shape[0] or count > self.stats[0].shape[0]:
+            raise ValueError('chunk larger than the metric buffers')
+        self.labels[:L].copy_(torch.from_numpy(np.ascontiguousarray(label_rows, dtype=np.float32)))
+        self.pairs[:count].copy_(torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32)))
+        rp = eng.reset_period
+        flags = np.array([1 if (rp > 0 and (first + k) % rp == 0) else 0 for k in range(count)], dtype=np.uint8)
+        self.resets[:count].copy_(torch.from_numpy(flags))
+        rc = eng.lib.kfn_eval_metrics(eng.c_meas.ptr, eng.c_temp.ptr, eng.c_kf.ptr, eng.c_rec.ptr, eng.c_nis.ptr,
+                                      self.labels.data_ptr(), self.pairs.data_ptr(), self.resets.data_ptr(), self.t12,
+                                      int(count), int(eng.hw), self.dist_threshold, float(eng.net.min_uncertainty),
+                                      self.stats[slot].data_ptr(), self.dist[slot].data_ptr(), eng._stream())
+        _lib.check(rc, 'kfn_eval_metrics')
+        self.h_stats[slot][:count].copy_(self.stats[slot][:count], non_blocking=True)
+        self.h_dist[slot][:count].copy_(self.dist[slot][:count], non_blocking=True)
+        self.done[slot] = torch.cuda.Event()
+        self.done[slot].record(torch.cuda.current_stream(eng.device))
 
-
-def frame_metrics(i, pair, meas, temp, rec, nis, labels_pair, transform, reset, grid_hw):
-    """All fields of one eval.py log line.  meas/temp [h,w,4] raw (coord, sigma); rec [h,w,4] =
-    (T.x_KF, 1/sigma_KF) as emitted; nis [h,w,3]; labels_pair = (label[a], label[b]) full-res
-    [H,W,4]; reset = this step re-initialised the filter (eval.py:94-101)."""
-    T = transform
-    gt = np.stack([resize_nearest(l, grid_hw) for l in labels_pair])        # [2,h,w,4]
-    gt_c, gt_m = gt[..., :3], gt[..., 3:4]
-    t_meas = apply_transform(meas[None, ..., :3], T)
-    t_temp = apply_transform(temp[None, ..., :3], T)
-    kf_c, kf_s = rec[None, ..., :3], 1.0 / rec[None, ..., 3:4]
-    l_m, a_m = coord_loss_with_uncertainty(t_meas, meas[None, ..., 3:4], gt_c, gt_m)
-    l_t, a_t = coord_loss_with_uncertainty(t_temp, temp[None, ..., 3:4], gt_c, gt_m)
-    l_kf, a_kf = coord_loss_with_uncertainty(kf_c, kf_s, gt_c, gt_m)
-    if reset:   # eval.py:98-101 overrides the temp/KF outputs by the measurement for dist_error
-        t_temp = t_meas
-    d_m, _ = dist_error(t_meas[0], gt_c[-1], gt_m[-1])
-    d_t, _ = dist_error(t_temp[0], gt_c[-1], gt_m[-1])
-    d_kf, _ = dist_error(kf_c[0], gt_c[-1], gt_m[-1])
-    return dict(i=i, pair=pair, l_m=l_m, l_t=l_t, l_kf=l_kf, a_m=a_m, a_t=a_t, a_kf=a_kf, d_m=d_m, d_t=d_t,
-                d_kf=d_kf, nis=get_NIS_measurement(nis))
+    def collect(self, slot, first, count, pairs_global):
+        """Wait for slot `slot` and finish: one dict per frame with the fields of eval.py's log line."""
+        self.done[slot].synchronize()
+        st = self.h_stats[slot][:count].numpy()
+        dm = self.h_dist[slot][:count].numpy()
+        out = []
+        for k in range(count):
+            s = st[k]
+            valid = float(s[6])
+            m = dict(i=first + k, pair=(int(pairs_global[k][0]), int(pairs_global[k][1])),
+                     l_m=float(s[0]) / valid, l_t=float(s[1]) / valid, l_kf=float(s[2]) / valid,
+                     a_m=(valid - float(s[3])) / valid, a_t=(valid - float(s[4])) / valid, a_kf=(valid - float(s[5])) / valid,
+                     d_m=dist_median(dm[k, 0]), d_t=dist_median(dm[k, 1]), d_kf=dist_median(dm[k, 2]),
+                     nis=(float(s[8]) / float(s[7])) if s[7] > 0 else 0.0)
+            out.append(m)
+        return out
 
 
 def format_line(m):

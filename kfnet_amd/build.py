@@ -25,6 +25,8 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno
 EXTRA = {
     # the Kalman/warp kernel reproduces the reference's unfused elementwise arithmetic
     'kfn_kalman.hip': ['-ffp-contract=off'],
+    # the metrics kernel restates TF elementwise ops whose results are thresholded and counted
+    'kfn_metrics.hip': ['-ffp-contract=off'],
 }
 
 

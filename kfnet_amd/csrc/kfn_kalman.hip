@@ -33,6 +33,8 @@ struct KalmanArgs {
   f32x4* rec;
   f32x4* opt_temp;
   float* opt_nis;
+  f32x4* opt_kf;      // raw (untransformed, ungated) KF estimate per frame, or null
+  int raw_on_reset;   // debug outputs of a reset frame = what the reference GRAPH computes there
   kfn_kalman_desc d;
 };
 
@@ -51,17 +53,21 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a, const f32x4* st
   const f32x4 z = in.z;  // (zx, zy, zz, sigma_z)
   f32x4 outv;                // record before transform: (x, y, z, sigma)
   f32x4 nv;
-  if (reset) {
-    // eval.py:94-101: state := measurement, outputs := measurement
-    nv = z;
-    outv = z;
+  // eval.py runs the graph on EVERY step -- also on a reset step, where temp / KF / NIS are computed
+  // from whatever the state variables hold and only the host overrides outputs and feedback afterwards
+  // (KFNet/eval.py:94-101).  With raw_on_reset the debug outputs (temp, NIS, raw KF: what the losses of
+  // eval.py:113-118 are computed from) follow the graph; the state and the record follow the host.
+  const bool graph_path = !reset || (a.raw_on_reset && (a.opt_temp || a.opt_nis || a.opt_kf));
+  if (reset && !graph_path) {
     if (a.opt_temp) a.opt_temp[off + p] = z;
+    if (a.opt_kf) a.opt_kf[off + p] = z;
     if (a.opt_nis) {
       a.opt_nis[(off + p) * 3 + 0] = 0.f;
       a.opt_nis[(off + p) * 3 + 1] = 0.f;
       a.opt_nis[(off + p) * 3 + 2] = 0.f;
     }
-  } else {
+  }
+  if (graph_path) {
     const int y = p / W, x = p - y * W;
     // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
     const float px = (float)x + in.flow.x;
@@ -89,11 +95,14 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a, const f32x4* st
     const float mv = z.w * z.w;
     const float K = lv / (lv + mv);
     const float om = fmaxf(1.0f - K, 0.0f);
-    nv.x = om * g.x + K * z.x;
-    nv.y = om * g.y + K * z.y;
-    nv.z = om * g.z + K * z.z;
-    nv.w = sqrtf(om * lv);
-    outv = nv;  // eval.py:103-104: the raw KF state (nv) is what is fed back
+    f32x4 kf;
+    kf.x = om * g.x + K * z.x;
+    kf.y = om * g.y + K * z.y;
+    kf.z = om * g.z + K * z.z;
+    kf.w = sqrtf(om * lv);
+    nv = kf;
+    outv = kf;  // eval.py:103-104: the raw KF state (nv) is what is fed back
+    if (a.opt_kf) a.opt_kf[off + p] = kf;
     if (want_nis) {
       // GetNIS (KFNet.py:164-184)
       const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
@@ -114,6 +123,11 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a, const f32x4* st
       f32x4 tv = {g.x, g.y, g.z, temp_unc};
       a.opt_temp[off + p] = tv;
     }
+  }
+  if (reset) {
+    // eval.py:94-101: state := measurement, outputs := measurement
+    nv = z;
+    outv = z;
   }
   // ApplyTransform (util.py:12-40) + 1/sigma (eval.py:123)
   f32x4 r;
@@ -273,16 +287,17 @@ int launch_scan(const KalmanArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
-                               const float* sigma_trans, const float* meas, float* state,
-                               float* records, float* opt_temp, float* opt_nis, void* stream) {
+extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy,
+                                  const float* sigma_trans, const float* meas, float* state,
+                                  float* records, float* opt_temp, float* opt_nis, float* opt_kf,
+                                  int raw_on_reset, void* stream) {
   KFN_REQUIRE(d && flow_xy && sigma_trans && meas && state && records, "kfn_kalman_scan: null argument");
   KFN_REQUIRE(d->S > 0 && d->T > 0 && d->H > 1 && d->W > 1, "kfn_kalman_scan: bad shape S=%d T=%d H=%d W=%d",
               d->S, d->T, d->H, d->W);
   const int HW = d->H * d->W;
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(flow_xy) & 7) | (reinterpret_cast<uintptr_t>(meas) & 15) |
                (reinterpret_cast<uintptr_t>(state) & 15) | (reinterpret_cast<uintptr_t>(records) & 15) |
-               (reinterpret_cast<uintptr_t>(opt_temp) & 15)) == 0,
+               (reinterpret_cast<uintptr_t>(opt_temp) & 15) | (reinterpret_cast<uintptr_t>(opt_kf) & 15)) == 0,
               "kfn_kalman_scan: misaligned buffer");
   KalmanArgs a;
   a.flow = reinterpret_cast<const f32x2*>(flow_xy);
@@ -292,6 +307,8 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
   a.rec = reinterpret_cast<f32x4*>(records);
   a.opt_temp = reinterpret_cast<f32x4*>(opt_temp);
   a.opt_nis = opt_nis;
+  a.opt_kf = reinterpret_cast<f32x4*>(opt_kf);
+  a.raw_on_reset = raw_on_reset;
   a.d = *d;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if ((size_t)HW * 16 > 160 * 1024) {
@@ -321,6 +338,12 @@ extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
   if (HW <= 512 * 10) return launch_scan<512, 10, false, false>(a, s);
   if (HW <= 512 * 16) return launch_scan<512, 16, false, false>(a, s);
   return launch_scan<512, 20, false, false>(a, s);
+}
+
+extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
+                               const float* sigma_trans, const float* meas, float* state,
+                               float* records, float* opt_temp, float* opt_nis, void* stream) {
+  return kfn_kalman_scan_ex(d, flow_xy, sigma_trans, meas, state, records, opt_temp, opt_nis, nullptr, 0, stream);
 }
 
 extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis,

@@ -31,7 +31,7 @@ def grid_size(image_hw):
 class KFNetEngine(object):
     def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
                  nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False,
-                 conv_operands='f32', use_graph=False):
+                 conv_operands='f32', use_graph=False, emit_metrics=False):
         import torch
         self.torch = torch
         self.B = int(batch)
@@ -41,7 +41,9 @@ class KFNetEngine(object):
         self.nis_gate = float(nis_gate)
         self.transform = None if transform is None else np.asarray(transform, dtype=np.float32)
         self.max_chunk = int(max_chunk)
+        emit_debug = bool(emit_debug or emit_metrics)
         self.emit_debug = emit_debug
+        self.emit_metrics = bool(emit_metrics)
 
         g = self.graph = Graph()
         g.conv_operands = conv_operands
@@ -66,10 +68,13 @@ class KFNetEngine(object):
         self.c_rec = g.tensor((T, self.h, self.w, 4), name='chunk_records')
         self.c_temp = g.tensor((T, self.h, self.w, 4), name='chunk_temp') if emit_debug else None
         self.c_nis = g.tensor((T, self.h, self.w, 3), name='chunk_nis') if emit_debug else None
+        # eval.py's log line needs the raw KF estimate and the graph's (not the host's) view of reset steps
+        self.c_kf = g.tensor((T, self.h, self.w, 4), name='chunk_kf_raw') if emit_metrics else None
         self.chunk_scan = KalmanScanOp(self.c_flow, self.c_sigma, self.c_meas, self.state, self.c_rec,
                                        self.c_temp, self.c_nis, S=1, T=1, H=self.h, W=self.w,
                                        reset_period=self.reset_period, min_uncertainty=self.net.min_uncertainty,
-                                       nis_gate=self.nis_gate, transform=self.transform)
+                                       nis_gate=self.nis_gate, transform=self.transform, kf_raw=self.c_kf,
+                                       raw_on_reset=emit_metrics)
         g.finalize(device)
         g.load_weights(weights)
         self.lib = _lib.load()

@@ -638,10 +638,12 @@ class KalmanScanOp(Op):
     """S sequences x T frames of warp + Kalman fuse (+NIS, transform, emit)."""
 
     def __init__(self, flow, sigma_t, meas, state, records, temp=None, nis=None, S=1, T=1, H=0, W=0,
-                 reset_period=500, min_uncertainty=1e-5, nis_gate=0.0, transform=None):
+                 reset_period=500, min_uncertainty=1e-5, nis_gate=0.0, transform=None, kf_raw=None,
+                 raw_on_reset=False):
         self.name = 'kalman_scan'
         self.flow, self.sigma_t, self.meas, self.state = flow, sigma_t, meas, state
         self.records, self.temp, self.nis = records, temp, nis
+        self.kf_raw, self.raw_on_reset = kf_raw, raw_on_reset   # kfn_kalman_scan_ex debug outputs
         self.S, self.T, self.H, self.W = S, T, H, W
         self.reset_period = reset_period
         self.min_uncertainty = min_uncertainty
@@ -657,9 +659,11 @@ class KalmanScanOp(Op):
             t = np.asarray(self.transform, dtype=np.float32)[:3, :4].reshape(-1)
             for i in range(12):
                 d.transform[i] = float(t[i])
-        rc = lib.kfn_kalman_scan(C.byref(d), self.flow.ptr, self.sigma_t.ptr, self.meas.ptr, self.state.ptr,
-                                 self.records.ptr, self.temp.ptr if self.temp is not None else None,
-                                 self.nis.ptr if self.nis is not None else None, stream)
+        rc = lib.kfn_kalman_scan_ex(C.byref(d), self.flow.ptr, self.sigma_t.ptr, self.meas.ptr, self.state.ptr,
+                                    self.records.ptr, self.temp.ptr if self.temp is not None else None,
+                                    self.nis.ptr if self.nis is not None else None,
+                                    self.kf_raw.ptr if self.kf_raw is not None else None,
+                                    int(bool(self.raw_on_reset)), stream)
         _lib.check(rc, 'kfn_kalman_scan')
 
 

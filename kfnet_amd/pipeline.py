@@ -148,7 +148,9 @@ class StreamedSequence(object):
         self.ev_done = [None, None]
         self.ev_down = [None, None]
 
-    def run(self, chunks):
+    def run(self, chunks, after_process=None):
+        """`after_process(k, first_index, n)` (optional) is called right after chunk k's compute has been
+        enqueued, on the compute stream -- e.g. to enqueue a reduction over the chunk's scan buffers."""
         torch = self.eng.torch
         eng = self.eng
         main = torch.cuda.current_stream(eng.device)
@@ -167,6 +169,8 @@ class StreamedSequence(object):
             if self.ev_down[b] is not None:
                 main.wait_event(self.ev_down[b])             # download of chunk k-2 has read dev_rec[b]
             rec = eng.process(self.dev_frames[b][:n], t0=lo)
+            if after_process is not None:
+                after_process(k, lo, n)
             self.dev_rec[b][:n].copy_(rec)                   # the engine's record buffer is reused by chunk k+1
             self.ev_done[b] = torch.cuda.Event()
             self.ev_done[b].record(main)

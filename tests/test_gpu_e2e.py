@@ -163,26 +163,47 @@ def test_long_recursion_error_does_not_grow():
 
 
 def test_eval_with_labels_prints_reference_metrics(capsys):
-    """eval() with label maps reproduces the reference's log line fields (KFNet/eval.py:113-118)."""
+    """eval() with label maps: the log-line fields come from kfn_eval_metrics on the device (sums / counts)
+    + host medians, through the STREAMED pipeline; every field against the numpy oracle evaluated on the
+    scan's own debug buffers -- including a reset step inside the run (graph-view losses, host-view
+    distances), the NIS gate, and the (s+1, s) pair of a sequence start."""
     from kfnet_amd.KFNet import eval as kf_eval
-    from kfnet_amd.KFNet import metrics as M
-    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.KFNet import metrics as HM
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
     from kfnet_amd.weights import synthetic_weights
+    from oracle import kfnet_metrics_oracle as MO
     rng = np.random.default_rng(5)
-    frames = synthetic_sequence(4, 64, 96, seed=6)
-    labels = rng.normal(size=(4, 64, 96, 4)).astype(np.float32)
-    labels[..., 3] = (rng.random(size=(4, 64, 96)) > 0.3).astype(np.float32)
-    T4 = np.eye(4, dtype=np.float32)
-    rec, mets = kf_eval.eval(None, T4, synthetic_weights(3), None, image_size=(64, 96), batch=2, frames=frames,
-                             labels=labels, chunk=4)
-    assert len(mets) == 4 and mets[0]['pair'] == (1, 0) and mets[2]['pair'] == (1, 2)
-    out = capsys.readouterr().out
-    assert '2, frame 1~2, l_m = ' in out and 'Median dist error:' in out
-    gt = M.resize_nearest(labels[3], (8, 12))
-    d_kf, _ = M.dist_error(rec[3][..., :3], gt[..., :3], gt[..., 3:4])
-    assert np.isclose(mets[3]['d_kf'], d_kf)
-    assert all(np.isfinite(m[k]) for m in mets for k in ('l_m', 'l_t', 'l_kf', 'a_kf', 'nis'))
-    assert mets[0]['d_t'] == mets[0]['d_m']      # reset step: temp output := measurement
+    n, size, grid = 7, (64, 96), (8, 12)
+    frames = synthetic_sequence(n, 64, 96, seed=6)
+    labels = (rng.normal(size=(n, 64, 96, 4)) * 0.05).astype(np.float32)
+    labels[..., 3] = (rng.random(size=(n, 64, 96)) > 0.3).astype(np.float32)
+    T4 = np.linalg.inv(synthetic_transform())
+    W = synthetic_weights(3)
+    for nis in (False, True):
+        rec, mets = kf_eval.eval(None, T4, W, None, nis=nis, image_size=size, batch=2, frames=frames, labels=labels,
+                                 chunk=3, sequence_length=4, metrics_sequence_length=4)
+        assert len(mets) == n and mets[0]['pair'] == (1, 0) and mets[2]['pair'] == (1, 2) and mets[4]['pair'] == (5, 4)
+        out = capsys.readouterr().out
+        assert '2, frame 1~2, l_m = ' in out and 'Median dist error:' in out
+        # oracle on the same intermediate maps (one resident pass with the debug outputs)
+        eng = KFNetEngine(W, image_size=size, batch=2, transform=T4, reset_period=4, nis_gate=7.815 if nis else 0.0,
+                          max_chunk=n, emit_metrics=True)
+        rec2 = eng.process(eng.upload_frames(frames)).cpu().numpy()
+        assert np.array_equal(rec2, rec)          # chunked + streamed == resident
+        d = eng.debug(n)
+        kf_raw = eng.c_kf.root_storage.buf[:n * eng.hw * 4].view(n, 8, 12, 4).cpu().numpy()
+        for i in range(n):
+            a, b = mets[i]['pair']
+            ref = MO.frame_metrics(i, (a, b), d['meas'][i], d['temp'][i], kf_raw[i], rec[i], d['nis'][i],
+                                   (labels[a], labels[b]), T4, i % 4 == 0, grid)
+            for key in ('l_m', 'l_t', 'l_kf', 'a_m', 'a_t', 'a_kf', 'nis'):
+                assert np.isclose(mets[i][key], ref[key], rtol=2e-5, atol=1e-6), (i, key, mets[i][key], ref[key])
+            for key in ('d_m', 'd_t', 'd_kf'):
+                assert np.isclose(mets[i][key], ref[key], rtol=1e-4), (i, key, mets[i][key], ref[key])
+        assert mets[4]['d_t'] == mets[4]['d_m']      # reset step: temp output := measurement (eval.py:98)
+        assert mets[4]['l_t'] != mets[4]['l_m']      # ... but the losses see the graph's prediction
+    assert HM.format_line(mets[1]).startswith('1, frame 0~1, l_m = ')
 
 
 def test_config5_fp16_convs_fp32_kalman():

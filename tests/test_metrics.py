@@ -1,7 +1,10 @@
-"""CPU tests of the eval.py metrics against hand-computed values."""
+"""CPU tests of the eval.py metrics: the numpy oracle against hand-computed values
+(what pins it), and the host side of kfnet_amd.KFNet.metrics (label reading, step schedule, line format).
+The device reduction itself is checked against the oracle in tests/test_gpu_e2e.py."""
 import numpy as np
 
-from kfnet_amd.KFNet import metrics as M
+from oracle import kfnet_metrics_oracle as M
+from kfnet_amd.KFNet import metrics as HM
 
 
 def test_resize_nearest_picks_8y_8x():
@@ -48,3 +51,25 @@ def test_log_line_format():
     m = dict(i=3, pair=(2, 3), l_m=-2.5, l_t=-2.4, l_kf=-2.6, a_m=0.5, a_t=0.4, a_kf=0.6, d_m=3.0, d_t=4.0,
              d_kf=2.0, nis=0.7)
     assert M.format_line(m).startswith('3, frame 2~3, l_m = -2.500, l_t = -2.400, l_kf = -2.600, a_m = 0.500')
+
+
+def test_host_label_grid_equals_tf_nearest_resize(tmp_path):
+    a = np.random.default_rng(1).normal(size=(480, 640, 4)).astype(np.float32)
+    p = tmp_path / 'l.bin'
+    a.tofile(p)
+    g = HM.read_label_grid(str(p), (480, 640), (60, 80))
+    assert g.shape == (60, 80, 4) and np.array_equal(g, M.resize_nearest(a, (60, 80)))
+    assert np.array_equal(HM.resize_nearest(a, (60, 80)), M.resize_nearest(a, (60, 80)))
+    assert HM.format_line(dict(i=3, pair=(2, 3), l_m=-2.5, l_t=-2.4, l_kf=-2.6, a_m=0.5, a_t=0.4, a_kf=0.6, d_m=3.0,
+                               d_t=4.0, d_kf=2.0, nis=0.7)) == M.format_line(dict(i=3, pair=(2, 3), l_m=-2.5, l_t=-2.4,
+                               l_kf=-2.6, a_m=0.5, a_t=0.4, a_kf=0.6, d_m=3.0, d_t=4.0, d_kf=2.0, nis=0.7))
+
+
+def test_pair_schedule_follows_get_indexes():
+    """KFNet/train.py:67-71: [[s+1, s], [s, s+1], ...] per test sequence; 'stairs' sequences are 500 long."""
+    ps = HM.pair_schedule(0, 4, 2000, 1000)
+    assert ps.tolist() == [[1, 0], [0, 1], [1, 2], [2, 3]]
+    assert HM.pair_schedule(998, 4, 2000, 1000).tolist() == [[997, 998], [998, 999], [1001, 1000], [1000, 1001]]
+    assert HM.pair_schedule(499, 3, 1000, 500).tolist() == [[498, 499], [501, 500], [500, 501]]
+    assert HM.pair_schedule(0, 1, 1, 1000).tolist() == [[0, 0]]
+    assert HM.TEST_SEQUENCE_LENGTH['stairs'] == 500 and HM.TEST_SEQUENCE_LENGTH['heads'] == 1000
