@@ -84,6 +84,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
+// voffset (per lane, range-checked) + soffset (wave-uniform, NOT range-checked): the uniform part of an
+// address costs a scalar add instead of a VALU add -- and VALU instructions are paid in MFMA time on the
+// fp32 matrix pipe (tools/mb/mfma_fill.hip: ~5 cycles each beside a 64-cycle MFMA, never hidden).
+__device__ __forceinline__ f32x4 buf_load_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
 template <int I, int N, class F>
@@ -208,14 +214,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int n_first = TRANSPOSED ? 0 : fdiv(CVOL ? (m0 >> 6) : m0, p.fd_img);
   const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
   const unsigned long long a_rest = p.x_bytes - a_base;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
-      (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
+  // The range check of a buffer load looks at the per-lane offset only (the scalar offset is excluded), and
+  // the per-row offset of the input pixel (iy0, ix0) may lie up to (pad_t rows + pad_l pixels) BEFORE the
+  // image (5 rows + 5 pixels for the cost-volume window): the descriptor is based that far below the tile's
+  // first image and every row offset shifted up by the same amount, so that row offsets are non-negative
+  // and the tap / channel offset can ride in the scalar operand.
+  const unsigned a_shift = (TRANSPOSED || WINO) ? 0u
+                           : (unsigned)(((CVOL ? 5 : p.pad_t) * p.W + (CVOL ? 5 : p.pad_l)) * p.ldx) * 4u;
+  char* const a_ptr = const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base;
+  const unsigned long long a_span = a_rest + a_shift;
+  const int a_records = (int)(a_span < 0x7fffffffull ? a_span : 0x7fffffffull);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a_ptr - a_shift, 0, a_records, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(  // CVOL: f2 (same shape as f1)
       const_cast<char*>(reinterpret_cast<const char*>(CVOL ? p.x2 : p.x)) + a_base, 0,
       (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.w) + (size_t)grp * p.cout_pad * p.Ktot, 0, p.w_bytes, 0x00020000);
+  float* const b_ptr = const_cast<float*>(p.w) + (size_t)grp * p.cout_pad * p.Ktot;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread im2col row state -------------------------------------------------
   // conv:        a_off = byte offset of input pixel (iy0, ix0) (may be "negative" = wrapped;
@@ -234,6 +248,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const float w_sra = (w_xi == 2) ? -1.f : 1.f, w_srb = (w_xi == 0 || w_xi == 3) ? -1.f : 1.f;
   const float w_sca = (w_nu == 2) ? -1.f : 1.f, w_scb = (w_nu == 0 || w_nu == 3) ? -1.f : 1.f;
   const float w_s00 = w_sra * w_sca, w_s01 = w_sra * w_scb, w_s10 = w_srb * w_sca, w_s11 = w_srb * w_scb;
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  const f32x2s w_p00 = {w_s00, w_s00}, w_p01 = {w_s01, w_s01}, w_p10 = {w_s10, w_s10}, w_p11 = {w_s11, w_s11};
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int r = r0 + i * RPP;
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
             if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) m2 |= 1u << t;
           }
         }
-        a_off[i] = (unsigned)(((n_img * p.H + oy + wi - 5) * p.W + (ox + wj - 5)) * p.ldx + q * 4) * 4u;
+        a_off[i] = (unsigned)(((n_img * p.H + oy + wi - 5) * p.W + (ox + wj - 5)) * p.ldx + q * 4) * 4u + a_shift;
         a_off2[CVOL ? i : 0] = (unsigned)((n_img * HW + rem) * p.ldx + q * 4) * 4u;
         a_msk[i] = m1;
         a_msk2[CVOL ? i : 0] = m2;
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
       } else {
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * 4u;
+        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * 4u + a_shift;
         // valid taps = [ky_lo, ky_hi) x [kx_lo, kx_hi)
         const int ky_lo = iy0 < 0 ? -iy0 : 0, ky_hi = (p.H - iy0 < p.kh) ? p.H - iy0 : p.kh;
         const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = (p.W - ix0 < p.kw) ? p.W - ix0 : p.kw;
@@ -381,6 +397,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int rot = ((p.rot_mode & 3) == 0 || (p.rot_mode & 3) == 3) ? 0 : ((tm * 7 + tn * 3 + ((p.rot_mode & 3) == 2 ? grp * 5 : 0)) % kchunks);
   int ld_ci = 0;
   int ld_c0 = rot * KCH;
+  // Is the load stream's current tap inside the image for row slot i?  Evaluated when the tap CHANGES (once
+  // per Cin/KCH stages) and carried as a lane mask, so that a load costs one v_cndmask instead of a
+  // shift + and + compare + select per stage.
+  bool a_ok[AP], a_ok2[CVOL ? AP : 1];
+  auto refresh_ok = [&]() {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      a_ok[i] = (ld_tap < 32) && ((a_msk[i] >> (ld_tap & 31)) & 1u);
+      if (CVOL) a_ok2[CVOL ? i : 0] = (ld_tap < 32) && ((a_msk2[CVOL ? i : 0] >> (ld_tap & 31)) & 1u);
+    }
+  };
+  refresh_ok();
   auto advance = [&]() {
     ++ld_ci;
     ld_c0 += KCH;
@@ -390,6 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       ld_c0 = rot * KCH;
       const unsigned rest = (ld_tap < 31) ? (tapmask & ~((2u << ld_tap) - 1u)) : 0u;
       ld_tap = rest ? __builtin_ctz(rest) : 32;
+      if (!WINO && !TRANSPOSED) refresh_ok();
     }
   };
 
@@ -397,47 +426,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // iterator has run off the end: keeps the loop body branch-free).
   auto load_one = [&](int k, bool live, unsigned adelta, unsigned bdelta, int ky, int kx, int tap) {
     if (WINO && k < AP * NSRC) {
-      const unsigned base = a_w4[WINO ? k / NSRC : 0][k % NSRC];
-      ga[k] = buf_load(rsA, live ? base + (unsigned)ld_c0 * 4u : OOB);
+      // per-lane: the source pixel's offset (or OOB for zero padding); uniform: channel offset; a stream
+      // that has run off the end reads through a descriptor with num_records = 0 (scalar select)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a_ptr, 0, live ? a_records : 0, 0x00020000);
+      ga[k] = buf_load_s(rs, a_w4[WINO ? k / NSRC : 0][k % NSRC], (unsigned)ld_c0 * 4u);
     } else if (CVOL && k < AP * NSRC) {
       const int i = k / NSRC;
       if (k % NSRC == 0) {  // f2[p]: same for every tap that lies inside the window
-        const bool ok = live && ((a_msk[i] >> tap) & 1u);
-        ga[k] = buf_load(rsA2, ok ? a_off2[CVOL ? i : 0] + (unsigned)ld_c0 * 4u : OOB);
+        ga[k] = buf_load_s(rsA2, a_ok[i] ? a_off2[CVOL ? i : 0] : OOB, (unsigned)ld_c0 * 4u);
       } else {              // shifted f1
-        const bool ok = live && ((a_msk2[CVOL ? i : 0] >> tap) & 1u);
-        ga[k] = buf_load(rsA, ok ? a_off[i] + adelta : OOB);
+        ga[k] = buf_load_s(rsA, a_ok2[CVOL ? i : 0] ? a_off[i] : OOB, adelta);
       }
     } else if (F16 && k < AP * NSRC) {   // two consecutive float4 = the 8 channels of one fp16 quad
       const int i = k / NSRC;
-      unsigned vo;
       if (TRANSPOSED) {
         const int ty = a_y[i] - ky, tx = a_x[i] - kx;
         const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
-        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
+        unsigned vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
+        vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo + (unsigned)(k % NSRC) * 16u : OOB;
+        ga[k] = buf_load(rsA, vo);
       } else {
-        vo = a_off[i] + adelta;
+        ga[k] = buf_load_s(rsA, a_ok[i] ? a_off[i] : OOB, adelta + (unsigned)(k % NSRC) * 16u);
       }
-      vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo + (unsigned)(k % NSRC) * 16u : OOB;
-      ga[k] = buf_load(rsA, vo);
     } else if (!F16 && k < AP) {
       const int i = k;
-      unsigned vo;
       if (TRANSPOSED) {
         const int ty = a_y[i] - ky, tx = a_x[i] - kx;
         const unsigned pix = a_off[i] + (unsigned)((ty >> 1) * p.W + (tx >> 1));
-        vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
+        unsigned vo = (pix * (unsigned)p.ldx + (unsigned)(ld_c0 + q * QCH)) * 4u;
+        vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo : OOB;
+        ga[i] = buf_load(rsA, vo);
       } else {
-        vo = a_off[i] + adelta;
+        ga[i] = buf_load_s(rsA, a_ok[i] ? a_off[i] : OOB, adelta);
       }
-      vo = (live && ((a_msk[i] >> tap) & 1u)) ? vo : OOB;
-      ga[i] = buf_load(rsA, vo);
     } else {
       const int kk = k - AP * NSRC;
       const int i = kk / NPART;
       // f16x3: the packed weights are [hi | lo], lo starts w_lo_bytes after hi
       const unsigned part_off = (X3 && (kk % NPART)) ? p.w_lo_bytes : 0u;
-      gb[kk] = buf_load(rsB, live ? b_off[i] + (F16 ? bdelta >> 1 : bdelta) + part_off : OOB);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, live ? (int)p.w_bytes : 0, 0x00020000);
+      gb[kk] = buf_load_s(rs, b_off[i], (F16 ? bdelta >> 1 : bdelta) + part_off);
     }
   };
 
@@ -448,11 +476,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     if (k < AP) {
       const int i = k;
       f32x4 v;
-      if (WINO) {  // B^T d B for this (xi,nu): four signed source pixels
-        v = w_s00 * ga[i * NSRC + 0];
-        v += w_s01 * ga[i * NSRC + (WINO ? 1 : 0)];
-        v += w_s10 * ga[i * NSRC + (WINO ? 2 : 0)];
-        v += w_s11 * ga[i * NSRC + (WINO ? 3 : 0)];
+      if (WINO) {  // B^T d B for this (xi,nu): four signed source pixels, as packed fp32 math
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4 g0 = ga[i * NSRC + 0], g1 = ga[i * NSRC + (WINO ? 1 : 0)], g2 = ga[i * NSRC + (WINO ? 2 : 0)],
+                    g3 = ga[i * NSRC + (WINO ? 3 : 0)];
+        // (the compiler scalarises <2 x float> fma; the signs are wave-uniform register pairs)
+        f32x2 lo, hi;
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "s"(w_p00), "v"(g0.xy));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "s"(w_p00), "v"(g0.zw));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "s"(w_p01), "v"(g1.xy));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "s"(w_p01), "v"(g1.zw));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "s"(w_p10), "v"(g2.xy));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "s"(w_p10), "v"(g2.zw));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "s"(w_p11), "v"(g3.xy));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "s"(w_p11), "v"(g3.zw));
+        v = f32x4{lo.x, lo.y, hi.x, hi.y};
       } else if (CVOL) {
         v = ga[i * NSRC] - ga[i * NSRC + (CVOL ? 1 : 0)];   // diff_feat = feat_map2 - shift(feat_map1)
       } else if (F16) {
