@@ -575,9 +575,12 @@ def main():
             'unit': 'TFLOP/s', 'frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'traffic': traffic,
             'algorithmic_tflops': round(tf, 2), 'algorithmic_frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': ('kernel template args <TM,TN,WM,WN,BK,MODE,F16>: MODE 2 = the 16 GEMMs of Winograd F(2x2,3x3) (fp32): '
-                     'algorithmic_* counts the direct-convolution FLOPs they replace and may exceed the MFMA peak; MODE 0 = '
-                     'direct implicit GEMM, 1 = transposed conv, 3 = conv0 with the cost volume generated in the loader'),
+            'note': ('wino2_kernel = single-kernel Winograd F(2x2,3x3) (kfn_conv2d_winograd_fused, fp32): achieved = FLOPs the '
+                     'MFMAs execute (16/36 of the nominal direct-convolution FLOPs + tile-block padding) / time, algorithmic_* '
+                     'counts the nominal FLOPs of SURVEY App. C and may exceed the MFMA peak; traffic = PMC HBM-side bytes per '
+                     'launch, averaged over the launches of a batch like avg_launch_ms. conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,'
+                     'PREC>: MODE 0 direct implicit GEMM, 1 transposed, 2 the 16 GEMMs of the two-kernel Winograd form, 3 conv0 '
+                     'with the cost volume in the loader'),
             'launches_per_batch': n_dom,
             'algorithmic_gflop_per_launch_avg': round(fl_dom / n_dom / 1e9, 3),
             'executed_gflop_per_launch_avg': round(ex_dom / n_dom / 1e9, 3),
