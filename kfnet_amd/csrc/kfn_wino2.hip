@@ -405,6 +405,11 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
 
 }  // namespace
 
+namespace kfn {
+int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed, const float* bias, float* y,
+                 hipStream_t stream);   // kfn_wino3.hip: four waves share one input transform
+}
+
 // Can the single-kernel path take this layer?  (host-side routing; no device access)
 extern "C" int kfn_winograd_fused_supported(const kfn_conv_desc* d) {
   if (!d) return 0;
@@ -433,6 +438,15 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
               "kfn_conv2d_winograd_fused: fp32, no fused head epilogue");
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u2_packed)) & 15) == 0,
               "kfn_conv2d_winograd_fused: buffers must be 16-byte aligned");
+  {
+    // >= 128 output channels and whole 32-channel super-steps: the 4-wave form (one transform per 128 output
+    // channels, input read Cout/128 times); KFN_WINO_FORM=2 forces the one-wave form for A/B measurements
+    static const int form = getenv("KFN_WINO_FORM") ? atoi(getenv("KFN_WINO_FORM")) : 0;
+    const long img_b = (long)d->H * d->W * d->ldx * 4L;
+    if (form != 2 && d->Cout >= 128 && d->Cin % 32 == 0 && 2 * img_b < (1L << 31) &&
+        2L * d->H * d->W * d->ldy * 4L < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31))
+      return kfn::launch_wino3(d, x, u2_packed, bias, y, (hipStream_t)stream);
+  }
   Wino2Args a;
   a.x = x; a.u2 = u2_packed; a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;

@@ -1,0 +1,450 @@
+// kfn_wino3.hip -- single-kernel Winograd F(2x2,3x3), four waves sharing ONE input transform.
+//
+// Same algorithm and data layouts as kfn_wino2.hip (kfn_conv2d_winograd_fused routes here when the layer has
+// >= 128 output channels and Cin % 32 == 0).  wino2_kernel pays, per wave of 32 tiles x 32 output channels:
+// one input transform (64 packed adds per 64 MFMAs = ~9 % of the fp32 matrix pipe, which VALU work is never
+// hidden behind), one read of the raw patch per 32 output channels (the input crosses HBM Cout/32 times) and
+// its own prologue round trip.  Here a workgroup of FOUR waves (one per SIMD) owns the same block of 8 x 4
+// tiles x 128 output channels (wave w: channels n0 + 32 w ...):
+//
+//   * V = B^T d B of an 8-channel chunk is computed ONCE, by one wave, and shared through LDS
+//     ([16 positions][32 tiles][8 ch] = 16 KiB per chunk; the consumer's fragment address is the producer's
+//     store address, so both sides are conflict-free 1 KiB runs).  The producing wave gathers its tiles' raw
+//     4x4 patches straight from global memory (16 range-checked loads, zero padding baked into the per-lane
+//     offsets), transforms them in registers (64 packed adds) and stores 16 quads.
+//   * Work is balanced over SUPER-STEPS of 4 chunks (32 input channels): in super-step k every wave runs the
+//     MFMAs of chunks 4k..4k+3 for its 32 channels AND produces chunk 4(k+1)+w for everybody -- so every wave
+//     carries exactly one transform per 256 MFMAs (~2.5 %) and one raw-buffer barrier per super-step
+//     (16 K cycles) is all the synchronisation there is.  8 V buffers (128 KiB) make that legal: the buffers
+//     written during super-step k are the ones read during k-1.
+//   * The input crosses HBM Cout/128 times instead of Cout/32, and the prologue is shared.
+//   * B fragments as in wino2 (U re-packed [Cin/8][16][Cout][8], 1 KiB contiguous per fragment, L2 -> registers),
+//     but the ring is 16 deep (one whole chunk ahead): the V registers of wino2 are gone.
+#include "kfn_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned OOBV = 0x80000000u;
+constexpr int BW = 8, BH = 4;           // tile block: 8 (x) by 4 (y) tiles = 32 MFMA rows
+constexpr int NWAVE = 4;                // waves per workgroup = 32-channel column blocks
+constexpr int NT = 32 * NWAVE;          // output channels per workgroup
+// One chunk of V in LDS: [16 positions][2 k-halves][32 tiles][4 floats], padded so that the PRODUCER's stores
+// (8 consecutive lanes = the 8 channel quads of one tile = 4 chunks x 2 halves) fall on 8 different 16-byte bank
+// groups: half stride = 512 + 64, chunk stride = 16 positions + 16 bytes.
+constexpr int VHALF = 512 + 64;
+constexpr int VPOS = 2 * VHALF;
+constexpr int VBUF = 16 * VPOS + 16;
+constexpr int NVBUF = 8;                // two super-steps of 4 chunks
+constexpr int NBR = 16;                 // B ring = one chunk of positions ahead
+constexpr int NVR = 8;                  // V fragment ring (positions ahead inside a super-step)
+// producer schedule inside a super-step of 256 MFMA slots (tools/mb/wino3_prof.hip sweeps these)
+#ifndef KFN_W3_GSTEP
+#define KFN_W3_GSTEP 8      // one raw-patch gather every GSTEP slots, from slot 0
+#define KFN_W3_XSLOT 175    // the transform burst
+#define KFN_W3_SSLOT 192    // first V store
+#define KFN_W3_SSTEP 2      // one V store every SSTEP slots
+#endif
+
+struct Wino3Args {
+  const float* x;
+  const float* u2;    // [Cin/8][16][cout_pad][8]
+  const float* bias;
+  float* y;
+  int N, H, W, Cin, ldx;
+  int Cout, cout_pad, ldy;
+  int Th, Tw;
+  int vrows;
+  int bw;
+  int tiles_m, tiles_n;
+  int relu;
+  int wide_store;     // Cout, ldy multiples of 4 and y 16-byte aligned: 16-byte stores of the transposed block
+  unsigned long long x_bytes;
+  unsigned long long y_bytes;
+  unsigned u_bytes;
+#ifdef KFN_WINO3_PROF
+  unsigned long long* prof;   // tools/mb/wino3_prof.hip: [block][wave][8] cycle stamps
+#endif
+};
+
+#ifdef KFN_WINO3_PROF
+// Every lane stores the same counter value to the same address: an `if (lane == 0)` here is divergent control flow,
+// after which hipcc no longer trusts the gather descriptors to be uniform and wraps each buffer_load in a
+// waterfall loop (4 v_readfirstlane + compare + branch) -- +12 % on the main loop, in the profiled build only.
+#define KFN_STAMP(i) (p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + (i)] = __builtin_readcyclecounter())
+#else
+#define KFN_STAMP(i) do { } while (0)
+#endif
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl<0, N>(f);
+}
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+__device__ __forceinline__ int xcd_remap3(int b, int nwg) {
+  int xcd = b & 7;
+  int q = nwg >> 3, r = nwg & 7;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+__device__ __forceinline__ void pk_sub_ip(f32x2& a, const f32x2& b) {
+  asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a) : "v"(b));
+}
+__device__ __forceinline__ void pk_rsub_ip(f32x2& a, const f32x2& b) {
+  asm("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a) : "v"(b));
+}
+__device__ __forceinline__ f32x2 pk_add(const f32x2& a, const f32x2& b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(const f32x2& a, const f32x2& b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (d0,d1,d2,d3) -> (d0-d2, d1+d2, d2-d1, d1-d3): one 1-D pass of B^T, in place
+__device__ __forceinline__ void bt_pass(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3) {
+  pk_sub_ip(d0, d2);
+  pk_rsub_ip(d3, d1);
+  const f32x2 s = pk_add(d1, d2);
+  pk_sub_ip(d2, d1);
+  d1 = s;
+}
+__device__ __forceinline__ void bt_d_b(f32x2 (&v)[32]) {   // v[2*(4*r + c) + half] -> v[2*(4*xi + nu) + half]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bt_pass(v[2 * (4 * r + 0) + h], v[2 * (4 * r + 1) + h], v[2 * (4 * r + 2) + h], v[2 * (4 * r + 3) + h]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bt_pass(v[2 * (0 + c) + h], v[2 * (4 + c) + h], v[2 * (8 + c) + h], v[2 * (12 + c) + h]);
+}
+
+__global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];   // [NVBUF][VBUF]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it in an SGPR
+  KFN_STAMP(0);
+#ifdef KFN_WINO3_PROF
+  p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+#endif
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap3(blockIdx.x, nwg);
+  const int tm = tile % p.tiles_m;          // M fastest
+  const int tn = tile / p.tiles_m;
+  const int cb = tm % p.bw, rb = tm / p.bw;
+  const int n0 = tn * NT + wave * 32;       // this wave's 32 output channels
+
+  // ---- block geometry (uniform) ----------------------------------------------------------
+  const int vr0 = rb * BH;
+  const int img0 = vr0 / p.Th;
+  const int ty0 = vr0 - img0 * p.Th;
+  const int brk = (p.Th - ty0 < BH) ? (p.Th - ty0) : BH;   // tile rows >= brk belong to image img0 + 1
+
+  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u2), 0, p.u_bytes, 0x00020000);
+
+  // ---- this lane as a PRODUCER: wave w owns tile row w of the block for ALL 32 channels of a super-step ----
+  // lane = (tile column tc, chunk cq, k-half h): 8 CONSECUTIVE lanes read the 128 contiguous bytes of a pixel's 32
+  // channels (the texture addresser only merges neighbouring lanes: lanes of one quad on four different pixels
+  // are four requests), and a lane's 16 loads are the 4x4 patch of tile (w, tc) for channels 8 cq + 4 h ..+3.
+  const int tc = lane >> 3, ph = lane & 1, cq = (lane >> 1) & 3;
+  // A patch pixel's address splits into a wave-uniform row part (tile row = wave): one descriptor per patch row,
+  // based at the row's first pixel and exactly one image row long (zero long if the row is above/below the image
+  // or the tile row does not exist), and a per-lane column part.  Columns left of the image give a negative =
+  // huge unsigned vector offset, columns right of it an offset past the row: both fail the range check and
+  // read as zero.
+  unsigned gcol[4];                   // byte offset of patch column c at this lane's channel quad
+  __amdgpu_buffer_rsrc_t rs_row[4];   // uniform
+  {
+    const int tr = wave;
+    const int img_rel = tr < brk ? 0 : 1;
+    const int ty = tr < brk ? ty0 + tr : tr - brk;
+    const int tx = cb * BW + tc;
+    const bool tile_ok = (vr0 + tr < p.vrows);
+    const int row_bytes = ((p.W - 1) * p.ldx + p.Cin) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = 2 * ty - 1 + r;
+      const bool ok = tile_ok && (unsigned)yy < (unsigned)p.H;
+      const unsigned long long off =
+          ok ? (unsigned long long)((img_rel * p.H + yy) * p.W) * (unsigned long long)(p.ldx * 4) : 0ull;
+      rs_row[r] = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base + off, 0, ok ? row_bytes : 0, 0x00020000);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gcol[c] = (unsigned)(((2 * tx - 1 + c) * p.ldx + cq * 8 + ph * 4) * 4);
+  }
+  // consumer fragment of position g: g*VPOS + half*VHALF + tile*16; the producer lane stores into chunk cq
+  const int v_lane = (lane >> 5) * VHALF + (lane & 31) * 16;
+  const int v_st = cq * VBUF + ph * VHALF + wave * 128 + tc * 16;
+  const int n_chunks = p.Cin / 8;
+  const int n_super = n_chunks / 4;
+  const int s_last = n_super - 1;
+
+  // ---- this lane as a CONSUMER ---------------------------------------------------------------
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * 4);
+  const unsigned b_step = (unsigned)p.cout_pad * 32u;
+  const int q_last = n_chunks * 16 - 1;
+
+  const int n = n0 + li;
+  const bool n_ok = n < p.Cout;
+  const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+  f32x16 acc[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[g][e] = (g == 5) ? bv : 0.f;   // bias rides in position (1,1), cf. kfn_wino2.hip
+
+  f32x2 pv[32];        // producer: raw patch -> V of the chunk this wave produces
+  f32x4 bq[NBR];       // B ring
+  f32x4 vq[NVR];       // V fragment ring
+
+  // producer steps for super-step `ss` (clamped past the end: chunks nobody will read)
+  auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i >> 2, c = i & 3;
+    const int sc = ss < s_last ? ss : s_last;
+    const f32x4 q = bload(rs_row[r], gcol[c], (unsigned)(sc * 128));
+    pv[2 * i] = q.xy;
+    pv[2 * i + 1] = q.zw;
+  };
+  auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    const f32x4 q = {pv[2 * g].x, pv[2 * g].y, pv[2 * g + 1].x, pv[2 * g + 1].y};
+    *reinterpret_cast<f32x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+  };
+  auto b_load = [&](auto gc, int qidx) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    const int qc = qidx < q_last ? qidx : q_last;
+    bq[g % NBR] = bload(rsU, voff_b, (unsigned)qc * b_step);
+  };
+  auto v_read = [&](auto gc, int ch) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    vq[g % NVR] = *reinterpret_cast<const f32x4*>(smem3 + (ch & (NVBUF - 1)) * VBUF + g * VPOS + v_lane);
+  };
+
+  KFN_STAMP(1);
+  // ---- prologue: every wave produces its tile row of super-step 0 -------------------------------
+  sfor<16>([&](auto ic) { p_gather(ic, 0); });
+  sfor<NBR>([&](auto gc) { b_load(gc, decltype(gc)::value); });
+  bt_d_b(pv);
+  sfor<16>([&](auto gc) { p_store(gc, 0); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  KFN_STAMP(2);
+  // One super-step: the MFMAs of chunks c0 .. c0+3 (slot j = 4 interleaved positions x 4 k-steps), and as a
+  // producer: gather chunk c0+4+wave behind the first MFMAs of chunk c0, transform it as ONE burst in the
+  // middle of chunk c0+2, store it behind the MFMAs of chunk c0+3; then the barrier.
+#ifdef KFN_W3_TL
+  unsigned long long tl[17];
+#endif
+  for (int ks = 0; ks < n_super; ++ks) {
+    const int c0 = ks * 4;
+    const int pch = ks + 1;   // the super-step this wave produces its tile row of
+    // the V fragments of the first NVR positions (nothing of this super-step could be read before the barrier)
+#ifndef KFN_W3_NOVREAD
+    sfor<NVR>([&](auto gc) { v_read(gc, c0); });
+#endif
+    sfor<4>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      const int ch = c0 + cc;
+      const int qbase = ch * 16;
+      sfor<64>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int g = (j >> 4) * 4 + (j & 3), t = (j >> 2) & 3;
+#ifdef KFN_W3_TL
+        if constexpr ((cc * 64 + j) % 16 == 0) tl[(cc * 64 + j) / 16] = __builtin_readcyclecounter();
+#endif
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[g % NVR][t], bq[g % NBR][t], acc[g], 0, 0, 0);
+        if constexpr (t == 3) {
+#ifndef KFN_W3_NOBLOAD
+          b_load(std::integral_constant<int, g>{}, qbase + g + NBR);
+#endif
+#ifndef KFN_W3_NOVREAD
+          // V fragment NVR positions ahead: same chunk, or the next chunk of THIS super-step
+          if constexpr (g + NVR < 16) v_read(std::integral_constant<int, g + NVR>{}, ch);
+          else if constexpr (cc < 3) v_read(std::integral_constant<int, g + NVR - 16>{}, ch + 1);
+#endif
+        }
+        // producer work, spread thin: the four waves of a CU share one texture addresser and one LDS port, and a
+        // wave whose vector-memory instruction cannot issue stalls its MFMAs behind it
+        constexpr int sj = cc * 64 + j;   // slot inside the super-step
+#ifndef KFN_W3_NOGATHER
+        if constexpr (sj < 16 * KFN_W3_GSTEP && sj % KFN_W3_GSTEP == 0) p_gather(std::integral_constant<int, sj / KFN_W3_GSTEP>{}, pch);
+#endif
+#ifndef KFN_W3_NOXFORM
+        if constexpr (sj == KFN_W3_XSLOT) bt_d_b(pv);
+#endif
+#ifndef KFN_W3_NOSTORE
+        if constexpr (sj >= KFN_W3_SSLOT && sj < KFN_W3_SSLOT + 16 * KFN_W3_SSTEP && (sj - KFN_W3_SSLOT) % KFN_W3_SSTEP == 0)
+          p_store(std::integral_constant<int, (sj - KFN_W3_SSLOT) / KFN_W3_SSTEP>{}, pch);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+#ifndef KFN_W3_NOBAR
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+  }
+
+#ifdef KFN_W3_NOSTORE
+#pragma unroll
+  for (int i = 0; i < 32; ++i) asm volatile("; keep %0" ::"v"(pv[i]));
+#endif
+#ifdef KFN_W3_TL
+  tl[16] = __builtin_readcyclecounter();
+#pragma unroll
+  for (int i = 0; i < 17; ++i) p.prof[((size_t)gridDim.x * NWAVE) * 8 + ((size_t)blockIdx.x * NWAVE + wave) * 17 + i] = tl[i];
+#endif
+  KFN_STAMP(3);
+  // ---- epilogue (per wave, as kfn_wino2.hip) -----------------------------------------------------
+  const bool relu = p.relu != 0;
+  const unsigned long long y_base = (unsigned long long)img0 * p.H * p.W * p.ldy * 4ull;
+  const unsigned long long y_rest = p.y_bytes - y_base;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+  const int txl = cb * BW + 4 * lh;
+  const unsigned voff_y = (unsigned)((2 * txl * p.ldy + n) * 4);
+  const int pix_bytes = p.ldy * 4;
+  // Output transform (16 positions -> 2x2 pixels, packed adds), then the stores.  Global stores are ISSUE bound
+  // (~60 cycles per store instruction per CU whatever its width), so 64 dword stores per wave cost ~16 K cycles.
+  // Instead every wave transposes its 128 pixels x 32 channels through its own 16 KiB of the (now idle) V
+  // buffers -- [pixel][32 channels], written by ds_write_b32 (32 lanes = one 128-byte pixel row), read back as
+  // 1 KiB runs -- and issues 16 stores of 16 bytes per lane: 8 lanes cover the 128 contiguous bytes of a pixel.
+  auto out_transform = [&](auto&& put) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ep = 0; ep < 8; ++ep) {
+      const int e0 = 2 * ep;
+      f32x2 r0[4], r1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const f32x2 m0 = {acc[0 + nu][e0], acc[0 + nu][e0 + 1]}, m1 = {acc[4 + nu][e0], acc[4 + nu][e0 + 1]};
+        const f32x2 m2 = {acc[8 + nu][e0], acc[8 + nu][e0 + 1]}, m3 = {acc[12 + nu][e0], acc[12 + nu][e0 + 1]};
+        r0[nu] = pk_add(pk_add(m0, m1), m2);
+        r1[nu] = pk_sub(pk_sub(m1, m2), m3);
+      }
+      const f32x2 o0 = pk_add(pk_add(r0[0], r0[1]), r0[2]), o1 = pk_sub(pk_sub(r0[1], r0[2]), r0[3]);
+      const f32x2 o2 = pk_add(pk_add(r1[0], r1[1]), r1[2]), o3 = pk_sub(pk_sub(r1[1], r1[2]), r1[3]);
+      const int trow = e0 >> 2, ec = e0 & 3;
+      put(o0.x, trow, ec, 0, 0); put(o1.x, trow, ec, 0, 1); put(o2.x, trow, ec, 1, 0); put(o3.x, trow, ec, 1, 1);
+      put(o0.y, trow, ec + 1, 0, 0); put(o1.y, trow, ec + 1, 0, 1); put(o2.y, trow, ec + 1, 1, 0); put(o3.y, trow, ec + 1, 1, 1);
+    }
+  };
+  if (p.wide_store) {
+    char* const stg = smem3 + wave * VBUF;
+    const int st_w = lh * 1024 + li * 4;   // block pixel (oy, ox) = (2 trow + a, 8 lh + 2 ec + b) -> row oy*16 + ox
+    out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
+      *reinterpret_cast<float*>(stg + st_w + ((2 * trow + a) * 16 + 2 * ec + b) * 128) = v;
+    });
+#ifdef KFN_W3_EPI
+    KFN_STAMP(6);
+#endif
+    const int oxl = lane >> 3, nq = lane & 7;            // store lane: pixel column oxl (+8), channel quad nq
+    const unsigned voff_q = (unsigned)((oxl * p.ldy + n0 + nq * 4) * 4);
+    const bool q_ok = n0 + nq * 4 < p.Cout;
+    const int ox0 = 2 * cb * BW;
+    const unsigned voff_h[2] = {(q_ok && ox0 + oxl < p.W) ? voff_q : OOBV, (q_ok && ox0 + 8 + oxl < p.W) ? voff_q : OOBV};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + i * 1024 + lane * 16);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int trow = i >> 2, a = (i >> 1) & 1, hx = i & 1;
+      const int img_rel = trow < brk ? 0 : 1;
+      const int ty = trow < brk ? ty0 + trow : trow - brk;
+      const int oy = 2 * ty + a;
+      const bool row_ok = vr0 + trow < p.vrows && oy < p.H;        // uniform
+      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + ox0 + 8 * hx) * pix_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             rsY, row_ok ? voff_h[hx] : OOBV, soff, 0);
+    }
+  } else {
+    // Cout or the row pitch not a multiple of 4 floats: one dword per store
+    out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
+      const int img_rel = trow < brk ? 0 : 1;
+      const int ty = trow < brk ? ty0 + trow : trow - brk;
+      const int oy = 2 * ty + a;
+      v = relu ? fmaxf(v, 0.f) : v;
+      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 2 * ec + b) * pix_bytes);
+      const int tx = txl + ec;
+      const bool ok = n_ok && tx < p.Tw && 2 * tx + b < p.W && vr0 + trow < p.vrows && oy < p.H;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, ok ? voff_y : OOBV, soff, 0);
+    });
+  }
+  KFN_STAMP(4);
+#ifdef KFN_WINO3_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  KFN_STAMP(5);
+#endif
+}
+
+}  // namespace
+
+#ifdef KFN_WINO3_PROF
+unsigned long long* g_wino3_prof = nullptr;
+#endif
+
+namespace kfn {
+
+// Launch of the 4-wave form for a descriptor kfn_conv2d_winograd_fused has already validated
+// (Cin % 32 == 0, Cout >= 128).  Called from kfn_wino2.hip.
+int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed, const float* bias, float* y,
+                 hipStream_t stream) {
+  Wino3Args a;
+  a.x = x; a.u2 = u2_packed; a.bias = bias; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
+  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
+  a.Th = (d->H + 1) / 2; a.Tw = (d->W + 1) / 2;
+  const long vrows = (long)d->N * a.Th;
+  const long in_pix = (long)d->N * d->H * d->W;
+  a.vrows = (int)vrows;
+  a.bw = ceil_div(a.Tw, BW);
+  const long tiles_m = (long)a.bw * ceil_div(a.vrows, BH);
+  a.tiles_n = ceil_div(d->cout_pad, NT);
+  KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
+  a.tiles_m = (int)tiles_m;
+  a.relu = d->relu;
+  a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
+  a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
+  a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
+  a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * 4L);
+#ifdef KFN_WINO3_PROF
+  a.prof = g_wino3_prof;
+#endif
+  static std::atomic<uint64_t> attr_done{0};
+  {
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel), NVBUF * VBUF, attr_done);
+    if (rc != KFN_OK) return rc;
+  }
+  hipLaunchKernelGGL(wino3_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE), NVBUF * VBUF, stream, a);
+  KFN_LAUNCH_CHECK("wino3_kernel");
+  return KFN_OK;
+}
+
+}  // namespace kfn

@@ -470,7 +470,10 @@ def test_conv_f16x3_split_operands(case, config):
 # the last 2x2 tile overhangs, Cout not a multiple of 32, wide K
 FUSED_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (3, 12, 16, 64, 36),
                (2, 10, 6, 48, 64), (2, 30, 40, 64, 96), (5, 60, 80, 32, 32), (3, 9, 70, 16, 32),
-               (4, 14, 33, 32, 40), (1, 64, 96, 64, 64), (17, 10, 12, 16, 8), (2, 16, 30, 1024, 32)]
+               (4, 14, 33, 32, 40), (1, 64, 96, 64, 64), (17, 10, 12, 16, 8), (2, 16, 30, 1024, 32),
+               # >= 128 output channels and Cin % 32 == 0: the four-wave form (kfn_wino3.hip) -- ragged channel
+               # tiles (waves past Cout), blocks straddling two images, ragged tile blocks, many super-steps
+               (5, 30, 40, 64, 256), (3, 14, 33, 32, 192), (17, 10, 12, 32, 136), (2, 12, 16, 512, 128)]
 
 
 @pytest.mark.parametrize('relu', [1, 0])
