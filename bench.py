@@ -575,7 +575,8 @@ def main():
             'unit': 'TFLOP/s', 'frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'traffic': traffic,
             'algorithmic_tflops': round(tf, 2), 'algorithmic_frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': ('wino2_kernel = single-kernel Winograd F(2x2,3x3) (kfn_conv2d_winograd_fused, fp32): achieved = FLOPs the '
+            'note': ('wino3_kernel / wino2_kernel = single-kernel Winograd F(2x2,3x3) (kfn_conv2d_winograd_fused, fp32; four waves '
+                     'sharing one input transform through LDS / one wave per 32 output channels): achieved = FLOPs the '
                      'MFMAs execute (16/36 of the nominal direct-convolution FLOPs + tile-block padding) / time, algorithmic_* '
                      'counts the nominal FLOPs of SURVEY App. C and may exceed the MFMA peak; traffic = PMC HBM-side bytes per '
                      'launch, averaged over the launches of a batch like avg_launch_ms. conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,'

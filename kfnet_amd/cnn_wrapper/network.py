@@ -211,9 +211,8 @@ class Network(object):
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16X3))
             return y
         fmin = g.winograd_fused_min_channels
-        # (measured, 17-frame batch: the single-kernel form wins for Cin <= 512 -- conv1b 2.2 vs 3.3 ms direct,
-        #  conv2b 5.9 vs 7.0, conv3b 5.6 vs 5.9, conv6 0.70 vs 0.76 -- and ties at Cin = 1024, where the
-        #  two-kernel form's 128x256 tiles re-use the 64 MB of transformed weights better)
+        # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs
+        #  7.10, conv3b 5.05 vs 5.99, conv4b 4.93 vs 5.42, conv5 2.49 vs 2.73, conv6 0.63 vs 0.77)
         if (k == 3 and strides == 1 and g.winograd_fused and fmin and cin >= fmin and filters >= fmin
                 and cin <= g.winograd_fused_max_channels
                 and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters)):

@@ -366,7 +366,9 @@ class WinogradConvOp(ConvOp):
 
 class WinogradFusedConvOp(ConvOp):
     """3x3 stride-1 SAME conv through kfn_conv2d_winograd_fused: all 16 Winograd positions of a tile
-    block in one wavefront, input and output transforms in registers -- one launch, no workspace."""
+    block in registers, input and output transforms in the kernel -- one launch, no workspace.  The library
+    picks the form: four waves sharing one input transform through LDS (wino3_kernel, 128 output channels
+    per workgroup) when Cout >= 128 and Cin % 32 == 0, else one wave per 32 output channels (wino2_kernel)."""
 
     def __init__(self, name, x, y, kernel, bias, relu):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
@@ -376,16 +378,24 @@ class WinogradFusedConvOp(ConvOp):
         n, h, w, _ = x_shape
         return cin % 16 == 0 and (h + 1) // 2 >= 4
 
+    def four_wave(self):
+        """Mirror of the routing rule in kfn_conv2d_winograd_fused (kfn_wino2.hip)."""
+        return self.y.shape[3] >= 128 and self.x.shape[3] % 32 == 0
+
     def kernel_name(self, lib):
-        return 'wino2_kernel'
+        return 'wino3_kernel' if self.four_wave() else 'wino2_kernel'
 
     def mfma_flops(self):
-        """FLOPs the MFMAs execute: 16 positions x (tile blocks padded to 8x4 tiles, batch rows packed)."""
+        """FLOPs the MFMAs execute: 16 positions x (tile blocks padded to 8x4 tiles, batch rows packed) x
+        output channels padded to the workgroup's column block."""
         n, ho, wo, cout = self.y.shape
         n = _scaled(n, self.x.graph)
         th, tw = (ho + 1) // 2, (wo + 1) // 2
         tiles = (-(-tw // 8) * 8) * (-(-(n * th) // 4) * 4)
-        return 2.0 * 16 * tiles * (-(-cout // 32) * 32) * self.x.shape[3]
+        cpad = -(-cout // 32) * 32
+        if self.four_wave():
+            cpad = -(-cpad // 128) * 128
+        return 2.0 * 16 * tiles * cpad * self.x.shape[3]
 
     def launch(self, lib, stream, phases=3):
         d = self.desc()
@@ -703,7 +713,7 @@ class Graph(object):
         # cannot take (Cin % 16, fewer than 4 tile rows) fall back to the two-kernel form above
         self.winograd_fused = True
         self.winograd_fused_min_channels = 64
-        self.winograd_fused_max_channels = 512
+        self.winograd_fused_max_channels = 1024
         # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
         # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
         self.factor_cost_volume = True
