@@ -148,6 +148,18 @@ int kfn_winograd_fused_supported(const kfn_conv_desc* desc);
 int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const float* u2_packed,
                               const float* bias, float* y, void* stream);
 
+/* 3x3 STRIDE-2 'same' convolution of an image with even H and W (tf.layers.conv2d(3, strides=2, 'same'),
+ * cnn_wrapper/network.py:116-135: SCoordNet conv2a / conv3a / conv4a, cnn_wrapper/SCoordNet.py:12-27) by
+ * polyphase decomposition + F(2,2) minimal filtering: 25 instead of 36 multiplies per 2x2 outputs, one launch,
+ * no workspace (csrc/kfn_wino_s2.hip).  u2_packed = the 16 pre-transformed, pre-signed weight fragments
+ * [Cin/8][16][cout_pad][8] (fragments 0-8: G g00 G^T of the taps w[2a][2b]; 9-11: G (w[0][1], w[2][1]);
+ * 12-14: G (w[1][0], w[1][2]); 15: w[1][1]; the fragments of Winograd index 2 negated) -- kfnet_amd.graph.
+ * pack_winograd_s2_kernel.  Needs Cin % 16 == 0, H and W even, H >= 14, cout_pad % 32 == 0, fp32 operands, no
+ * fused head epilogue (kfn_winograd_s2_supported() == 1); KFN_ERR_UNSUPPORTED otherwise. */
+int kfn_winograd_s2_supported(const kfn_conv_desc* desc);
+int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const float* u2_packed, const float* bias,
+                           float* y, void* stream);
+
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
  * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature
  * tower's preprocess + feat1 (KFNet/KFNet.py:317-320) in ONE pass over the image.

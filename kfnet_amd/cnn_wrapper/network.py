@@ -12,9 +12,10 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp, as_f16,
+from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
+                     WinogradS2ConvOp, as_f16,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
-                     pack_winograd_fused_kernel, pack_winograd_kernel)
+                     pack_winograd_fused_kernel, pack_winograd_kernel, pack_winograd_s2_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -155,7 +156,7 @@ class Network(object):
         if len(hits) != 1:
             raise KeyError('set_epilogue: %d convolution launches are named %r' % (len(hits), layer_name))
         op = hits[0]
-        if isinstance(op, (WinogradConvOp, WinogradFusedConvOp)):
+        if isinstance(op, (WinogradConvOp, WinogradFusedConvOp, WinogradS2ConvOp)):
             if op.kernel.storage is not None:
                 raise RuntimeError('set_epilogue(%r): weights are already packed for the Winograd kernel' % layer_name)
             # in place (the op object may already sit in other launch lists): same tensors and
@@ -218,6 +219,13 @@ class Network(object):
                 and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_fused_kernel)
             self._emit(WinogradFusedConvOp(name, input, y, kern, bias, relu))
+            return y
+        smin = g.winograd_s2_min_channels
+        # 3x3 stride-2 layers (SCoordNet conv2a / conv3a / conv4a): polyphase + F(2,2), 25/36 of the direct MFMAs
+        if (k == 3 and strides == 2 and smin and cin >= smin and filters >= 128
+                and WinogradS2ConvOp.supported(input.shape, cin, filters)):
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel)
+            self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu))
             return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):

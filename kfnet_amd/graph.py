@@ -239,6 +239,30 @@ def pack_winograd_fused_kernel(w):
     return np.ascontiguousarray(u.reshape(g, cp, ci // 8, 8).transpose(2, 0, 1, 3))
 
 
+def pack_winograd_s2_kernel(w):
+    """TF HWIO [3,3,Cin,Cout] -> the 16 weight fragments [Cin/8][16][cout_pad][8] of kfn_conv2d_winograd_s2
+    (3x3 stride-2 conv as four stride-1 polyphase filters under F(2,2), csrc/kfn_wino_s2.hip): with
+    G = [[1,0],[1,1],[0,1]] fragments 0-8 = (G g00 G^T)[xi][nu] of the 2x2 taps g00[a][b] = w[2a][2b], 9-11 =
+    G (w[0][1], w[2][1]), 12-14 = G (w[1][0], w[1][2]), 15 = w[1][1]; every Winograd index 2 carries a minus sign
+    (its output coefficient A^T[1][2] = -1 is folded into the weights so that positions can share accumulators)."""
+    w = np.asarray(w, np.float32)
+    kh, kw, ci, co = w.shape
+    assert kh == 3 and kw == 3 and ci % 8 == 0
+    G = np.array([[1, 0], [1, 1], [0, 1]], np.float32)
+    sg = np.array([1, 1, -1], np.float32)
+    u = np.zeros((16, ci, co), np.float32)
+    g00 = w[0::2, 0::2]                                        # [2,2,ci,co]
+    u00 = np.einsum('xa,abio,nb->xnio', G, g00, G)             # [3,3,ci,co]
+    u[0:9] = (u00 * sg[:, None, None, None] * sg[None, :, None, None]).reshape(9, ci, co)
+    u[9:12] = np.einsum('xa,aio->xio', G, w[0::2, 1]) * sg[:, None, None]
+    u[12:15] = np.einsum('nb,bio->nio', G, w[1, 0::2]) * sg[:, None, None]
+    u[15] = w[1, 1]
+    cp = -(-co // 32) * 32
+    out = np.zeros((16, cp, ci), np.float32)
+    out[:, :co, :] = u.transpose(0, 2, 1)
+    return np.ascontiguousarray(out.reshape(16, cp, ci // 8, 8).transpose(2, 0, 1, 3))
+
+
 def as_f16(pack):
     """Wrap a weight packer so that the packed matrix is stored as IEEE halfs (fp16-operand convs)."""
     def f(w):
@@ -402,6 +426,37 @@ class WinogradFusedConvOp(ConvOp):
         rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
                                            self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_winograd_fused[%s]' % self.name)
+
+
+class WinogradS2ConvOp(ConvOp):
+    """3x3 stride-2 SAME conv of an even-sized image through kfn_conv2d_winograd_s2 (polyphase + F(2,2):
+    25 MFMA streams into 9 accumulators per 2x2 outputs instead of 36 direct taps)."""
+
+    def __init__(self, name, x, y, kernel, bias, relu):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu)
+
+    @staticmethod
+    def supported(x_shape, cin, cout):
+        n, h, w, _ = x_shape
+        return cin % 16 == 0 and h % 2 == 0 and w % 2 == 0 and (h // 2 + 1) // 2 >= 4
+
+    def kernel_name(self, lib):
+        return 'wino_s2_kernel'
+
+    def mfma_flops(self):
+        """FLOPs the MFMAs execute: 25 products per 2x2-output tile and input channel, tile blocks padded to
+        8x4 tiles (batch rows packed), output channels padded to the workgroup's 128."""
+        n, ho, wo, cout = self.y.shape
+        n = _scaled(n, self.x.graph)
+        th, tw = (ho + 1) // 2, (wo + 1) // 2
+        tiles = (-(-tw // 8) * 8) * (-(-(n * th) // 4) * 4)
+        return 2.0 * 25 * tiles * (-(-cout // 128) * 128) * self.x.shape[3]
+
+    def launch(self, lib, stream, phases=3):
+        d = self.desc()
+        rc = lib.kfn_conv2d_winograd_s2(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                        self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        _lib.check(rc, 'kfn_conv2d_winograd_s2[%s]' % self.name)
 
 
 class FirstConvOp(Op):
@@ -714,6 +769,9 @@ class Graph(object):
         self.winograd_fused = True
         self.winograd_fused_min_channels = 64
         self.winograd_fused_max_channels = 1024
+        # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
+        # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM
+        self.winograd_s2_min_channels = 64
         # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
         # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
         self.factor_cost_volume = True

@@ -509,6 +509,77 @@ def test_winograd_fused_vs_oracle(case, relu):
     assert err <= 3 * _conv_tol(x, wt), err
 
 
+# kfn_conv2d_winograd_s2 (3x3 stride 2, even images): blocks straddling images (Th % 4 != 0), odd output sizes
+# where the last 2x2 tile overhangs, ragged tile blocks and channel tiles, strided output, many super-steps
+S2_CASES = [(1, 16, 16, 16, 128), (2, 14, 18, 32, 160), (1, 120, 160, 64, 128), (3, 30, 34, 48, 36),
+            (5, 20, 24, 16, 8), (2, 60, 80, 256, 256), (17, 14, 16, 32, 136), (1, 64, 96, 512, 128)]
+
+
+@pytest.mark.parametrize('relu', [1, 0])
+@pytest.mark.parametrize('case', S2_CASES)
+def test_winograd_s2_vs_oracle(case, relu):
+    """kfn_conv2d_winograd_s2 (polyphase + F(2,2): 25 MFMA streams into 9 accumulators per 2x2 outputs) == the
+    oracle's stride-2 SAME convolution up to fp32 round-off; strided output window, guard rows untouched."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_s2_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    ho, wo = h // 2, w // 2
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 9)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy = co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=2, relu=relu)
+    assert lib.kfn_winograd_s2_supported(C.byref(d)) == 1
+    GUARD = 64
+    y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_s2_kernel(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                          stream()), 'wino_s2')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, co:] == -5.0) and np.all(got[n * ho * wo:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 2, bool(relu))
+    assert ref.shape == (n, ho, wo, co)
+    err = np.abs(got[:n * ho * wo, :co].reshape(ref.shape) - ref).max()
+    assert err <= 3 * _conv_tol(x, wt), err
+
+
+def test_winograd_s2_strided_input_and_unsupported_shapes():
+    """Input inside a wider buffer (ldx > Cin) and the shapes the polyphase kernel declines (odd sizes -- TF then
+    pads before the image too --, stride 1, Cin % 16, too few tile rows)."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_s2_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(78)
+    n, h, w, ci, co, ldx, off = 2, 16, 20, 32, 128, 48, 8
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    xb = np.full((n * h * w, ldx), 9.0, np.float32)
+    xb[:, off:off + ci] = x.reshape(-1, ci)
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=128, ldy=co, kh=3, kw=3, stride=2, relu=0)
+    dxb = dev(xb)
+    y = torch.zeros((n * (h // 2) * (w // 2), co), device='cuda')
+    _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dxb.data_ptr() + off * 4, dev(pack_winograd_s2_kernel(wt)).data_ptr(),
+                                          None, y.data_ptr(), stream()), 'wino_s2 strided')
+    sync()
+    ref = O.conv2d_same(x.astype(np.float64), wt, None, 2, False)
+    assert np.abs(y.cpu().numpy().reshape(ref.shape) - ref).max() <= 3 * _conv_tol(x, wt)
+    for bad in (dict(H=15), dict(W=19), dict(stride=1), dict(Cin=24, ldx=24), dict(H=12)):
+        kw = dict(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=128, ldy=co, kh=3, kw=3, stride=2, relu=0)
+        kw.update(bad)
+        db_ = _lib.ConvDesc(**kw)
+        assert lib.kfn_winograd_s2_supported(C.byref(db_)) == 0
+        rc = lib.kfn_conv2d_winograd_s2(C.byref(db_), dxb.data_ptr(), dxb.data_ptr(), None, y.data_ptr(), stream())
+        assert rc in (-3, -1), rc     # KFN_ERR_UNSUPPORTED / KFN_ERR_ARG
+
+
 def test_winograd_fused_strided_input_and_unsupported_shapes():
     """Input living in a wider buffer (ldx > Cin, the concat case) and the shapes the single-kernel path
     declines (Cin % 16, fewer than 4 tile rows): the host must be told, not handed wrong numbers."""

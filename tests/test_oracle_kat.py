@@ -201,3 +201,63 @@ def test_cost_volume_factorisation_identity():
                     g = Gp[a, bb, k * co:(k + 1) * co] if 0 <= a < H + 4 and 0 <= bb < W + 4 else 0.0
                     got[y, x, ci, cj] = T[y, x, k * co:(k + 1) * co] - g
     assert np.abs(got - ref).max() < 1e-5     # the class kernels are stored in fp32
+
+
+def test_polyphase_f22_stride2_identity():
+    """The algebra behind kfn_conv2d_winograd_s2 (csrc/kfn_wino_s2.hip), checked on the CPU against the oracle's
+    own stride-2 convolution with the weight fragments kfnet_amd.graph.pack_winograd_s2_kernel produces: the four
+    polyphase filters under F(2,2) (25 products per 2x2 outputs) accumulated into NINE accumulators
+    (D00 D01 D10 D11 | R0 R1 | C0 C1 | Z) and Y00 = D00+R0+C0+Z, Y01 = D01+R0+C1+Z, Y10 = D10+R1+C0+Z,
+    Y11 = D11+R1+C1+Z.  Slot / fragment / accumulator tables as in the kernel."""
+    from kfnet_amd.graph import pack_winograd_s2_kernel
+    rng = np.random.default_rng(11)
+    n, H, W, ci, co = 2, 8, 12, 8, 5
+    x = rng.normal(size=(n, H, W, ci))
+    wt = rng.normal(size=(3, 3, ci, co)).astype(np.float32)
+    b = rng.normal(size=co)
+    ref = O.conv2d_same(x, wt.astype(np.float64), b, 2, False)
+    u = pack_winograd_s2_kernel(wt)                                  # [ci/8][16][cout_pad][8]
+    U = u.transpose(1, 0, 3, 2).reshape(16, ci, u.shape[2])[:, :, :co].astype(np.float64)   # [frag][ci][co]
+    D00, D01, D10, D11, R0, R1, C0, C1, Z = range(9)
+    POS_SLOT = [0, 2, 6, 8, 20, 13, 14, 17, 18, 23, 19, 21, 22, 24, 15, 9, 10, 11, 12, 16, 4, 1, 7, 3, 5]
+    POS_FRAG = [0, 2, 6, 8, 13, 9, 9, 11, 11, 13, 12, 14, 12, 14, 10, 15, 15, 15, 15, 10, 4, 1, 7, 3, 5]
+    POS_ACC = [D00, D01, D10, D11, R0, D00, D01, D10, D11, R1, D00, D01, D10, D11, C0, D00, D01, D10, D11, C1,
+               Z, R0, R1, C0, C1]
+    bt = lambda d0, d1, d2: (d0 - d1, d1, d1 - d2)
+    xp = np.pad(x, ((0, 0), (0, 4), (0, 4), (0, 0)))                 # zeros after the image
+    got = np.zeros_like(ref)
+    for im in range(n):
+        for ty in range((H // 2 + 1) // 2):
+            for tx in range((W // 2 + 1) // 2):
+                d = xp[im, 4 * ty:4 * ty + 5, 4 * tx:4 * tx + 5]     # 5x5 patch
+                slot = [None] * 25
+                e = [[d[2 * m, 2 * k] for k in range(3)] for m in range(3)]          # (even,even): B^T e B
+                e = [list(bt(*row)) for row in e]
+                cols = [bt(e[0][k], e[1][k], e[2][k]) for k in range(3)]
+                for m in range(3):
+                    for k in range(3):
+                        slot[3 * m + k] = cols[k][m]
+                for m in range(2):                                                    # (odd,odd)
+                    for k in range(2):
+                        slot[9 + 2 * m + k] = d[2 * m + 1, 2 * k + 1]
+                for k in range(2):                                                    # (even,odd): along rows
+                    t = bt(d[0, 2 * k + 1], d[2, 2 * k + 1], d[4, 2 * k + 1])
+                    for m in range(3):
+                        slot[13 + 2 * m + k] = t[m]
+                for m in range(2):                                                    # (odd,even): along columns
+                    t = bt(d[2 * m + 1, 0], d[2 * m + 1, 2], d[2 * m + 1, 4])
+                    for k in range(3):
+                        slot[19 + 3 * m + k] = t[k]
+                acc = [np.zeros(co) for _ in range(9)]
+                for a in (D00, D01, D10, D11):
+                    acc[a] += b
+                for p in range(25):
+                    acc[POS_ACC[p]] += slot[POS_SLOT[p]] @ U[POS_FRAG[p]]
+                y = [[acc[D00] + acc[R0] + acc[C0] + acc[Z], acc[D01] + acc[R0] + acc[C1] + acc[Z]],
+                     [acc[D10] + acc[R1] + acc[C0] + acc[Z], acc[D11] + acc[R1] + acc[C1] + acc[Z]]]
+                for di in range(2):
+                    for dj in range(2):
+                        oy, ox = 2 * ty + di, 2 * tx + dj
+                        if oy < H // 2 and ox < W // 2:
+                            got[im, oy, ox] = y[di][dj]
+    assert np.abs(got - ref).max() < 1e-5     # the fragments are stored in fp32

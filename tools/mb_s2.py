@@ -1,0 +1,28 @@
+"""Microbenchmark of SCoordNet's 3x3 stride-2 layers at the bench batch: the polyphase F(2,2) kernel
+(kfn_conv2d_winograd_s2, 25/36 of the nominal MFMAs) vs the direct implicit GEMM."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kfnet_amd import _lib
+lib = _lib.load()
+st = torch.cuda.current_stream().cuda_stream
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+N = int(os.environ.get('MB_BATCH', '16'))
+for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320, 256, 512), ('conv4a', 120, 160, 512, 1024)]:
+    x = torch.randn(N * H * W * ci, device='cuda')
+    u = torch.randn(16 * co * ci, device='cuda') * 0.02
+    w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
+    y = torch.empty(N * (H // 2) * (W // 2) * co, device='cuda')
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1)
+    t_s2 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 's2'))
+    t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
+    nominal = 2.0 * N * (H // 2) * (W // 2) * 9 * ci * co
+    print('%-7s %3dx%3d C%4d->%4d: polyphase %.3f ms (%.1f TF executed, %.1f nominal) | direct %.3f ms (%.1f TF)'
+          % (name, H, W, ci, co, t_s2, nominal * 25 / 36 / t_s2 / 1e9, nominal / t_s2 / 1e9, t_dir, nominal / t_dir / 1e9), flush=True)
+    del x, u, y, w9
