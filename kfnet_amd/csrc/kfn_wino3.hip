@@ -22,6 +22,11 @@
 //     but the ring is 16 deep (one whole chunk ahead): the V registers of wino2 are gone.
 #include "kfn_common.h"
 #include <type_traits>
+#include <cstdlib>
+
+#ifndef KFN_WINO_DEFAULT_N_FAST
+#define KFN_WINO_DEFAULT_N_FAST 0   // measured (KFN_WINO_ORDER=0/1): 2.9 vs 4.8 GB fetched per launch, conv4b 4.59 vs 4.72 ms
+#endif
 
 namespace {
 
@@ -62,6 +67,7 @@ struct Wino3Args {
   int bw;
   int tiles_m, tiles_n;
   int relu;
+  int n_fast;          // workgroup order: channel groups of a tile block adjacent (1) or M fastest (0)
   int wide_store;     // Cout, ldy multiples of 4 and y 16-byte aligned: 16-byte stores of the transposed block
   unsigned long long x_bytes;
   unsigned long long y_bytes;
@@ -150,8 +156,11 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
 #endif
   const int nwg = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap3(blockIdx.x, nwg);
-  const int tm = tile % p.tiles_m;          // M fastest
-  const int tn = tile / p.tiles_m;
+  // Workgroups that run side by side on an XCD share its L2.  n_fast: the Cout/128 channel groups of one tile
+  // block are neighbours (the input crosses HBM once, every group's weights are live at once); else M fastest
+  // (one channel group's weights stay hot, the input is fetched once per channel group).
+  const int tm = p.n_fast ? tile / p.tiles_n : tile % p.tiles_m;
+  const int tn = p.n_fast ? tile % p.tiles_n : tile / p.tiles_m;
   const int cb = tm % p.bw, rb = tm / p.bw;
   const int n0 = tn * NT + wave * 32;       // this wave's 32 output channels
 
@@ -430,6 +439,10 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed,
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
+  {
+    static const int order = getenv("KFN_WINO_ORDER") ? atoi(getenv("KFN_WINO_ORDER")) : -1;
+    a.n_fast = order >= 0 ? order : KFN_WINO_DEFAULT_N_FAST;
+  }
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);

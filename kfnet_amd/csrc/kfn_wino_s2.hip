@@ -33,6 +33,11 @@
 // chunk buffers of [26 slots][2 k-halves][32 tiles][4 floats] (117 KiB).
 #include "kfn_common.h"
 #include <type_traits>
+#include <cstdlib>
+
+#ifndef KFN_WINO_DEFAULT_N_FAST
+#define KFN_WINO_DEFAULT_N_FAST 1   // measured (KFN_WINO_ORDER=0/1): 3.8 vs 4.8 GB fetched per launch, same time
+#endif
 
 namespace {
 
@@ -86,6 +91,7 @@ struct WinoS2Args {
   int bw;
   int tiles_m, tiles_n;
   int relu;
+  int n_fast;          // workgroup order: channel groups of a tile block adjacent (1) or M fastest (0)
   int wide_store;
   unsigned long long x_bytes;
   unsigned long long y_bytes;
@@ -127,8 +133,11 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nwg = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap_s2(blockIdx.x, nwg);
-  const int tm = tile % p.tiles_m;          // M fastest
-  const int tn = tile / p.tiles_m;
+  // Workgroups that run side by side on an XCD share its L2.  n_fast: the Cout/128 channel groups of one tile
+  // block are neighbours (the input crosses HBM once, every group's weights are live at once); else M fastest
+  // (one channel group's weights stay hot, the input is fetched once per channel group).
+  const int tm = p.n_fast ? tile / p.tiles_n : tile % p.tiles_m;
+  const int tn = p.n_fast ? tile % p.tiles_n : tile / p.tiles_m;
   const int cb = tm % p.bw, rb = tm / p.bw;
   const int n0 = tn * NT + wave * 32;
 
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   // (2i, 2i+1) of pixel i; every line is (d0,d1,d2) -> (d0-d1, d1, d1-d2).  EXEC is all ones before and after.
   auto p_transform = [&]() __attribute__((always_inline)) {
     asm volatile(
-      "s_mov_b64 exec, 0xffffffff\n\t"
+      "s_mov_b32 exec_hi, 0\n\t"
       "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %4, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %1, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
       "v_pk_add_f32 %16, %10, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %5, %5, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %17, %11, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "s_mov_b64 exec, 0xffffffff00000000\n\t"
+      "s_mov_b32 exec_lo, 0\n\t"
+      "s_mov_b32 exec_hi, -1\n\t"
       "v_pk_add_f32 %0, %0, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %8, %4, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %1, %1, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
       "v_pk_add_f32 %22, %20, %22 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %19, %19, %21 neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %23, %21, %23 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-      "s_mov_b64 exec, -1\n\t"
+      "s_mov_b32 exec_lo, -1\n\t"
       : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15]), "+v"(pv[16]), "+v"(pv[17]), "+v"(pv[18]), "+v"(pv[19]), "+v"(pv[20]), "+v"(pv[21]), "+v"(pv[22]), "+v"(pv[23]), "+v"(pv[24]), "+v"(pv[25]));
   };
   auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
@@ -432,6 +442,10 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_s2: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
+  {
+    static const int order = getenv("KFN_WINO_ORDER") ? atoi(getenv("KFN_WINO_ORDER")) : -1;
+    a.n_fast = order >= 0 ? order : KFN_WINO_DEFAULT_N_FAST;
+  }
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   const long in_pix = (long)d->N * d->H * d->W, out_pix = (long)d->N * a.Ho * a.Wo;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
