@@ -211,6 +211,15 @@ int kfn_flow_softargmax(const float* logits, float* flow_xy, float* prob, int P,
 int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow_xy,
                   float* opt_logits, int P, int C, void* stream);
 
+/* OFlowNet's tail for every window in ONE launch: conv6 (3x3, 48 -> 16, ReLU; cnn_wrapper/OFlowNet.py:36-40) on
+ * x = concat0 [P,8,8,48], the 'prediction' conv (3x3, 16 -> 1, linear; OFlowNet.py:41), the softmax over the 64
+ * cells (OFlowNet.py:45-47) and the soft-argmax flow (KFNet/KFNet.py:381-385) -> flow_xy [P,2] (and the 64 logits
+ * per window into opt_logits when given).  One wave per window, the patch resident in LDS, conv6's weights in
+ * registers (csrc/kfn_oflow_tail.hip).  w6_packed = [108][64] per-lane fragments (kfnet_amd.graph.
+ * pack_oflow_tail_kernel), wp = [3][3][16].  Only c_in = 48, c_mid = 16 (KFN_ERR_UNSUPPORTED otherwise). */
+int kfn_oflow_tail(const float* x, const float* w6_packed, const float* b6, const float* wp, const float* bp,
+                   float* flow_xy, float* opt_logits, int P, int c_in, int c_mid, void* stream);
+
 /* ---- the recurrent part: warp + Kalman predict/update + NIS + transform/emit ----------
  * One launch scans T frames of S independent sequences (one workgroup per sequence,
  * state resident in LDS when it fits).  Per frame and pixel, in this order:

@@ -12,8 +12,8 @@ Encoder 8x8 -> 4x4 -> 2x2 -> 1x1, decoder back up with skip concatenations:
     heads: softmax over the 64 'prediction' cells; fc1 (64) - fc2 (32) - uncertainty (1) on conv3b
 """
 from .. import _lib
-from ..graph import (ConvOp, FlowHeadOp, FlowOp, as_f16, pack_bias, pack_dense_kernel,
-                     pack_flow_head_kernel)
+from ..graph import (ConvOp, FlowHeadOp, FlowOp, OFlowTailOp, as_f16, pack_bias, pack_dense_kernel,
+                     pack_flow_head_kernel, pack_oflow_tail_kernel)
 from .network import Network
 
 # Program for Network: ('conv'|'deconv', name, channels, stride) or ('join', name, producer, skip)
@@ -87,7 +87,19 @@ class OFlowNet(Network):
             self.ops.remove(pred_op)
             kern = g.params[pred_op.kernel.name]
             kern.pack = pack_flow_head_kernel
-            self._emit(FlowHeadOp(x, kern, pred_op.bias, flow))
+            c6 = [op for op in self.ops if op.y is x and type(op) is ConvOp]
+            tail = (g.fuse_oflow_tail and len(c6) == 1 and c6[0].x.is_whole() and c6[0].x.shape[1:] == (8, 8, 48)
+                    and x.shape[3] == 16 and c6[0].kh == 3 and c6[0].stride == 1 and c6[0].relu
+                    and c6[0].operand_dtype == _lib.OPERAND_F32 and c6[0].kernel.storage is None)
+            if tail:
+                # conv6 too: its input patch stays in LDS, its output never exists in memory
+                g.ops.remove(c6[0])
+                self.ops.remove(c6[0])
+                k6 = g.params[c6[0].kernel.name]
+                k6.pack = pack_oflow_tail_kernel
+                self._emit(OFlowTailOp(c6[0].x, k6, c6[0].bias, kern, pred_op.bias, flow))
+            else:
+                self._emit(FlowHeadOp(x, kern, pred_op.bias, flow))
         else:
             self._emit(FlowOp(logits, flow, prob_map if g.debug_prob else None, window))
         prob_map.flow = flow

@@ -674,6 +674,41 @@ class FlowHeadOp(Op):
         _lib.check(rc, 'kfn_flow_head')
 
 
+def pack_oflow_tail_kernel(w):
+    """TF HWIO [3,3,48,16] (OFlowNet conv6) -> the per-lane weight fragments [108][64] of kfn_oflow_tail:
+    fragment t = tap*12 + j of lane (kq = lane // 16, n = lane % 16) is w[tap][kq*12 + j][n] (16x16x4 MFMA B
+    operand, K ordered so that a lane's 12 k-steps of a tap are 12 consecutive input channels)."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 48, 16)
+    wt = w.reshape(9, 4, 12, 16)                       # [tap][kq][j][n]
+    return np.ascontiguousarray(wt.transpose(0, 2, 1, 3).reshape(108, 64))
+
+
+class OFlowTailOp(Op):
+    """OFlowNet conv6 + 'prediction' conv + softmax + soft-argmax in one launch (kfn_oflow_tail): one wave per
+    window, the 8x8x48 patch resident in LDS, conv6's weights in registers."""
+
+    def __init__(self, x, k6, b6, kp, bpred, flow, logits=None):
+        self.name = 'oflow_tail[conv6+prediction+softargmax]'
+        self.x, self.k6, self.b6, self.kp, self.bpred, self.flow, self.logits = x, k6, b6, kp, bpred, flow, logits
+
+    def kernel_name(self, lib):
+        return 'oflow_tail_kernel'
+
+    def flops(self):
+        n, h, w, c = self.x.shape
+        return 2.0 * n * h * w * 9 * (c * 16 + 16)
+
+    def launch(self, lib, stream):
+        n, h, w, c = self.x.shape
+        assert h == 8 and w == 8 and self.x.is_whole()
+        P = _scaled(n, self.x.graph)
+        rc = lib.kfn_oflow_tail(self.x.ptr, self.k6.ptr, self.b6.ptr if self.b6 is not None else None, self.kp.ptr,
+                                self.bpred.ptr if self.bpred is not None else None, self.flow.ptr,
+                                self.logits.ptr if self.logits is not None else None, P, c, 16, stream)
+        _lib.check(rc, 'kfn_oflow_tail')
+
+
 class CopyChannelsOp(Op):
     def __init__(self, src, dst):
         self.name = 'copy_channels'
@@ -757,6 +792,7 @@ class Graph(object):
         self.device = None
         self.debug_prob = False
         self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
+        self.fuse_oflow_tail = True  # ... and conv6 in front of it (kfn_oflow_tail: the 8x8x48 patch stays in LDS)
         self.fuse_cost_volume = True  # BuildCoordVolume generated inside OFlowNet conv0's loader
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
         # (0 disables).  Below ~128 channels the [tiles][16][Cout] workspace traffic outweighs

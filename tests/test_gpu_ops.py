@@ -338,6 +338,45 @@ def test_flow_head_vs_oracle(Cc):
     assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 20 * tol
 
 
+@pytest.mark.parametrize('P', [1, 5, 1029, 3001])
+def test_oflow_tail_vs_oracle(P):
+    """kfn_oflow_tail (conv6 + prediction + softmax + soft-argmax, one wave per window, patch resident in LDS)
+    == the oracle's conv2d(relu) -> conv2d -> softmax -> offsets; window counts below / not a multiple of / far
+    above the number of resident waves."""
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_oflow_tail_kernel
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(31 + P)
+    x = np.maximum(rng.normal(size=(P, 8, 8, 48)), 0).astype(np.float32)
+    w6 = (rng.normal(size=(3, 3, 48, 16)) * np.sqrt(2.0 / (9 * 48))).astype(np.float32)
+    b6 = (rng.normal(size=16) * 0.1).astype(np.float32)
+    wp = (rng.normal(size=(3, 3, 16, 1)) * 0.5).astype(np.float32)
+    bp = np.array([0.3], np.float32)
+    flow = torch.zeros(P * 2, device='cuda')
+    logits = torch.zeros(P * 64, device='cuda')
+    dx, d6, db6, dwp, dbp = dev(x), dev(pack_oflow_tail_kernel(w6)), dev(b6), dev(wp[..., 0]), dev(bp)
+    _lib.check(lib.kfn_oflow_tail(dx.data_ptr(), d6.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(),
+                                  flow.data_ptr(), logits.data_ptr(), P, 48, 16, stream()), 'oflow_tail')
+    sync()
+    mid = O.conv2d_same(x.astype(np.float64), w6, b6, 1, True)
+    ref_logits = O.conv2d_same(mid, wp, bp, 1, False)[..., 0].reshape(P, 64)
+    pr = O.softmax(ref_logits)
+    offs = O.coord_volume(np.zeros((1, 2, 2, 1)), np.zeros((1, 2, 2, 1)), 8)[1]
+    tol = 6e-6 * max(1.0, float(np.abs(ref_logits).max()))
+    assert np.abs(logits.cpu().numpy().reshape(P, 64) - ref_logits).max() < tol
+    assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 20 * tol
+    # without the optional logits output, and a shape the kernel declines
+    flow2 = torch.zeros(P * 2, device='cuda')
+    _lib.check(lib.kfn_oflow_tail(dx.data_ptr(), d6.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(),
+                                  flow2.data_ptr(), None, P, 48, 16, stream()), 'oflow_tail')
+    sync()
+    assert torch.equal(flow, flow2)
+    assert lib.kfn_oflow_tail(dx.data_ptr(), d6.data_ptr(), None, dwp.data_ptr(), None, flow2.data_ptr(), None, P, 32, 16,
+                              stream()) == -3
+
+
 WINO_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (3, 12, 16, 64, 36),
               (1, 5, 5, 32, 4), (2, 10, 6, 48, 64)]
 
