@@ -142,10 +142,14 @@ int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* 
  * u2_packed = [Cin/8][16][cout_pad][8]: the (G g G^T)[xi][nu] of kfn_conv2d_winograd, re-packed so
  * that the 32-channel fragment of one (8-channel k-chunk, position) is one contiguous 1 KiB read:
  *   u2[((ci/8)*16 + 4*xi+nu)*cout_pad + co][ci%8].
- * Needs Cin % 16 == 0, (H+1)/2 >= 4, cout_pad % 32 == 0, fp32, no fused head epilogue
- * (kfn_winograd_fused_supported() == 1); KFN_ERR_UNSUPPORTED otherwise. */
+ * Needs Cin % 16 == 0, (H+1)/2 >= 4, cout_pad % 32 == 0, no fused head epilogue
+ * (kfn_winograd_fused_supported() == 1); KFN_ERR_UNSUPPORTED otherwise.  Layers with Cout >= 128 and
+ * Cin % 32 == 0 run in the four-wave form (csrc/kfn_wino3.hip: one input transform per 128 output channels,
+ * shared through LDS).  operand_dtype KFN_OPERAND_F16 (BASELINE config 5; four-wave form only, Cin % 64 == 0): u2_packed holds
+ * IEEE halfs in the same layout, the input transform runs in fp32 on the fp32 activations and is rounded to fp16
+ * when it is shared, the products are fp16 MFMAs with fp32 accumulation. */
 int kfn_winograd_fused_supported(const kfn_conv_desc* desc);
-int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const float* u2_packed,
+int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const void* u2_packed,
                               const float* bias, float* y, void* stream);
 
 /* 3x3 STRIDE-2 'same' convolution of an image with even H and W (tf.layers.conv2d(3, strides=2, 'same'),
@@ -154,10 +158,12 @@ int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const f
  * no workspace (csrc/kfn_wino_s2.hip).  u2_packed = the 16 pre-transformed, pre-signed weight fragments
  * [Cin/8][16][cout_pad][8] (fragments 0-8: G g00 G^T of the taps w[2a][2b]; 9-11: G (w[0][1], w[2][1]);
  * 12-14: G (w[1][0], w[1][2]); 15: w[1][1]; the fragments of Winograd index 2 negated) -- kfnet_amd.graph.
- * pack_winograd_s2_kernel.  Needs Cin % 16 == 0, H and W even, H >= 14, cout_pad % 32 == 0, fp32 operands, no
- * fused head epilogue (kfn_winograd_s2_supported() == 1); KFN_ERR_UNSUPPORTED otherwise. */
+ * pack_winograd_s2_kernel.  Needs Cin % 16 == 0, H and W even, H >= 14, cout_pad % 32 == 0, no fused head
+ * epilogue (kfn_winograd_s2_supported() == 1); KFN_ERR_UNSUPPORTED otherwise.  operand_dtype KFN_OPERAND_F16
+ * (BASELINE config 5): u2_packed holds IEEE halfs in the same layout, the input transform runs in fp32 and is
+ * rounded to fp16 when it is shared, fp16 MFMAs with fp32 accumulation. */
 int kfn_winograd_s2_supported(const kfn_conv_desc* desc);
-int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const float* u2_packed, const float* bias,
+int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void* u2_packed, const float* bias,
                            float* y, void* stream);
 
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------

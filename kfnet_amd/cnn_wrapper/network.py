@@ -203,6 +203,19 @@ class Network(object):
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
         wmin = g.winograd_min_channels
         f16 = g.conv_operands == 'f16' and cin % 32 == 0
+        if (f16 and k == 3 and strides == 1 and g.winograd_fused
+                and WinogradFusedConvOp.supported(input.shape, cin, filters, _lib.OPERAND_F16)):
+            # BASELINE config 5: the four-wave Winograd kernel on fp16 MFMAs (transform in fp32, V and U rounded to fp16)
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_fused_kernel))
+            self._emit(WinogradFusedConvOp(name, input, y, kern, bias, relu, operand_dtype=_lib.OPERAND_F16))
+            return y
+        # (the fp16 instantiation of the polyphase stride-2 kernel exists and is tested, but at fp16 MFMA rates it is
+        #  latency-bound and the direct fp16 kernel is faster: conv3a 1.20 vs 1.68 ms -- Graph.winograd_s2_f16 = False)
+        if (f16 and k == 3 and strides == 2 and g.winograd_s2_f16 and cin >= 64
+                and filters >= 128 and WinogradS2ConvOp.supported(input.shape, cin, filters)):
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_s2_kernel))
+            self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, operand_dtype=_lib.OPERAND_F16))
+            return y
         if f16:
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_conv_kernel))
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16))

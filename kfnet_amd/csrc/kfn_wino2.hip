@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
 }  // namespace
 
 namespace kfn {
-int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed, const float* bias, float* y,
-                 hipStream_t stream);   // kfn_wino3.hip: four waves share one input transform
+int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias, float* y,
+                 hipStream_t stream);   // kfn_wino3.hip: four waves share one input transform (fp32 or fp16 operands)
 }
 
 // Can the single-kernel path take this layer?  (host-side routing; no device access)
@@ -416,12 +416,15 @@ extern "C" int kfn_winograd_fused_supported(const kfn_conv_desc* d) {
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->transposed) return 0;
   if (d->Cin <= 0 || d->Cin % KS != 0) return 0;
   if ((d->H + 1) / 2 < BH) return 0;   // a 4-row tile block may straddle at most two images
-  if (d->epilogue != KFN_EPI_NONE || d->operand_dtype != KFN_OPERAND_F32) return 0;
+  if (d->epilogue != KFN_EPI_NONE) return 0;
   if (d->cout_pad % 32 != 0) return 0;
+  // fp16 operands (BASELINE config 5): the four-wave form only
+  if (d->operand_dtype == KFN_OPERAND_F16) return d->Cout >= 128 && d->Cin % 64 == 0;   // two super-steps per loop trip
+  if (d->operand_dtype != KFN_OPERAND_F32) return 0;
   return 1;
 }
 
-extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x, const float* u2_packed,
+extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x, const void* u2_packed,
                                          const float* bias, float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_fused: null argument");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed,
@@ -434,8 +437,11 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0 && d->Cout > 0 && d->ldy >= d->Cout &&
                   d->cout_pad >= d->Cout && d->cout_pad % 32 == 0,
               "kfn_conv2d_winograd_fused: bad strides / channel counts");
-  KFN_REQUIRE(d->epilogue == KFN_EPI_NONE && d->operand_dtype == KFN_OPERAND_F32,
-              "kfn_conv2d_winograd_fused: fp32, no fused head epilogue");
+  KFN_REQUIRE(d->epilogue == KFN_EPI_NONE && (d->operand_dtype == KFN_OPERAND_F32 || d->operand_dtype == KFN_OPERAND_F16),
+              "kfn_conv2d_winograd_fused: fp32 or fp16 operands, no fused head epilogue");
+  const bool h16 = d->operand_dtype == KFN_OPERAND_F16;
+  if (h16 && !(d->Cout >= 128 && d->Cin % 64 == 0))
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_fused: fp16 operands need Cout >= 128 and Cin %% 64 == 0");
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u2_packed)) & 15) == 0,
               "kfn_conv2d_winograd_fused: buffers must be 16-byte aligned");
   {
@@ -443,12 +449,13 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
     // channels, input read Cout/128 times); KFN_WINO_FORM=2 forces the one-wave form for A/B measurements
     static const int form = getenv("KFN_WINO_FORM") ? atoi(getenv("KFN_WINO_FORM")) : 0;
     const long img_b = (long)d->H * d->W * d->ldx * 4L;
-    if (form != 2 && d->Cout >= 128 && d->Cin % 32 == 0 && 2 * img_b < (1L << 31) &&
+    if ((form != 2 || h16) && d->Cout >= 128 && d->Cin % 32 == 0 && 2 * img_b < (1L << 31) &&
         2L * d->H * d->W * d->ldy * 4L < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31))
       return kfn::launch_wino3(d, x, u2_packed, bias, y, (hipStream_t)stream);
+    if (h16) return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_fused: image or kernel beyond 2 GiB of 32-bit offsets");
   }
   Wino2Args a;
-  a.x = x; a.u2 = u2_packed; a.bias = bias; a.y = y;
+  a.x = x; a.u2 = static_cast<const float*>(u2_packed); a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.Th = (d->H + 1) / 2; a.Tw = (d->W + 1) / 2;

@@ -41,9 +41,15 @@ constexpr int NT = 32 * NWAVE;          // output channels per workgroup
 // One chunk of V in LDS: [16 positions][2 k-halves][32 tiles][4 floats], padded so that the PRODUCER's stores
 // (8 consecutive lanes = the 8 channel quads of one tile = 4 chunks x 2 halves) fall on 8 different 16-byte bank
 // groups: half stride = 512 + 64, chunk stride = 16 positions + 16 bytes.
-constexpr int VHALF = 512 + 64;
-constexpr int VPOS = 2 * VHALF;
-constexpr int VBUF = 16 * VPOS + 16;
+// LDS layout of one chunk of V per operand precision H16 (0: fp32 fragments of 16 B, 1: fp16 fragments of 8 B).
+// The pads put the 8 (fp32) / 16 (fp16) lanes of one producer store group on different banks.
+template <bool H16> struct VLayout {
+  static constexpr int FRAG = H16 ? 8 : 16;                 // bytes a lane reads per position: 4 k-values
+  static constexpr int VHALF = H16 ? 256 + 16 : 512 + 64;   // [32 tiles][FRAG] + pad
+  static constexpr int VPOS = 2 * VHALF;                    // two k-halves
+  static constexpr int VBUF = 16 * VPOS + (H16 ? 32 : 16);  // 16 positions + pad
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int NVBUF = 8;                // two super-steps of 4 chunks
 constexpr int NBR = 16;                 // B ring = one chunk of positions ahead
 constexpr int NVR = 8;                  // V fragment ring (positions ahead inside a super-step)
@@ -144,8 +150,14 @@ __device__ __forceinline__ void bt_d_b(f32x2 (&v)[32]) {   // v[2*(4*r + c) + ha
     for (int h = 0; h < 2; ++h) bt_pass(v[2 * (0 + c) + h], v[2 * (4 + c) + h], v[2 * (8 + c) + h], v[2 * (12 + c) + h]);
 }
 
+// H16: BASELINE config 5's fp16-operand convolutions -- V is rounded to fp16 when it is stored to LDS (the input
+// transform itself runs in fp32 on the fp32 activations), U arrives as fp16, one v_mfma_f32_32x32x8_f16 per
+// (position, 8-channel chunk) replaces four v_mfma_f32_32x32x2_f32; accumulation, bias, output transform fp32.
+template <bool H16>
 __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];   // [NVBUF][VBUF]
+  constexpr int VHALF = VLayout<H16>::VHALF, VPOS = VLayout<H16>::VPOS, VBUF = VLayout<H16>::VBUF, FRAG = VLayout<H16>::FRAG;
+  using frag_t = std::conditional_t<H16, f32x2, f32x4>;   // one (position, chunk) fragment of a lane
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it in an SGPR
@@ -206,16 +218,16 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
     for (int c = 0; c < 4; ++c) gcol[c] = (unsigned)(((2 * tx - 1 + c) * p.ldx + cq * 8 + ph * 4) * 4);
   }
   // consumer fragment of position g: g*VPOS + half*VHALF + tile*16; the producer lane stores into chunk cq
-  const int v_lane = (lane >> 5) * VHALF + (lane & 31) * 16;
-  const int v_st = cq * VBUF + ph * VHALF + wave * 128 + tc * 16;
+  const int v_lane = (lane >> 5) * VHALF + (lane & 31) * FRAG;
+  const int v_st = cq * VBUF + ph * VHALF + wave * (8 * FRAG) + tc * FRAG;
   const int n_chunks = p.Cin / 8;
   const int n_super = n_chunks / 4;
   const int s_last = n_super - 1;
 
   // ---- this lane as a CONSUMER ---------------------------------------------------------------
   const int li = lane & 31, lh = lane >> 5;
-  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * 4);
-  const unsigned b_step = (unsigned)p.cout_pad * 32u;
+  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * (H16 ? 2 : 4));
+  const unsigned b_step = (unsigned)p.cout_pad * (H16 ? 16u : 32u);
   const int q_last = n_chunks * 16 - 1;
 
   const int n = n0 + li;
@@ -227,40 +239,57 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[g][e] = (g == 5) ? bv : 0.f;   // bias rides in position (1,1), cf. kfn_wino2.hip
 
-  f32x2 pv[32];        // producer: raw patch -> V of the chunk this wave produces
-  f32x4 bq[NBR];       // B ring
-  f32x4 vq[NVR];       // V fragment ring
+  // At fp16 MFMA rates a super-step is ~2 K cycles -- less than one HBM round trip and barely one L2 round trip --
+  // so the fp16 instantiation looks further ahead: raw patches are gathered TWO super-steps ahead into a second
+  // register buffer (transformed and stored one super-step later, when they have long arrived), and the B ring is
+  // two chunks deep.  (fp16 fragments are half the registers, which pays for both.)
+  constexpr int NPB = H16 ? 2 : 1;            // raw-patch register buffers
+  constexpr int NB = H16 ? 2 * NBR : NBR;     // B ring depth in fragments
+  f32x2 pv[NPB][32];   // producer: raw patch -> V of the tile row this wave produces
+  frag_t bq[NB];       // B ring
+  frag_t vq[NVR];      // V fragment ring
 
-  // producer steps for super-step `ss` (clamped past the end: chunks nobody will read)
-  auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
+  // producer steps for super-step `ss` (clamped past the end: chunks nobody will read), register buffer `pb`
+  auto p_gather = [&](auto ic, int ss, auto pb_) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value, pb = decltype(pb_)::value;
     constexpr int r = i >> 2, c = i & 3;
     const int sc = ss < s_last ? ss : s_last;
     const f32x4 q = bload(rs_row[r], gcol[c], (unsigned)(sc * 128));
-    pv[2 * i] = q.xy;
-    pv[2 * i + 1] = q.zw;
+    pv[pb][2 * i] = q.xy;
+    pv[pb][2 * i + 1] = q.zw;
   };
-  auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
-    constexpr int g = decltype(gc)::value;
-    const f32x4 q = {pv[2 * g].x, pv[2 * g].y, pv[2 * g + 1].x, pv[2 * g + 1].y};
-    *reinterpret_cast<f32x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+  auto p_store = [&](auto gc, int ss, auto pb_) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value, pb = decltype(pb_)::value;
+    if constexpr (H16) {
+      const f16x4 q = {(_Float16)pv[pb][2 * g].x, (_Float16)pv[pb][2 * g].y, (_Float16)pv[pb][2 * g + 1].x,
+                       (_Float16)pv[pb][2 * g + 1].y};   // RNE
+      *reinterpret_cast<f16x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+    } else {
+      const f32x4 q = {pv[pb][2 * g].x, pv[pb][2 * g].y, pv[pb][2 * g + 1].x, pv[pb][2 * g + 1].y};
+      *reinterpret_cast<f32x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+    }
   };
-  auto b_load = [&](auto gc, int qidx) __attribute__((always_inline)) {
-    constexpr int g = decltype(gc)::value;
+  // fragment qidx = chunk*16 + position into ring slot `sl`
+  auto b_load = [&](auto sl_, int qidx) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_)::value;
     const int qc = qidx < q_last ? qidx : q_last;
-    bq[g % NBR] = bload(rsU, voff_b, (unsigned)qc * b_step);
+    if constexpr (H16) bq[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsU, voff_b, (unsigned)qc * b_step, 0));
+    else bq[sl] = bload(rsU, voff_b, (unsigned)qc * b_step);
   };
   auto v_read = [&](auto gc, int ch) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
-    vq[g % NVR] = *reinterpret_cast<const f32x4*>(smem3 + (ch & (NVBUF - 1)) * VBUF + g * VPOS + v_lane);
+    vq[g % NVR] = *reinterpret_cast<const frag_t*>(smem3 + (ch & (NVBUF - 1)) * VBUF + g * VPOS + v_lane);
   };
 
   KFN_STAMP(1);
   // ---- prologue: every wave produces its tile row of super-step 0 -------------------------------
-  sfor<16>([&](auto ic) { p_gather(ic, 0); });
-  sfor<NBR>([&](auto gc) { b_load(gc, decltype(gc)::value); });
-  bt_d_b(pv);
-  sfor<16>([&](auto gc) { p_store(gc, 0); });
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  sfor<16>([&](auto ic) { p_gather(ic, 0, I0{}); });
+  sfor<NB>([&](auto gc) { b_load(gc, decltype(gc)::value); });
+  bt_d_b(pv[0]);
+  sfor<16>([&](auto gc) { p_store(gc, 0, I0{}); });
+  if constexpr (H16) sfor<16>([&](auto ic) { p_gather(ic, 1, I1{}); });   // super-step 1: transformed during super-step 0
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -272,61 +301,67 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
 #ifdef KFN_W3_TL
   unsigned long long tl[17];
 #endif
-  for (int ks = 0; ks < n_super; ++ks) {
+  // MFMA slots per chunk and the producer's schedule inside the 4-chunk super-step.  fp32: gather super-step ks+1
+  // early, transform late, store.  fp16: transform + store super-step ks+1 (gathered during ks-1) first, then gather
+  // ks+2 into the buffer that just became free.
+  constexpr int SPC = H16 ? 16 : 64;
+  constexpr int GSLOT = H16 ? 32 : 0, GSTEP = H16 ? 2 : KFN_W3_GSTEP, XSLOT = H16 ? 8 : KFN_W3_XSLOT;
+  constexpr int SSLOT = H16 ? 12 : KFN_W3_SSLOT, SSTEP = H16 ? 1 : KFN_W3_SSTEP;
+  auto super_step = [&](int ks, auto par_) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_)::value;        // fp16: ks & 1 = the buffer this super-step gathers into
+    using GB = std::integral_constant<int, par>;               // gather buffer
+    using XB = std::integral_constant<int, H16 ? par ^ 1 : 0>;  // transform / store buffer
     const int c0 = ks * 4;
-    const int pch = ks + 1;   // the super-step this wave produces its tile row of
+    const int g_ss = H16 ? ks + 2 : ks + 1;   // super-step being gathered
+    const int x_ss = ks + 1;                  // super-step being transformed and stored
     // the V fragments of the first NVR positions (nothing of this super-step could be read before the barrier)
-#ifndef KFN_W3_NOVREAD
     sfor<NVR>([&](auto gc) { v_read(gc, c0); });
-#endif
     sfor<4>([&](auto cc_) {
       constexpr int cc = decltype(cc_)::value;
       const int ch = c0 + cc;
       const int qbase = ch * 16;
-      sfor<64>([&](auto jc) {
+      sfor<SPC>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int g = (j >> 4) * 4 + (j & 3), t = (j >> 2) & 3;
+        // fp32: 4 interleaved positions x 4 k-steps of 32x32x2; fp16: one 32x32x8 per position
+        constexpr int g = H16 ? j : (j >> 4) * 4 + (j & 3), t = H16 ? 3 : (j >> 2) & 3;
+        constexpr int sl = (cc * 16 + g) % NB;     // B ring slot of fragment ch*16 + g (c0 is a multiple of 4)
 #ifdef KFN_W3_TL
-        if constexpr ((cc * 64 + j) % 16 == 0) tl[(cc * 64 + j) / 16] = __builtin_readcyclecounter();
+        if constexpr (!H16 && (cc * 64 + j) % 16 == 0) tl[(cc * 64 + j) / 16] = __builtin_readcyclecounter();
 #endif
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[g % NVR][t], bq[g % NBR][t], acc[g], 0, 0, 0);
+        if constexpr (H16)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4, vq[g % NVR]), __builtin_bit_cast(f16x4, bq[sl]), acc[g], 0, 0, 0);
+        else
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[g % NVR][t], bq[sl][t], acc[g], 0, 0, 0);
         if constexpr (t == 3) {
-#ifndef KFN_W3_NOBLOAD
-          b_load(std::integral_constant<int, g>{}, qbase + g + NBR);
-#endif
-#ifndef KFN_W3_NOVREAD
+          b_load(std::integral_constant<int, sl>{}, qbase + g + NB);
           // V fragment NVR positions ahead: same chunk, or the next chunk of THIS super-step
           if constexpr (g + NVR < 16) v_read(std::integral_constant<int, g + NVR>{}, ch);
           else if constexpr (cc < 3) v_read(std::integral_constant<int, g + NVR - 16>{}, ch + 1);
-#endif
         }
         // producer work, spread thin: the four waves of a CU share one texture addresser and one LDS port, and a
         // wave whose vector-memory instruction cannot issue stalls its MFMAs behind it
-        constexpr int sj = cc * 64 + j;   // slot inside the super-step
-#ifndef KFN_W3_NOGATHER
-        if constexpr (sj < 16 * KFN_W3_GSTEP && sj % KFN_W3_GSTEP == 0) p_gather(std::integral_constant<int, sj / KFN_W3_GSTEP>{}, pch);
-#endif
-#ifndef KFN_W3_NOXFORM
-        if constexpr (sj == KFN_W3_XSLOT) bt_d_b(pv);
-#endif
-#ifndef KFN_W3_NOSTORE
-        if constexpr (sj >= KFN_W3_SSLOT && sj < KFN_W3_SSLOT + 16 * KFN_W3_SSTEP && (sj - KFN_W3_SSLOT) % KFN_W3_SSTEP == 0)
-          p_store(std::integral_constant<int, (sj - KFN_W3_SSLOT) / KFN_W3_SSTEP>{}, pch);
-#endif
+        constexpr int sj = cc * SPC + j;   // slot inside the super-step
+        if constexpr (sj >= GSLOT && sj < GSLOT + 16 * GSTEP && (sj - GSLOT) % GSTEP == 0)
+          p_gather(std::integral_constant<int, (sj - GSLOT) / GSTEP>{}, g_ss, GB{});
+        if constexpr (sj == XSLOT) bt_d_b(pv[XB::value]);
+        if constexpr (sj >= SSLOT && sj < SSLOT + 16 * SSTEP && (sj - SSLOT) % SSTEP == 0)
+          p_store(std::integral_constant<int, (sj - SSLOT) / SSTEP>{}, x_ss, XB{});
         __builtin_amdgcn_sched_barrier(0);
       });
     });
-#ifndef KFN_W3_NOBAR
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#endif
+  };
+  if constexpr (H16) {
+    for (int ks = 0; ks < n_super; ks += 2) {   // n_super is even (Cin % 64 == 0): two super-steps per trip, one per buffer
+      super_step(ks, I0{});
+      super_step(ks + 1, I1{});
+    }
+  } else {
+    for (int ks = 0; ks < n_super; ++ks) super_step(ks, I0{});
   }
 
-#ifdef KFN_W3_NOSTORE
-#pragma unroll
-  for (int i = 0; i < 32; ++i) asm volatile("; keep %0" ::"v"(pv[i]));
-#endif
 #ifdef KFN_W3_TL
   tl[16] = __builtin_readcyclecounter();
 #pragma unroll
@@ -367,7 +402,7 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
     }
   };
   if (p.wide_store) {
-    char* const stg = smem3 + wave * VBUF;
+    char* const stg = smem3 + wave * (H16 ? 16384 : VBUF);   // 16 KiB per wave inside the idle V buffers
     const int st_w = lh * 1024 + li * 4;   // block pixel (oy, ox) = (2 trow + a, 8 lh + 2 ec + b) -> row oy*16 + ox
     out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
       *reinterpret_cast<float*>(stg + st_w + ((2 * trow + a) * 16 + 2 * ec + b) * 128) = v;
@@ -423,10 +458,11 @@ namespace kfn {
 
 // Launch of the 4-wave form for a descriptor kfn_conv2d_winograd_fused has already validated
 // (Cin % 32 == 0, Cout >= 128).  Called from kfn_wino2.hip.
-int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed, const float* bias, float* y,
+int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias, float* y,
                  hipStream_t stream) {
+  const bool h16 = d->operand_dtype == KFN_OPERAND_F16;
   Wino3Args a;
-  a.x = x; a.u2 = u2_packed; a.bias = bias; a.y = y;
+  a.x = x; a.u2 = static_cast<const float*>(u2_packed); a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.Th = (d->H + 1) / 2; a.Tw = (d->W + 1) / 2;
@@ -446,16 +482,25 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const float* u2_packed,
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
-  a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * 4L);
+  a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * (h16 ? 2L : 4L));
 #ifdef KFN_WINO3_PROF
   a.prof = g_wino3_prof;
 #endif
   static std::atomic<uint64_t> attr_done{0};
   {
-    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel), NVBUF * VBUF, attr_done);
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<false>), NVBUF * VLayout<false>::VBUF, attr_done);
     if (rc != KFN_OK) return rc;
   }
-  hipLaunchKernelGGL(wino3_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE), NVBUF * VBUF, stream, a);
+  if (h16) {
+    static std::atomic<uint64_t> attr_done16{0};
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<true>), NVBUF * VLayout<true>::VBUF, attr_done16);
+    if (rc != KFN_OK) return rc;
+    hipLaunchKernelGGL(wino3_kernel<true>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE), NVBUF * VLayout<true>::VBUF,
+                       stream, a);
+  } else {
+    hipLaunchKernelGGL(wino3_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE),
+                       NVBUF * VLayout<false>::VBUF, stream, a);
+  }
   KFN_LAUNCH_CHECK("wino3_kernel");
   return KFN_OK;
 }

@@ -53,9 +53,16 @@ constexpr int NPOS = 25;                // products per tile and channel
 constexpr int NSLOT = 26;               // LDS slots per chunk: 13 per producer half-wave
 constexpr int NFRAG = 16;               // distinct transformed-weight fragments per chunk
 constexpr int NACC = 9;
-constexpr int VHALF = 512 + 64;         // see kfn_wino3.hip: bank spreading of the producer's stores
-constexpr int VPOS = 2 * VHALF;
-constexpr int VBUF = NSLOT * VPOS + 32;   // + 32 B: the two chunks a producer 8-lane group writes land on different banks
+// LDS layout of one chunk of V per operand precision H16 (0: fp32 fragments of 16 B, 1: fp16 fragments of 8 B); the
+// pads spread the lanes of one producer store group (8 lanes x 16 B / 16 lanes x 8 B) over all banks, cf. kfn_wino3.hip
+template <bool H16> struct VLayoutS2 {
+  static constexpr int FRAG = H16 ? 8 : 16;
+  static constexpr int VHALF = H16 ? 256 + 32 : 512 + 64;
+  static constexpr int VPOS = 2 * VHALF;
+  static constexpr int VBUF = NSLOT * VPOS + (H16 ? 64 : 32);
+  static constexpr int LDS = 4 * VBUF > 65536 ? 4 * VBUF : 65536;   // the epilogue stages 4 x 16 KiB
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int NVBUF = 4;                // two super-steps of 2 chunks
 constexpr int SS_CH = 16;               // input channels per super-step
 
@@ -126,8 +133,15 @@ __device__ __forceinline__ f32x2 pk_add(const f32x2& a, const f32x2& b) {
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// H16: BASELINE config 5's fp16-operand convolutions -- the input transform runs in fp32 on the fp32 activations
+// and is rounded to fp16 when it is stored to LDS, the weight fragments arrive as fp16, one v_mfma_f32_32x32x8_f16
+// per (position, 8-channel chunk) replaces four v_mfma_f32_32x32x2_f32; accumulation and epilogue stay fp32.
+template <bool H16>
 __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem_s2[];   // [NVBUF][VBUF]
+  constexpr int VHALF = VLayoutS2<H16>::VHALF, VPOS = VLayoutS2<H16>::VPOS, VBUF = VLayoutS2<H16>::VBUF, FRAG = VLayoutS2<H16>::FRAG;
+  using frag_t = std::conditional_t<H16, f32x2, f32x4>;
+  constexpr int NVG = H16 ? 3 : 2;      // V fragment groups in flight
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -179,16 +193,16 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
     }
   }
   // LDS addresses: slot s of chunk c at c*VBUF + s*VPOS + half*VHALF + tile*16
-  const int v_lane = (lane >> 5) * VHALF + (lane & 31) * 16;                                  // consumer
-  const int v_st = (pq >> 1) * VBUF + ps * 13 * VPOS + (pq & 1) * VHALF + wave * 128 + tc * 16;   // producer
+  const int v_lane = (lane >> 5) * VHALF + (lane & 31) * FRAG;                                          // consumer
+  const int v_st = (pq >> 1) * VBUF + ps * 13 * VPOS + (pq & 1) * VHALF + wave * (8 * FRAG) + tc * FRAG;   // producer
   const int n_chunks = p.Cin / 8;
   const int n_super = n_chunks / 2;
   const int s_last = n_super - 1;
 
   // ---- this lane as a CONSUMER ---------------------------------------------------------------
   const int li = lane & 31, lh = lane >> 5;
-  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * 4);
-  const unsigned b_step = (unsigned)p.cout_pad * 32u;     // bytes between fragments
+  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * (H16 ? 2 : 4));
+  const unsigned b_step = (unsigned)p.cout_pad * (H16 ? 16u : 32u);     // bytes between fragments
   const int q_last = n_chunks * NFRAG - 1;
 
   const int n = n0 + li;
@@ -201,8 +215,8 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
     for (int e = 0; e < 16; ++e) acc[g][e] = (g <= D11) ? bv : 0.f;   // the bias rides in the four one-output accumulators
 
   f32x2 pv[26];          // producer: 13 patch pixels x 4 channels
-  f32x4 bq[NFRAG];       // weight fragments of the current chunk (reloaded for the next one after their last use)
-  f32x4 vq[2][5];        // V fragments: the group in flight and the next one
+  frag_t bq[NFRAG];      // weight fragments of the current chunk (reloaded for the next one after their last use)
+  frag_t vq[NVG][5];     // V fragments: the group in flight and the next one (fp16: the next two)
 
   auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
@@ -268,20 +282,26 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
     const f32x4 q = {pv[2 * g].x, pv[2 * g].y, pv[2 * g + 1].x, pv[2 * g + 1].y};
-    *reinterpret_cast<f32x4*>(smem_s2 + (ss & 1) * (2 * VBUF) + v_st + g * VPOS) = q;
+    if constexpr (H16) {
+      const f16x4 h = {(_Float16)q.x, (_Float16)q.y, (_Float16)q.z, (_Float16)q.w};   // RNE
+      *reinterpret_cast<f16x4*>(smem_s2 + (ss & 1) * (2 * VBUF) + v_st + g * VPOS) = h;
+    } else {
+      *reinterpret_cast<f32x4*>(smem_s2 + (ss & 1) * (2 * VBUF) + v_st + g * VPOS) = q;
+    }
   };
   auto b_load = [&](auto fc, int ch) __attribute__((always_inline)) {
     constexpr int f = decltype(fc)::value;
     const int qi = ch * NFRAG + f;
     const int qc = qi < q_last ? qi : q_last;
-    bq[f] = bload(rsU, voff_b, (unsigned)qc * b_step);
+    if constexpr (H16) bq[f] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsU, voff_b, (unsigned)qc * b_step, 0));
+    else bq[f] = bload(rsU, voff_b, (unsigned)qc * b_step);
   };
   // V fragment of position pp of chunk ch into half `hb` of the double buffer
   auto v_read = [&](auto pc, auto hb, int ch) __attribute__((always_inline)) {
     constexpr int pp = decltype(pc)::value;
     constexpr int slot = POS_SLOT[pp];
     vq[decltype(hb)::value][pp % 5] =
-        *reinterpret_cast<const f32x4*>(smem_s2 + (ch & (NVBUF - 1)) * VBUF + slot * VPOS + v_lane);
+        *reinterpret_cast<const frag_t*>(smem_s2 + (ch & (NVBUF - 1)) * VBUF + slot * VPOS + v_lane);
   };
 
   // ---- prologue: every wave produces its tile row of super-step 0 -------------------------------
@@ -293,34 +313,46 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // One super-step = chunks 2ks, 2ks+1: 2 x 100 MFMA slots.  Producer work for super-step ks+1: 13 gathers behind
-  // the first slots, the transform burst in the second chunk, the 13 stores after it; then the barrier.
+  // One super-step = chunks 2ks, 2ks+1: 2 x 100 MFMA slots (fp16: 2 x 25).  Producer work for super-step ks+1: 13
+  // gathers behind the first slots, the transform burst in the second chunk, the 13 stores after it; then the
+  // barrier.
+  constexpr int SPC = H16 ? 25 : 100;                       // MFMA slots per chunk
+  constexpr int GSTEP = H16 ? 2 : 8, XSLOT = H16 ? 36 : 150, SSLOT = H16 ? 37 : 160, SSTEP = H16 ? 1 : 2;
   for (int ks = 0; ks < n_super; ++ks) {
     const int nxt = ks + 1;
-    // group 0 of the first chunk: nothing of this super-step could be read before the barrier.  10 groups per
-    // super-step, so the double buffer is back at half 0 here.
+    // the first group(s) of the first chunk: nothing of this super-step could be read before the barrier.  10 groups
+    // per super-step; fp32 rotates 2 fragment buffers (back at 0 here), fp16 3 (restarted at 0 here).
     sfor<5>([&](auto pc) { v_read(pc, std::integral_constant<int, 0>{}, 2 * ks); });
+    if constexpr (H16) sfor<5>([&](auto pc) { v_read(std::integral_constant<int, 5 + decltype(pc)::value>{}, std::integral_constant<int, 1>{}, 2 * ks); });
     sfor<2>([&](auto cc_) {
       constexpr int cc = decltype(cc_)::value;
       const int ch = 2 * ks + cc;
-      sfor<100>([&](auto jc) {
+      sfor<SPC>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int G = j / 20, t = (j % 20) / 5, k = j % 5;
+        constexpr int G = H16 ? j / 5 : j / 20, t = H16 ? 3 : (j % 20) / 5, k = j % 5;
         constexpr int pp = G * 5 + k;
         constexpr int ia = POS_ACC[pp], ifr = POS_FRAG[pp];
-        constexpr int hb = (cc * 5 + G) & 1;      // half of the V double buffer this group reads
-        acc[ia] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[hb][k][t], bq[ifr][t], acc[ia], 0, 0, 0);
+        constexpr int gi = cc * 5 + G;            // group index inside the super-step
+        constexpr int hb = gi % NVG;              // fragment buffer this group reads
+        if constexpr (H16)
+          acc[ia] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4, vq[hb][k]), __builtin_bit_cast(f16x4, bq[ifr]), acc[ia], 0, 0, 0);
+        else
+          acc[ia] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[hb][k][t], bq[ifr][t], acc[ia], 0, 0, 0);
         // the next chunk's fragment, once this chunk is done with the registers
         if constexpr (t == 3 && last_user(pp)) b_load(std::integral_constant<int, ifr>{}, ch + 1);
-        // V of the next group (same chunk, or the second chunk of this super-step), during k-step 1
-        if constexpr (t == 1) {
+        // V of a later group (same chunk, or the second chunk of this super-step): fp32 the next group during
+        // k-step 1, fp16 the group after next right behind the MFMA that frees the buffer
+        if constexpr (H16) {
+          constexpr int tg = gi + 2;              // target group inside the super-step
+          if constexpr (tg < 10) v_read(std::integral_constant<int, (tg % 5) * 5 + k>{}, std::integral_constant<int, tg % NVG>{}, 2 * ks + tg / 5);
+        } else if constexpr (t == 1) {
           if constexpr (G < 4) v_read(std::integral_constant<int, (G + 1) * 5 + k>{}, std::integral_constant<int, hb ^ 1>{}, ch);
           else if constexpr (cc == 0) v_read(std::integral_constant<int, k>{}, std::integral_constant<int, hb ^ 1>{}, ch + 1);
         }
-        constexpr int sj = cc * 100 + j;   // slot inside the super-step
-        if constexpr (sj < 13 * 8 && sj % 8 == 0) p_gather(std::integral_constant<int, sj / 8>{}, nxt);
-        if constexpr (sj == 150) p_transform();
-        if constexpr (sj >= 160 && sj < 160 + 13 * 2 && (sj - 160) % 2 == 0) p_store(std::integral_constant<int, (sj - 160) / 2>{}, nxt);
+        constexpr int sj = cc * SPC + j;   // slot inside the super-step
+        if constexpr (sj < 13 * GSTEP && sj % GSTEP == 0) p_gather(std::integral_constant<int, sj / GSTEP>{}, nxt);
+        if constexpr (sj == XSLOT) p_transform();
+        if constexpr (sj >= SSLOT && sj < SSLOT + 13 * SSTEP && (sj - SSLOT) % SSTEP == 0) p_store(std::integral_constant<int, (sj - SSLOT) / SSTEP>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
       });
     });
@@ -400,12 +432,12 @@ extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
   if (d->H <= 0 || d->W <= 0 || (d->H & 1) || (d->W & 1)) return 0;     // 'same' pads after the image only
   if (d->Cin <= 0 || d->Cin % SS_CH != 0) return 0;
   if ((d->H / 2 + 1) / 2 < BH) return 0;   // a 4-row tile block may straddle at most two images
-  if (d->epilogue != KFN_EPI_NONE || d->operand_dtype != KFN_OPERAND_F32) return 0;
+  if (d->epilogue != KFN_EPI_NONE || (d->operand_dtype != KFN_OPERAND_F32 && d->operand_dtype != KFN_OPERAND_F16)) return 0;
   if (d->cout_pad % 32 != 0) return 0;
   return 1;
 }
 
-extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const float* u2_packed, const float* bias,
+extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias,
                                       float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 2 && !d->transposed,
@@ -420,8 +452,9 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0 && d->Cout > 0 && d->ldy >= d->Cout &&
                   d->cout_pad >= d->Cout && d->cout_pad % 32 == 0,
               "kfn_conv2d_winograd_s2: bad strides / channel counts");
-  KFN_REQUIRE(d->epilogue == KFN_EPI_NONE && d->operand_dtype == KFN_OPERAND_F32,
-              "kfn_conv2d_winograd_s2: fp32, no fused head epilogue");
+  KFN_REQUIRE(d->epilogue == KFN_EPI_NONE && (d->operand_dtype == KFN_OPERAND_F32 || d->operand_dtype == KFN_OPERAND_F16),
+              "kfn_conv2d_winograd_s2: fp32 or fp16 operands, no fused head epilogue");
+  const bool h16 = d->operand_dtype == KFN_OPERAND_F16;
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u2_packed)) & 15) == 0,
               "kfn_conv2d_winograd_s2: buffers must be 16-byte aligned");
   const long img_b = (long)d->H * d->W * d->ldx * 4L;
@@ -429,7 +462,7 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(2 * img_b < (1L << 31) && 2 * out_b < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31),
               "kfn_conv2d_winograd_s2: image or kernel beyond 2 GiB of 32-bit offsets");
   WinoS2Args a;
-  a.x = x; a.u2 = u2_packed; a.bias = bias; a.y = y;
+  a.x = x; a.u2 = static_cast<const float*>(u2_packed); a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.Ho = d->H / 2; a.Wo = d->W / 2;
@@ -450,14 +483,19 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   const long in_pix = (long)d->N * d->H * d->W, out_pix = (long)d->N * a.Ho * a.Wo;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((out_pix - 1) * d->ldy + d->Cout) * 4L);
-  a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * 4L);
-  static std::atomic<uint64_t> attr_done{0};
-  {
-    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2_kernel), NVBUF * VBUF, attr_done);
+  a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * (h16 ? 2L : 4L));
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(64 * NWAVE);
+  if (h16) {
+    static std::atomic<uint64_t> attr_done16{0};
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2_kernel<true>), VLayoutS2<true>::LDS, attr_done16);
     if (rc != KFN_OK) return rc;
+    hipLaunchKernelGGL(wino_s2_kernel<true>, grid, block, VLayoutS2<true>::LDS, (hipStream_t)stream, a);
+  } else {
+    static std::atomic<uint64_t> attr_done{0};
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2_kernel<false>), VLayoutS2<false>::LDS, attr_done);
+    if (rc != KFN_OK) return rc;
+    hipLaunchKernelGGL(wino_s2_kernel<false>, grid, block, VLayoutS2<false>::LDS, (hipStream_t)stream, a);
   }
-  hipLaunchKernelGGL(wino_s2_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE), NVBUF * VBUF,
-                     (hipStream_t)stream, a);
   KFN_LAUNCH_CHECK("wino_s2_kernel");
   return KFN_OK;
 }

@@ -394,12 +394,14 @@ class WinogradFusedConvOp(ConvOp):
     picks the form: four waves sharing one input transform through LDS (wino3_kernel, 128 output channels
     per workgroup) when Cout >= 128 and Cin % 32 == 0, else one wave per 32 output channels (wino2_kernel)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu):
-        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu, operand_dtype=operand_dtype)
 
     @staticmethod
-    def supported(x_shape, cin, cout):
+    def supported(x_shape, cin, cout, operand_dtype=_lib.OPERAND_F32):
         n, h, w, _ = x_shape
+        if operand_dtype == _lib.OPERAND_F16:      # fp16 operands: the four-wave form only
+            return cin % 64 == 0 and cout >= 128 and (h + 1) // 2 >= 4
         return cin % 16 == 0 and (h + 1) // 2 >= 4
 
     def four_wave(self):
@@ -407,6 +409,8 @@ class WinogradFusedConvOp(ConvOp):
         return self.y.shape[3] >= 128 and self.x.shape[3] % 32 == 0
 
     def kernel_name(self, lib):
+        if self.operand_dtype == _lib.OPERAND_F16:
+            return 'wino3_kernel<true>'
         return 'wino3_kernel' if self.four_wave() else 'wino2_kernel'
 
     def mfma_flops(self):
@@ -432,8 +436,8 @@ class WinogradS2ConvOp(ConvOp):
     """3x3 stride-2 SAME conv of an even-sized image through kfn_conv2d_winograd_s2 (polyphase + F(2,2):
     25 MFMA streams into 9 accumulators per 2x2 outputs instead of 36 direct taps)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu):
-        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu)
+    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu, operand_dtype=operand_dtype)
 
     @staticmethod
     def supported(x_shape, cin, cout):
@@ -441,7 +445,7 @@ class WinogradS2ConvOp(ConvOp):
         return cin % 16 == 0 and h % 2 == 0 and w % 2 == 0 and (h // 2 + 1) // 2 >= 4
 
     def kernel_name(self, lib):
-        return 'wino_s2_kernel'
+        return 'wino_s2_kernel<true>' if self.operand_dtype == _lib.OPERAND_F16 else 'wino_s2_kernel'
 
     def mfma_flops(self):
         """FLOPs the MFMAs execute: 25 products per 2x2-output tile and input channel, tile blocks padded to
@@ -808,6 +812,7 @@ class Graph(object):
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM
         self.winograd_s2_min_channels = 64
+        self.winograd_s2_f16 = False   # fp16-operand mode: stride-2 layers stay on the direct fp16 kernel (faster)
         # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
         # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
         self.factor_cost_volume = True

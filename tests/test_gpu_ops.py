@@ -588,6 +588,37 @@ def test_winograd_s2_vs_oracle(case, relu):
     assert err <= 3 * _conv_tol(x, wt), err
 
 
+@pytest.mark.parametrize('case', [(1, 16, 16, 16, 128), (2, 14, 18, 32, 160), (1, 120, 160, 64, 128), (2, 60, 80, 256, 256),
+                                  (17, 14, 16, 32, 136)])
+def test_winograd_s2_fp16_operands(case):
+    """kfn_conv2d_winograd_s2 with operand_dtype F16 (BASELINE config 5): transform in fp32, V and the weight
+    fragments rounded to fp16, fp16 MFMAs with fp32 accumulation -- within ~1 % of the output range of the exact
+    convolution, and measurably not the fp32 path."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import as_f16, pack_winograd_s2_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 12)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=co, kh=3, kw=3,
+                      stride=2, relu=1, operand_dtype=_lib.OPERAND_F16)
+    assert lib.kfn_winograd_s2_supported(C.byref(d)) == 1
+    y = torch.zeros((n * (h // 2) * (w // 2), co), device='cuda')
+    dx, du, db = dev(x), dev(as_f16(pack_winograd_s2_kernel)(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(), stream()),
+               'wino_s2 f16')
+    sync()
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 2, True)
+    err = np.abs(y.cpu().numpy().reshape(ref.shape) - ref).max()
+    scale = np.abs(ref).max()
+    print('wino_s2 f16: err %.3g, scale %.3g' % (err, scale))
+    assert 0 < err <= 1e-2 * max(1.0, scale), err
+
+
 def test_winograd_s2_strided_input_and_unsupported_shapes():
     """Input inside a wider buffer (ldx > Cin) and the shapes the polyphase kernel declines (odd sizes -- TF then
     pads before the image too --, stride 1, Cin % 16, too few tile rows)."""
@@ -617,6 +648,43 @@ def test_winograd_s2_strided_input_and_unsupported_shapes():
         assert lib.kfn_winograd_s2_supported(C.byref(db_)) == 0
         rc = lib.kfn_conv2d_winograd_s2(C.byref(db_), dxb.data_ptr(), dxb.data_ptr(), None, y.data_ptr(), stream())
         assert rc in (-3, -1), rc     # KFN_ERR_UNSUPPORTED / KFN_ERR_ARG
+
+
+@pytest.mark.parametrize('case', [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (5, 30, 40, 64, 256),
+                                  (17, 10, 12, 64, 136), (2, 12, 16, 512, 128)])
+def test_winograd_fused_fp16_operands(case):
+    """kfn_conv2d_winograd_fused with operand_dtype F16 (BASELINE config 5): V = B^T d B is formed in fp32 and
+    rounded to fp16 when shared, U is fp16, the products are fp16 MFMAs with fp32 accumulation.  Against the
+    fp64 convolution of the fp16-ROUNDED weights the error is that of rounding V (and of summing); against the
+    exact one it must stay inside the fp16-operand tolerance of the direct kernel's test, x2 for the transform."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import as_f16, pack_winograd_fused_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 6)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=co, kh=3, kw=3,
+                      stride=1, relu=1, operand_dtype=_lib.OPERAND_F16)
+    assert lib.kfn_winograd_fused_supported(C.byref(d)) == 1
+    y = torch.zeros((n * h * w, co), device='cuda')
+    dx, du, db = dev(x), dev(as_f16(pack_winograd_fused_kernel)(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                             stream()), 'wino3 f16')
+    sync()
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    err = np.abs(y.cpu().numpy().reshape(ref.shape) - ref).max()
+    scale = np.abs(ref).max()
+    print('wino3 f16: err %.3g, scale %.3g' % (err, scale))
+    assert 0 < err <= 1e-2 * max(1.0, scale), err        # reduced precision, and no worse than ~1 % of the output range
+    # and the shapes the fp16 path declines (one-wave form): told, not mis-computed
+    d2 = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1, relu=1,
+                       operand_dtype=_lib.OPERAND_F16)
+    assert lib.kfn_winograd_fused_supported(C.byref(d2)) == 0
+    assert lib.kfn_conv2d_winograd_fused(C.byref(d2), dx.data_ptr(), du.data_ptr(), None, y.data_ptr(), stream()) == -3
 
 
 def test_winograd_fused_strided_input_and_unsupported_shapes():

@@ -19,9 +19,13 @@ for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320,
     u = torch.randn(16 * co * ci, device='cuda') * 0.02
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     y = torch.empty(N * (H // 2) * (W // 2) * co, device='cuda')
+    F16 = os.environ.get('MB_F16', '') == '1'
     d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1)
-    t_s2 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 's2'))
-    t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
+    d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16)
+    if F16:
+        u = u.half(); w9 = w9.half()
+    t_s2 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d16 if F16 else d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 's2'))
+    t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d16 if F16 else d), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
     nominal = 2.0 * N * (H // 2) * (W // 2) * 9 * ci * co
     print('%-7s %3dx%3d C%4d->%4d: polyphase %.3f ms (%.1f TF executed, %.1f nominal) | direct %.3f ms (%.1f TF)'
           % (name, H, W, ci, co, t_s2, nominal * 25 / 36 / t_s2 / 1e9, nominal / t_s2 / 1e9, t_dir, nominal / t_dir / 1e9), flush=True)
