@@ -203,7 +203,9 @@ class Network(object):
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
         wmin = g.winograd_min_channels
         f16 = g.conv_operands == 'f16' and cin % 32 == 0
-        if (f16 and k == 3 and strides == 1 and g.winograd_fused
+        # (measured, 16 frames: conv3b 2.07 vs 2.31 ms direct fp16, conv4b 1.81 vs 2.59, conv5 1.00 vs 1.25; at
+        #  Cin = 256 the direct kernel is as fast -- conv2b 2.56 vs 2.48 -- and stays)
+        if (f16 and k == 3 and strides == 1 and g.winograd_fused and cin >= 512
                 and WinogradFusedConvOp.supported(input.shape, cin, filters, _lib.OPERAND_F16)):
             # BASELINE config 5: the four-wave Winograd kernel on fp16 MFMAs (transform in fp32, V and U rounded to fp16)
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_fused_kernel))

@@ -42,9 +42,12 @@ for (name, H, W, ci, co) in LAYERS:
         t_gemm = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 1, st), 'w'))
         t_out = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 2, st), 'w'))
         del ws
-    dd = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1)
+    dd = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1,
+                       operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32)
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
-    t_dir = float('nan') if FUSED_ONLY else timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(dd), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
+    if F16:
+        w9 = w9.half()
+    t_dir = float('nan') if (FUSED_ONLY and not F16) else timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(dd), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
     print('%-7s %3dx%3d C%4d->%4d: FUSED %.3f ms (%.1f TF exec) | two-kernel %.3f ms = gemm %.3f (%.1f TF exec) + out %.3f | direct %.3f ms (%.1f TF)'
           % (name, H, W, ci, co, t_fused, fl / t_fused / 1e9, t_gemm + t_out, t_gemm, fl / t_gemm / 1e9, t_out, t_dir, fl * 2.25 / t_dir / 1e9), flush=True)
     del x, u, y, w9
