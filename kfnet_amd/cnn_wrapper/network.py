@@ -13,9 +13,10 @@ import numpy as np
 
 from .. import _lib
 from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
-                     WinogradS2ConvOp, as_f16,
+                     WinogradS2ConvOp, WindowFcConvOp, as_f16,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
-                     pack_winograd_fused_kernel, pack_winograd_kernel, pack_winograd_s2_kernel)
+                     pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
+                     pack_winograd_s2_kernel)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -225,6 +226,13 @@ class Network(object):
         if g.conv_operands == 'f16x3' and cin % 32 == 0 and cin >= g.f16x3_min_channels:
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16x3(pack_conv_kernel))
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16X3))
+            return y
+        if (k == 3 and strides == 1 and h == 2 and w == 2 and g.window_fc and biased and cin % 8 == 0 and filters % 8 == 0
+                and g.conv_operands == 'f32'):
+            # OFlowNet's 2x2 level: dense window matrix (16 Cin Cout products per window instead of 36)
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_window_fc_kernel)
+            bias.pack = pack_bias_x4
+            self._emit(WindowFcConvOp(name, input, y, kern, bias, relu))
             return y
         fmin = g.winograd_fused_min_channels
         # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs

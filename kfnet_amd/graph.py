@@ -217,6 +217,30 @@ def pack_conv_kernel(w):
 _WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
 
 
+def pack_window_fc_kernel(w):
+    """TF HWIO [3,3,Cin,Cout] -> the same 3x3 SAME stride-1 convolution on a 2x2 image written as ONE dense matrix,
+    in the 1x1-kernel layout of pack_conv_kernel: row (q, o) x column (p, c) = w[py-qy+1, px-qx+1, c, o] with
+    p = 2 py + px the input pixel and q = 2 qy + qx the output pixel.  On a 2x2 image every input pixel reaches
+    every output pixel, so the matrix is dense: 16 Cin Cout products per window instead of the 36 Cin Cout the
+    nine-tap form spends (20 of them on zero padding)."""
+    w = np.asarray(w, np.float32)
+    kh, kw, ci, co = w.shape
+    assert kh == 3 and kw == 3
+    m = np.zeros((4 * co, 4 * ci), np.float32)
+    for q in range(4):
+        for p in range(4):
+            m[q * co:(q + 1) * co, p * ci:(p + 1) * ci] = w[(p >> 1) - (q >> 1) + 1, (p & 1) - (q & 1) + 1].T
+    cp = -(-(4 * co) // 32) * 32
+    out = np.zeros((cp, 4 * ci), np.float32)
+    out[:4 * co] = m
+    return out
+
+
+def pack_bias_x4(b):
+    """Bias of a layer run as a window matrix (pack_window_fc_kernel): one copy per output pixel."""
+    return np.tile(pack_bias(b), 4)
+
+
 def pack_winograd_kernel(w):
     """TF HWIO [3,3,Cin,Cout] -> U [16][cout_pad][Cin] with U[4*xi+nu] = (G g G^T)[xi][nu]
     (Winograd F(2x2,3x3) weight transform, evaluated in fp64, rounded once to fp32)."""
@@ -356,6 +380,39 @@ class ConvOp(Op):
         rc = lib.kfn_conv2d_nhwc(C.byref(d), self.x.ptr, self.kernel.ptr,
                                  self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_nhwc[%s]' % self.name)
+
+
+class WindowFcConvOp(ConvOp):
+    """3x3 stride-1 SAME conv on 2x2 images (OFlowNet's bottleneck level) as one dense [4 Cin] x [4 Cout] matrix per
+    window through the 1x1 path of kfn_conv2d_nhwc (pack_window_fc_kernel): 16/36 of the nine-tap form's MFMAs.
+    Needs both tensors pixel-contiguous; `resolve()` (called by Graph.finalize, after every concat has re-bound its
+    producers) falls back to the plain convolution otherwise."""
+
+    def __init__(self, name, x, y, kernel, bias, relu):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+
+    def resolve(self):
+        if self.x.ld == self.x.shape[3] and self.y.ld == self.y.shape[3]:
+            return
+        if self.kernel.storage is not None:
+            raise _lib.KfnError('%s: weights already packed as a window matrix' % self.name)
+        self.kernel.pack = pack_conv_kernel
+        if self.bias is not None:
+            self.bias.pack = pack_bias
+        self.__class__ = ConvOp
+
+    def desc(self):
+        n, h, w, cin = self.x.shape
+        cout = self.y.shape[3]
+        assert h == 2 and w == 2 and self.x.ld == cin and self.y.ld == cout
+        return _lib.ConvDesc(N=_scaled(n, self.x.graph), H=1, W=1, Cin=4 * cin, ldx=4 * cin, Cout=4 * cout,
+                             cout_pad=-(-(4 * cout) // 32) * 32, ldy=4 * cout, kh=1, kw=1, stride=1, transposed=0,
+                             relu=int(self.relu), epilogue=self.epilogue, config=self.config,
+                             operand_dtype=self.operand_dtype)
+
+    def mfma_flops(self):
+        n, h, w, cin = self.x.shape
+        return 2.0 * _scaled(n, self.x.graph) * (4 * cin) * (4 * self.y.shape[3])
 
 
 class WinogradConvOp(ConvOp):
@@ -812,7 +869,8 @@ class Graph(object):
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM
         self.winograd_s2_min_channels = 64
-        self.winograd_s2_f16 = False   # fp16-operand mode: stride-2 layers stay on the direct fp16 kernel (faster)
+        self.winograd_s2_f16 = False
+        self.window_fc = True   # 3x3 stride-1 layers on 2x2 images as one dense matrix per window (WindowFcConvOp)   # fp16-operand mode: stride-2 layers stay on the direct fp16 kernel (faster)
         # conv0 of OFlowNet by linearity: per-pixel class convolutions + a gather instead of a
         # 3x3 conv on every one of the 64 window cells (see kfn_cost_volume_gather)
         self.factor_cost_volume = True
@@ -867,6 +925,9 @@ class Graph(object):
                                 'gfx950 device (there is no CPU fallback)')
         _lib.load()
         self.device = torch.device(device)
+        for op in self.ops:          # routing decisions that depend on the final buffer bindings
+            if hasattr(op, 'resolve'):
+                op.resolve()
         for s in self.storages:
             s.allocate(self.device)
         return self

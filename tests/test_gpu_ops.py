@@ -377,6 +377,29 @@ def test_oflow_tail_vs_oracle(P):
                               stream()) == -3
 
 
+def test_window_fc_conv_on_2x2_windows():
+    """WindowFcConvOp's launch: a 3x3 SAME conv on [P,2,2,Cin] windows as the 1x1 convolution of [P,1,1,4 Cin] with
+    the dense window matrix (pack_window_fc_kernel) == the oracle's nine-tap convolution."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_bias_x4, pack_window_fc_kernel
+    lib = _lib.load()
+    rng = np.random.default_rng(44)
+    P, ci, co = 1037, 128, 64
+    x = np.maximum(rng.normal(size=(P, 2, 2, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    d = _lib.ConvDesc(N=P, H=1, W=1, Cin=4 * ci, ldx=4 * ci, Cout=4 * co, cout_pad=4 * co, ldy=4 * co, kh=1, kw=1,
+                      stride=1, relu=1)
+    y = torch.zeros((P, 4 * co), device='cuda')
+    dx, dw, db = dev(x), dev(pack_window_fc_kernel(wt)), dev(pack_bias_x4(b))
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(d), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), stream()), 'fc')
+    sync()
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    assert np.abs(y.cpu().numpy().reshape(ref.shape) - ref).max() <= 3 * _conv_tol(x, wt)
+
+
 WINO_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), (3, 12, 16, 64, 36),
               (1, 5, 5, 32, 4), (2, 10, 6, 48, 64)]
 

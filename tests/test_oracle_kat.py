@@ -261,3 +261,18 @@ def test_polyphase_f22_stride2_identity():
                         if oy < H // 2 and ox < W // 2:
                             got[im, oy, ox] = y[di][dj]
     assert np.abs(got - ref).max() < 1e-5     # the fragments are stored in fp32
+
+
+def test_window_fc_matrix_identity():
+    """pack_window_fc_kernel: a 3x3 SAME stride-1 convolution on 2x2 images equals one dense [4 Cin] x [4 Cout]
+    matrix per window (kfnet_amd.graph.WindowFcConvOp, OFlowNet's 2x2 level)."""
+    from kfnet_amd.graph import pack_bias_x4, pack_window_fc_kernel
+    rng = np.random.default_rng(21)
+    P, ci, co = 7, 8, 16
+    x = rng.normal(size=(P, 2, 2, ci))
+    wt = rng.normal(size=(3, 3, ci, co)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ref = O.conv2d_same(x, wt.astype(np.float64), b, 1, False)          # [P,2,2,co]
+    m = pack_window_fc_kernel(wt)[:4 * co].astype(np.float64)            # [(q,o)][(p,c)]
+    got = x.reshape(P, 4 * ci) @ m.T + pack_bias_x4(b)[:4 * co]
+    assert np.abs(got.reshape(P, 2, 2, co) - ref).max() < 1e-5
