@@ -95,6 +95,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KfnError('%s not found -- run `python -m kfnet_amd.build` (hipcc, gfx950); '
                        'kfnet_amd has no CPU fallback' % LIB_PATH)
+    try:
+        # torch bundles its own libamdhip64; the library must bind to that runtime, not to a second copy from
+        # /opt/rocm, or torch's device pointers mean nothing to it ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
