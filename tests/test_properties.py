@@ -130,3 +130,42 @@ def test_hip_cached_feature_path_equals_pair_evaluation(seed, batch):
         assert np.allclose(seq['flow'][t], d['flow'][1], atol=2e-5)
         assert np.allclose(seq['sigma_trans'][t], d['sigma_trans'][1], rtol=1e-4)
         assert np.allclose(seq['meas'][t], d['meas'][1], atol=2e-5, rtol=1e-4)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 2), st.integers(1, 4), st.integers(1, 5), st.integers(0, 2 ** 31 - 1))
+def test_polyphase_weight_fragments_reproduce_the_stride2_convolution(n, th, tw, seed):
+    """For any even image size: the 16 pre-signed fragments of pack_winograd_s2_kernel, applied per phase with the
+    F(2,2) output transform written out explicitly (no accumulator folding here -- that is checked in
+    test_oracle_kat), give the oracle's stride-2 SAME convolution."""
+    from kfnet_amd.graph import pack_winograd_s2_kernel
+    rng = np.random.default_rng(seed)
+    H, W, ci, co = 4 * th - 2 * int(rng.integers(0, 2)), 4 * tw - 2 * int(rng.integers(0, 2)), 8, 3
+    x = rng.normal(size=(n, H, W, ci))
+    wt = rng.normal(size=(3, 3, ci, co)).astype(np.float32)
+    ref = O.conv2d_same(x, wt.astype(np.float64), None, 2, False)
+    u = pack_winograd_s2_kernel(wt)
+    U = u.transpose(1, 0, 3, 2).reshape(16, ci, u.shape[2])[:, :, :co].astype(np.float64)
+    # the packer's minus sign on Winograd index 2 turns A^T = [[1,1,0],[0,1,-1]] into [[1,1,0],[0,1,1]]
+    AT = np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 1.0]])
+    BT = np.array([[1.0, -1.0, 0.0], [0.0, 1.0, 0.0], [0.0, 1.0, -1.0]])
+    xp = np.pad(x, ((0, 0), (0, 4), (0, 4), (0, 0)))
+    got = np.zeros_like(ref)
+    for im in range(n):
+        for ty in range((H // 2 + 1) // 2):
+            for tx in range((W // 2 + 1) // 2):
+                d = xp[im, 4 * ty:4 * ty + 5, 4 * tx:4 * tx + 5]
+                v00 = np.einsum('xm,mnc,yn->xyc', BT, d[0::2, 0::2], BT)
+                m00 = np.einsum('xyc,xyco->xyo', v00, U[0:9].reshape(3, 3, ci, co))
+                y = np.einsum('ax,xyo,by->abo', AT, m00, AT)
+                v01 = np.einsum('xm,mnc->xnc', BT, d[0::2, 1::2])                  # [3,2,ci]
+                y += np.einsum('ax,xno->ano', AT, np.einsum('xnc,xco->xno', v01, U[9:12]))
+                v10 = np.einsum('yn,mnc->myc', BT, d[1::2, 0::2])                  # [2,3,ci]
+                y += np.einsum('by,myo->mbo', AT, np.einsum('myc,yco->myo', v10, U[12:15]))
+                y += np.einsum('mnc,co->mno', d[1::2, 1::2], U[15])
+                for di in range(2):
+                    for dj in range(2):
+                        oy, ox = 2 * ty + di, 2 * tx + dj
+                        if oy < H // 2 and ox < W // 2:
+                            got[im, oy, ox] = y[di, dj]
+    assert np.abs(got - ref).max() < 1e-5
