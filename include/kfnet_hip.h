@@ -35,7 +35,7 @@ extern "C" {
 #define KFN_ERR_HIP (-2)
 #define KFN_ERR_UNSUPPORTED (-3)
 
-#define KFN_ABI_VERSION 3
+#define KFN_ABI_VERSION 4
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -85,8 +85,28 @@ typedef struct kfn_conv_desc {
   int32_t operand_dtype; /* KFN_OPERAND_F32 (exact fp32 MFMA) or KFN_OPERAND_F16: operands rounded
                           * to fp16 while staged, fp32 accumulate on v_mfma_f32_32x32x16_f16
                           * (BASELINE config 5); then w_packed holds IEEE halfs and Cin % 32 == 0.
-                          * Activations and outputs stay fp32 in memory either way. */
+                          * Activations and outputs stay fp32 in memory unless x_dtype / y_dtype say
+                          * otherwise. */
+  int32_t wino_order;    /* Winograd kernels only: workgroup order, KFN_WINO_ORDER_* (0 = the kernel's default) */
+  int32_t wino_form;     /* kfn_conv2d_winograd_fused only: KFN_WINO_FORM_* (0 = auto) */
+  int32_t x_dtype;       /* KFN_ACT_F32 / KFN_ACT_F16: element type of the input activations in memory */
+  int32_t y_dtype;       /* ... of the output activations.  KFN_ACT_F16 needs operand_dtype == KFN_OPERAND_F16
+                          * (BASELINE config 5: fp16 activations end to end); ldx / ldy count ELEMENTS. */
 } kfn_conv_desc;
+
+#define KFN_ACT_F32 0
+#define KFN_ACT_F16 1
+
+/* Order in which the Winograd kernels' workgroups walk (tile block, channel group): with the tile blocks
+ * fastest every resident workgroup of an XCD streams the same weight slice and the input crosses the
+ * fabric once per channel group; with the channel groups fastest the input crosses once and every group's
+ * weights are live at once.  Run time is the same either way (profiles/r03_wino_order_ab.log); the field
+ * exists so that this A/B stays reproducible without hidden state. */
+#define KFN_WINO_ORDER_AUTO 0
+#define KFN_WINO_ORDER_M_FAST 1
+#define KFN_WINO_ORDER_N_FAST 2
+#define KFN_WINO_FORM_AUTO 0
+#define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel would run */
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1

@@ -54,8 +54,13 @@ def load_images(paths, image_size):
     return out
 
 
+# eval.py's host loop resets the filter every `spec.sequence_length` frames, and KFNetDataSpec() is built with
+# the default scene there: 500 whatever --scene says.  ONE constant for every caller.
+RESET_PERIOD = 500
+
+
 def eval_sharded(image_paths, transform, weights, output_folder, rank, world, link, nis=False,
-                 image_size=(480, 640), batch=4, frames=None, sequence_length=500, verbose=True,
+                 image_size=(480, 640), batch=4, frames=None, sequence_length=RESET_PERIOD, verbose=True,
                  device=None, decode_workers=8):
     """Frame-sharded prediction (BASELINE config 4): this rank owns the contiguous chunk
     `chunk_bounds(T, world, rank)`, runs the state-independent heavy phase for it at once,
@@ -88,7 +93,7 @@ def eval_sharded(image_paths, transform, weights, output_folder, rank, world, li
 
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
-         frames=None, sequence_length=500, chunk=256, verbose=True, label_paths=None, labels=None,
+         frames=None, sequence_length=RESET_PERIOD, chunk=256, verbose=True, label_paths=None, labels=None,
          decode_workers=8, device=None, metrics_sequence_length=1000):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
@@ -219,6 +224,9 @@ def _main_sharded(a, W, size, rank, world):
     from ..dist import make_link
     ndev = torch.cuda.device_count()
     dev_index = int(os.environ.get('LOCAL_RANK', '0')) % max(ndev, 1)
+    if a.gpu != 0 and rank == 0:
+        print('WARNING: --gpu %d is ignored under torch.distributed.run: rank r uses device LOCAL_RANK' % a.gpu,
+              file=sys.stderr)
     torch.cuda.set_device(dev_index)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     backend = os.environ.get('KFN_DIST_BACKEND', 'nccl' if ndev >= world else 'gloo')
@@ -233,13 +241,19 @@ def _main_sharded(a, W, size, rank, world):
             from ..dist import chunk_bounds, needs_state
             lo, hi = chunk_bounds(a.synthetic, world, rank)
             # every rank generates only the frames it needs (frame t depends on (seed, t) alone)
-            first = lo - (1 if (hi > lo and needs_state(lo, 500)) else 0)
+            first = lo - (1 if (hi > lo and needs_state(lo, RESET_PERIOD)) else 0)
             part = synthetic_sequence(hi - first, a.height, a.width, start=first)
             frames = _ShiftedFrames(part, first, a.synthetic)
             transform = np.linalg.inv(synthetic_transform())
             eval_sharded(None, transform, W, a.output_folder, rank, world, link, a.NIS, image_size=size,
-                         batch=a.batch, frames=frames)
+                         batch=a.batch, frames=frames, sequence_length=RESET_PERIOD)
         else:
+            if os.path.exists(os.path.join(a.input_folder, 'label_list.txt')) and rank == 0:
+                # the single-process run prints eval.py's per-frame l_/a_/d_/nis line and the median summary from
+                # these labels; the sharded run writes the same coord_<i>.npy files but computes no metrics
+                print('WARNING: label_list.txt found, but the sharded run (WORLD_SIZE=%d) does not evaluate labels: '
+                      'no per-frame log line and no median summary will be printed.  Run single-process '
+                      '(python -m kfnet_amd.KFNet.eval --gpu N ...) for the metrics.' % world, file=sys.stderr)
             image_paths = read_lines(os.path.join(a.input_folder, 'image_list.txt'))
             eval_sharded(image_paths, get_transform(os.path.join(a.input_folder, 'transform.txt')), W,
                          a.output_folder, rank, world, link, a.NIS, image_size=size, batch=a.batch)

@@ -105,9 +105,15 @@ class DeviceMetrics(object):
         self.h_stats = [torch.zeros((T, 16), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.h_dist = [torch.zeros((T, 3, eng.h, eng.w), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.done = [None, None]
-        self.labels = torch.zeros((T + 2, eng.h, eng.w, 4), dtype=torch.float32, device=dev)
-        self.pairs = torch.zeros((T, 2), dtype=torch.int32, device=dev)
-        self.resets = torch.zeros((T,), dtype=torch.uint8, device=dev)
+        # per-slot inputs too (labels, pair table, reset flags), staged through pinned host buffers and copied
+        # stream-ordered on the compute stream: chunk k+1's labels can never overwrite chunk k's while its
+        # reduction is still reading them, and no upload blocks the host (upload / compute / download overlap)
+        self.labels = [torch.zeros((T + 2, eng.h, eng.w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.pairs = [torch.zeros((T, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.resets = [torch.zeros((T,), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.h_labels = [torch.zeros((T + 2, eng.h, eng.w, 4), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.h_pairs = [torch.zeros((T, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.h_resets = [torch.zeros((T,), dtype=torch.uint8).pin_memory() for _ in range(2)]
         tr = eng.transform
         self.t12 = None if tr is None else (C.c_float * 12)(*[float(v) for v in np.asarray(tr, np.float32)[:3, :4].reshape(-1)])
 
@@ -117,15 +123,22 @@ class DeviceMetrics(object):
         label_rows [L,h,w,4] host float32 = the label grids this chunk refers to, pairs [count,2] = rows of it."""
         eng, torch = self.eng, self.torch
         L = int(label_rows.shape[0])
-        if L > self.labels.shape[0] or count > self.stats[0].shape[0]:
+        if L > self.labels[0].shape[0] or count > self.stats[0].shape[0]:
             raise ValueError('chunk larger than the metric buffers')
-        self.labels[:L].copy_(torch.from_numpy(np.ascontiguousarray(label_rows, dtype=np.float32)))
-        self.pairs[:count].copy_(torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32)))
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()      # the pinned staging of this slot is free once its last use finished
         rp = eng.reset_period
         flags = np.array([1 if (rp > 0 and (first + k) % rp == 0) else 0 for k in range(count)], dtype=np.uint8)
-        self.resets[:count].copy_(torch.from_numpy(flags))
+        self.h_labels[slot][:L].copy_(torch.from_numpy(np.ascontiguousarray(label_rows, dtype=np.float32)))
+        self.h_pairs[slot][:count].copy_(torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32)))
+        self.h_resets[slot][:count].copy_(torch.from_numpy(flags))
+        with torch.cuda.stream(torch.cuda.current_stream(eng.device)):
+            self.labels[slot][:L].copy_(self.h_labels[slot][:L], non_blocking=True)
+            self.pairs[slot][:count].copy_(self.h_pairs[slot][:count], non_blocking=True)
+            self.resets[slot][:count].copy_(self.h_resets[slot][:count], non_blocking=True)
         rc = eng.lib.kfn_eval_metrics(eng.c_meas.ptr, eng.c_temp.ptr, eng.c_kf.ptr, eng.c_rec.ptr, eng.c_nis.ptr,
-                                      self.labels.data_ptr(), self.pairs.data_ptr(), self.resets.data_ptr(), self.t12,
+                                      self.labels[slot].data_ptr(), self.pairs[slot].data_ptr(),
+                                      self.resets[slot].data_ptr(), self.t12,
                                       int(count), int(eng.hw), self.dist_threshold, float(eng.net.min_uncertainty),
                                       self.stats[slot].data_ptr(), self.dist[slot].data_ptr(), eng._stream())
         _lib.check(rc, 'kfn_eval_metrics')

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
@@ -24,7 +24,8 @@ class KfnError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
-        'transposed', 'relu', 'epilogue', 'config', 'operand_dtype')]
+        'transposed', 'relu', 'epilogue', 'config', 'operand_dtype', 'wino_order', 'wino_form',
+        'x_dtype', 'y_dtype')]
 
 
 class KalmanDesc(C.Structure):

@@ -851,30 +851,15 @@ int g_num_cu = 0;
 // CU (VGPR-limited to 3 waves/SIMD): measured +3 % (160x128), +16 % (192x64), +33 % (256x32)
 // over BK = 32 on the direct kernel.  The Winograd GEMMs need the 128x128 tile for that
 // (166 VGPRs; the 160x128 one has 205): 128x128x16 beats 160x128x32 by 1-7 %.
-// KFN_CONV_BK=16|32 overrides both for experiments.
-int bk_override() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("KFN_CONV_BK");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+// (BK = 32 stays instantiated for the fp32 modes and is reachable only by editing pick_bk.)
 int pick_bk(int cin, int mode) {
-  if (cin % 32 != 0) return 16;
-  const int o = bk_override();
-  if (o == 16 || o == 32) return o;
+  (void)cin; (void)mode;
   return 16;
 }
 
-int rot_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("KFN_CONV_ROT");
-    mode = e ? atoi(e) : 0;  // measured: no effect on MI355X (326.4 / 326.5 / 326.6 fps for 0/1/2)
-  }
-  return mode;
-}
+// K-chunk rotation between concurrent workgroups (ConvArgs::rot_mode 1 / 2): measured without effect on
+// MI355X (326.4 / 326.5 / 326.6 frames/s for 0 / 1 / 2); off.
+constexpr int kRotMode = 0;
 
 int num_cu() {
   if (g_num_cu == 0) {
@@ -989,7 +974,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   a.x_bytes = (unsigned long long)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
-  a.rot_mode = rot_mode();
+  a.rot_mode = kRotMode;
 
   const int cfg = pick_config(d, a.M);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1126,7 +1111,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   a.x_bytes = (unsigned long long)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.tiles_m = a.tiles_n = 0;
-  a.rot_mode = rot_mode();
+  a.rot_mode = kRotMode;
   a.w_lo_bytes = 0;
   a.out_scale = 1.0f;
   int cfg = d->config;

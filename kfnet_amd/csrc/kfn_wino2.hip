@@ -26,6 +26,9 @@
 // 8 positions ahead and half a stage of staging loads + LDS writes (for the stage after next) are
 // slotted behind the MFMAs of the current chunk.
 #include "kfn_common.h"
+#ifndef KFN_WINO2_DBG
+#define KFN_WINO2_DBG 0
+#endif
 #include <type_traits>
 #include <cstdlib>
 
@@ -446,8 +449,8 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
               "kfn_conv2d_winograd_fused: buffers must be 16-byte aligned");
   {
     // >= 128 output channels and whole 32-channel super-steps: the 4-wave form (one transform per 128 output
-    // channels, input read Cout/128 times); KFN_WINO_FORM=2 forces the one-wave form for A/B measurements
-    static const int form = getenv("KFN_WINO_FORM") ? atoi(getenv("KFN_WINO_FORM")) : 0;
+    // channels, input read Cout/128 times); kfn_conv_desc.wino_form = KFN_WINO_FORM_ONE_WAVE forces the one-wave form for A/B measurements
+    const int form = d->wino_form == KFN_WINO_FORM_ONE_WAVE ? 2 : 0;
     const long img_b = (long)d->H * d->W * d->ldx * 4L;
     if ((form != 2 || h16) && d->Cout >= 128 && d->Cin % 32 == 0 && 2 * img_b < (1L << 31) &&
         2L * d->H * d->W * d->ldy * 4L < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31))
@@ -474,10 +477,7 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
-  {
-    static const int dbg = getenv("KFN_WINO2_DBG") ? atoi(getenv("KFN_WINO2_DBG")) : 0;
-    a.dbg = dbg;
-  }
+  a.dbg = KFN_WINO2_DBG;   // build-time timing hooks (-DKFN_WINO2_DBG=1: hot A, 2: hot B); 0 in the product build
   a.x_bytes = (unsigned long long)x_bytes;
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)u_bytes;

@@ -25,7 +25,7 @@
 #include <cstdlib>
 
 #ifndef KFN_WINO_DEFAULT_N_FAST
-#define KFN_WINO_DEFAULT_N_FAST 0   // measured (KFN_WINO_ORDER=0/1): 2.9 vs 4.8 GB fetched per launch, conv4b 4.59 vs 4.72 ms
+#define KFN_WINO_DEFAULT_N_FAST 0   // measured (kfn_conv_desc.wino_order M_FAST / N_FAST): 2.9 vs 4.8 GB fetched per launch, conv4b 4.59 vs 4.72 ms
 #endif
 
 namespace {
@@ -468,6 +468,9 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, 
   a.Th = (d->H + 1) / 2; a.Tw = (d->W + 1) / 2;
   const long vrows = (long)d->N * a.Th;
   const long in_pix = (long)d->N * d->H * d->W;
+  // (the caller checked the per-image and weight byte ranges; the batch-wide row count is checked here so that a
+  // very large N cannot overflow vrows and the img0 / ty0 arithmetic derived from it)
+  KFN_REQUIRE(vrows < (1L << 30), "kfn_conv2d_winograd_fused: N*ceil(H/2) = %ld tile rows exceed 32-bit addressing", vrows);
   a.vrows = (int)vrows;
   a.bw = ceil_div(a.Tw, BW);
   const long tiles_m = (long)a.bw * ceil_div(a.vrows, BH);
@@ -475,10 +478,7 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, 
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
-  {
-    static const int order = getenv("KFN_WINO_ORDER") ? atoi(getenv("KFN_WINO_ORDER")) : -1;
-    a.n_fast = order >= 0 ? order : KFN_WINO_DEFAULT_N_FAST;
-  }
+  a.n_fast = d->wino_order == KFN_WINO_ORDER_N_FAST ? 1 : (d->wino_order == KFN_WINO_ORDER_M_FAST ? 0 : KFN_WINO_DEFAULT_N_FAST);
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);

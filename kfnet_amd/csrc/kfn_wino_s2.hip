@@ -36,7 +36,7 @@
 #include <cstdlib>
 
 #ifndef KFN_WINO_DEFAULT_N_FAST
-#define KFN_WINO_DEFAULT_N_FAST 1   // measured (KFN_WINO_ORDER=0/1): 3.8 vs 4.8 GB fetched per launch, same time
+#define KFN_WINO_DEFAULT_N_FAST 1   // measured (kfn_conv_desc.wino_order M_FAST / N_FAST): 3.8 vs 4.8 GB fetched per launch, same time
 #endif
 
 namespace {
@@ -475,10 +475,7 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_s2: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
-  {
-    static const int order = getenv("KFN_WINO_ORDER") ? atoi(getenv("KFN_WINO_ORDER")) : -1;
-    a.n_fast = order >= 0 ? order : KFN_WINO_DEFAULT_N_FAST;
-  }
+  a.n_fast = d->wino_order == KFN_WINO_ORDER_N_FAST ? 1 : (d->wino_order == KFN_WINO_ORDER_M_FAST ? 0 : KFN_WINO_DEFAULT_N_FAST);
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   const long in_pix = (long)d->N * d->H * d->W, out_pix = (long)d->N * a.Ho * a.Wo;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);

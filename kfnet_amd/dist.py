@@ -134,17 +134,61 @@ class LoopbackLink(object):
         pass
 
 
+def _all_ranks_ok(dist, ok, device_index):
+    """MIN over ranks of a success flag (collective: every rank of the group must call it)."""
+    import torch
+    on_gpu = dist.get_backend() == 'nccl' and torch.cuda.is_available()
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device=torch.device('cuda', int(device_index)) if on_gpu else 'cpu')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def make_link(dist, rank, world, device_index, prefer='auto'):
     """The transport for this process group: the C-ABI RCCL link when every rank owns a GPU
-    (backend 'nccl'), torch.distributed otherwise.  prefer = 'auto' | 'cabi' | 'torch'."""
+    (backend 'nccl'), torch.distributed otherwise.  prefer = 'auto' | 'cabi' | 'torch'.
+
+    The choice is COLLECTIVE: every rank runs the same sequence of group operations whatever
+    fails where, so the ranks can never end up on different transports (a rank that cannot bind
+    librccl must not leave the others blocked in the id broadcast, and a group that mixes
+    ncclSend with torch.distributed.recv hangs at the first hand-off).
+      1. every rank probes the C-ABI side (dlopen + symbols: kfn_comm_unique_id into a scratch
+         buffer) -> all_reduce(MIN);
+      2. rank 0 broadcasts its unique id, every rank runs kfn_comm_init -> all_reduce(MIN);
+      3. only if every rank succeeded is RcclLink used; otherwise every rank closes what it
+         opened and takes TorchLink -- or, with prefer='cabi', every rank raises."""
     if dist is None or world <= 1:
         return None
-    if prefer != 'torch' and dist.get_backend() == 'nccl':
+    if prefer == 'torch' or dist.get_backend() != 'nccl':
+        if prefer == 'cabi':
+            raise _lib.KfnError("the C-ABI RCCL link needs backend 'nccl' (one GPU per rank), got %r"
+                                % dist.get_backend())
+        return TorchLink(dist)
+    why = None
+    lib = None
+    uid = None
+    try:
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(lib.kfn_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'kfn_comm_unique_id')
+        uid = bytes(buf.raw)
+    except (_lib.KfnError, OSError) as e:
+        why = e
+    link = None
+    if _all_ranks_ok(dist, why is None, device_index):
+        ids = [uid if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
         try:
-            return RcclLink(rank, world, device_index, dist=dist)
-        except (_lib.KfnError, OSError):
-            if prefer == 'cabi':
-                raise
+            link = RcclLink(rank, world, device_index, unique_id=ids[0])
+        except (_lib.KfnError, OSError, ValueError) as e:
+            why = e
+        if _all_ranks_ok(dist, link is not None, device_index):
+            return link
+        if link is not None:
+            link.close()
+    if prefer == 'cabi':
+        raise _lib.KfnError('C-ABI RCCL link unavailable on at least one rank (this rank: %s)'
+                            % (why if why is not None else 'ok'))
     return TorchLink(dist)
 
 

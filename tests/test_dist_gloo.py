@@ -111,3 +111,58 @@ def test_handoff_pairing_is_symmetric():
     # config 4: all 7 messages are needed
     assert [handoff_plan(256 * r, 256, r, 8, 500) for r in range(8)] == \
         [(False, True)] + [(True, True)] * 6 + [(True, False)]
+
+
+class _NcclLookalike(object):
+    """torch.distributed over gloo that claims to be 'nccl', so that make_link's RCCL branch (and its
+    collective fallback) can be driven without GPUs."""
+
+    def __init__(self, d):
+        self._d = d
+        self.ReduceOp = d.ReduceOp
+
+    def get_backend(self):
+        return 'nccl'
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+
+def _link_worker(rank, world, port, fail_rank, prefer, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from kfnet_amd import _lib, dist as kd
+    if rank == fail_rank:
+        def broken():
+            raise _lib.KfnError('simulated: librccl cannot be bound on this rank')
+        _lib.load = broken
+    try:
+        link = kd.make_link(_NcclLookalike(dist), rank, world, 0, prefer=prefer)
+        name = type(link).__name__
+        # the fallback link must be usable at once: one hand-off 0 -> 1
+        buf = torch.full((2, 3, 4), float(rank + 1))
+        link.via_host = True
+        if rank == 0:
+            link.send(buf, 1)
+        elif rank == 1:
+            link.recv(buf, 0)
+            assert float(buf[0, 0, 0]) == 1.0
+    except _lib.KfnError:
+        name = 'raised'
+    with open(os.path.join(out_dir, 'link_%d.txt' % rank), 'w') as f:
+        f.write(name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('fail_rank', [0, 1])
+@pytest.mark.parametrize('prefer', ['auto', 'cabi'])
+def test_make_link_fallback_is_collective(tmp_path, fail_rank, prefer):
+    """ADVICE r2 (dist.py:139): one rank failing to bind RCCL must not leave the others in the id
+    broadcast or on a different transport.  Whichever rank fails, BOTH ranks take TorchLink
+    ('auto') or BOTH raise ('cabi'), and nobody hangs."""
+    mp.spawn(_link_worker, args=(2, _free_port(), fail_rank, prefer, str(tmp_path)), nprocs=2, join=True)
+    names = [open(tmp_path / ('link_%d.txt' % r)).read() for r in range(2)]
+    assert names == (['TorchLink'] * 2 if prefer == 'auto' else ['raised'] * 2), names

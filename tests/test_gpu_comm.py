@@ -14,6 +14,16 @@ import pytest
 from kfnet_amd import _lib
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -78,7 +88,7 @@ def test_two_rank_state_transfer_over_rccl(tmp_path):
     script = tmp_path / 'two_rank.py'
     script.write_text(_TWO_RANK % ROOT)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29653', str(script)]
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
 

@@ -17,6 +17,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,7 +40,7 @@ def test_config4_eight_ranks_2048_frames_bit_identical_to_single_pass(tmp_path):
     out.mkdir()
     env = dict(os.environ, KFN_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
-           '--master-addr', '127.0.0.1', '--master-port', '29641', '-m', 'kfnet_amd.KFNet.eval',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), '-m', 'kfnet_amd.KFNet.eval',
            '--scene', 'heads', '--synthetic', str(T), '--random_weights', '--batch', '8',
            '--height', '64', '--width', '96', '--output_folder', str(out)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)

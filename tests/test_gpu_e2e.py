@@ -11,8 +11,22 @@ from oracle import kfnet_oracle_torch as OT
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 COORD_TOL = 1e-4
 CONF_RTOL = 1e-4
+
+
+# bound on the fraction of pixels config 5's tolerance statement excludes (measured: see profiles/r03_c5_parity.json)
+C5_MASKED_FRACTION_BOUND = 5e-3
 
 
 def _check(rec, ref):
@@ -99,7 +113,7 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KFN_DIST_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29617', os.path.join(root, 'bench.py'),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(root, 'bench.py'),
            '--gpus', '2', '--steps', '6', '--warmup', '2', '--batch', '2', '--height', '64', '--width', '96',
            '--no-kalman-roofline']
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -107,6 +121,37 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['frames_total'] == 12 and out['value'] > 0
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` -- the plain form, no torch.distributed.run around it -- must start
+    two ranks itself.  On a one-GPU box the ranks share the GPU over gloo and the
+    line says so; on a multi-GPU node the same command hands the state over RCCL (rccl_ranks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'KFN_DIST_BACKEND')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line (rank 0)'
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['self_launched'] is True
+    assert out['config']['frames_total'] == 12 and out['value'] > 0
+    assert len(out['rccl_ranks']) == 2 and len(out['rank_devices']) == 2
+    if torch.cuda.device_count() >= 2:
+        assert out['dist_backend'] == 'nccl' and out['rank_devices'] == [0, 1]
+        assert out['rccl_ranks'] == [[0, 2], [1, 2]], out['rccl_ranks']   # kfn_comm_rank on every rank
+        assert 'RCCL' in out['state_link']
+    else:
+        assert out['dist_backend'] == 'gloo' and out['rccl_ranks'] == [None, None]
+        assert 'FUNCTIONAL FALLBACK' in out['config']['parallelism']
 
 
 def test_config5_shape_batch_of_sequences():
@@ -230,6 +275,43 @@ def test_config5_fp16_convs_fp32_kalman():
     print('fp16-operand convs: coord max-abs %.3g, confidence max-rel %.3g' % (dc, dr))
     assert dc <= 2e-2 and dr <= 5e-2
     assert dc > 1e-6   # and it is measurably not the fp32 path
+
+
+def test_config5_tolerance_at_bench_scale():
+    """Config 5's tolerance as it is actually true, at the scale bench.py --config c5
+    reports: 4 sequences x 16 frames of 540x960, fp16-operand path against the fp32 HIP path (which
+    the tests above hold to the oracle at 1e-4).  The reference sampler (tools/util.py:36-93) is a
+    step function of the flow at x in {0, W-1} / y in {0, H-1}; a 1e-3 px flow difference can put
+    the two paths on different sides, and the recurrent state carries that on.  Statement: every
+    pixel whose fp32 sample position stays >= 0.05 px from those steps -- and has not read a pixel
+    that did not, since the last reset -- meets coord max-abs <= 2e-2 and confidence max-rel
+    <= 5e-2; the excluded fraction is reported and bounded."""
+    import torch
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.tools.parity import masked_parity, merge_parity
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    S, T = 4, 16
+    seqs = np.stack([synthetic_sequence(T, 540, 960, seed=3 + s) for s in range(S)])
+    dev = torch.from_numpy(seqs).cuda()
+    T4 = np.eye(4, dtype=np.float32)
+    recs = {}
+    for mode in ('f32', 'f16'):
+        eng = KFNetEngine(W, image_size=(540, 960), batch=8, transform=T4, reset_period=500, max_chunk=S * T,
+                          conv_operands=mode)
+        recs[mode] = eng.process_sequences(dev).cpu().numpy().copy()
+        if mode == 'f32':
+            flow = eng.debug(S * T)['flow'].reshape(S, T, eng.h, eng.w, 2).copy()
+        del eng
+        torch.cuda.empty_cache()
+    mp = merge_parity([masked_parity(recs['f16'][s], recs['f32'][s], flow[s], coord_tol=2e-2, conf_rel_tol=5e-2,
+                                     delta=0.05, reset_period=500) for s in range(S)])
+    print('config 5 at bench scale:', mp)
+    assert mp['pixels'] == S * T * 68 * 120
+    assert mp['unmasked_outside_tolerance'] == 0, mp
+    assert mp['masked_fraction'] <= C5_MASKED_FRACTION_BOUND, mp
+    assert mp['all_pixels_coord_max_abs'] > 1e-6     # and it is measurably not the fp32 path
 
 
 @pytest.mark.parametrize('size,batch', [((64, 96), 2), ((480, 640), 3)])

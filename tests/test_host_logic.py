@@ -154,7 +154,8 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe),
                            '-L', os.path.dirname(lib), '-lkfnet_hip', '-Wl,-rpath,' + os.path.dirname(lib)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    assert out == ['3', '240', '320']          # ABI version, TF-SAME output size of conv2a
+    from kfnet_amd._lib import ABI_VERSION
+    assert out == [str(ABI_VERSION), '240', '320']          # ABI version, TF-SAME output size of conv2a
 
 
 def test_comm_entry_points_validate_arguments_without_a_gpu():

@@ -1,12 +1,12 @@
 export TMPDIR=/tmp
 R=$(pwd)
 mkdir -p gpurun_out/order
-for o in 0 1; do
-  echo "== KFN_WINO_ORDER=$o"
-  KFN_WINO_ORDER=$o MB_FUSED_ONLY=1 MB_BATCH=16 python tools/mb_wino.py 2>&1 | grep -v amdgpu.ids | cut -c1-70
-  KFN_WINO_ORDER=$o python tools/mb_s2.py 2>&1 | grep -v amdgpu.ids | cut -c1-90
-  ( cd /tmp && KFN_WINO_ORDER=$o MB_FUSED_ONLY=1 MB_BATCH=16 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/order/f$o -- python $R/tools/mb_wino.py > /dev/null 2>&1 )
-  ( cd /tmp && KFN_WINO_ORDER=$o timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/order/s$o -- python $R/tools/mb_s2.py > /dev/null 2>&1 )
+for o in 1 2; do   # kfn_conv_desc.wino_order: 1 = tile blocks fastest, 2 = channel groups fastest
+  echo "== wino_order=$o"
+  MB_WINO_ORDER=$o MB_FUSED_ONLY=1 MB_BATCH=16 python tools/mb_wino.py 2>&1 | grep -v amdgpu.ids | cut -c1-70
+  MB_WINO_ORDER=$o python tools/mb_s2.py 2>&1 | grep -v amdgpu.ids | cut -c1-90
+  ( cd /tmp && MB_WINO_ORDER=$o MB_FUSED_ONLY=1 MB_BATCH=16 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/order/f$o -- python $R/tools/mb_wino.py > /dev/null 2>&1 )
+  ( cd /tmp && MB_WINO_ORDER=$o timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/order/s$o -- python $R/tools/mb_s2.py > /dev/null 2>&1 )
   for k in f s; do
     python - "$(find gpurun_out/order/$k$o -name '*.db' | head -1)" <<'PY'
 import sqlite3, sys

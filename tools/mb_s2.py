@@ -13,6 +13,7 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps
+ORDER = int(os.environ.get('MB_WINO_ORDER', '0'))   # kfn_conv_desc.wino_order: 0 default, 1 tile blocks fastest, 2 channel groups fastest
 N = int(os.environ.get('MB_BATCH', '16'))
 for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320, 256, 512), ('conv4a', 120, 160, 512, 1024)]:
     x = torch.randn(N * H * W * ci, device='cuda')
@@ -20,8 +21,8 @@ for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320,
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     y = torch.empty(N * (H // 2) * (W // 2) * co, device='cuda')
     F16 = os.environ.get('MB_F16', '') == '1'
-    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1)
-    d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16)
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, wino_order=ORDER)
+    d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16, wino_order=ORDER)
     if F16:
         u = u.half(); w9 = w9.half()
     t_s2 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d16 if F16 else d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 's2'))

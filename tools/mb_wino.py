@@ -15,6 +15,7 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps
+ORDER = int(os.environ.get('MB_WINO_ORDER', '0'))   # kfn_conv_desc.wino_order: 0 default, 1 tile blocks fastest, 2 channel groups fastest
 N = int(os.environ.get('MB_BATCH', '17'))
 LAYERS = [('conv1b', 480, 640, 64, 64), ('conv2b', 240, 320, 256, 256), ('conv3b', 120, 160, 512, 512),
           ('conv4b', 60, 80, 1024, 1024), ('conv5', 60, 80, 1024, 512), ('conv6', 60, 80, 512, 256)]
@@ -32,7 +33,7 @@ for (name, H, W, ci, co) in LAYERS:
         if not (co >= 128 and ci % 64 == 0):
             continue
         u = u.half()
-    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1,
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1, wino_order=ORDER,
                       config=int(os.environ.get('KFN_WINO_CFG', '0')), operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32)
     t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 'wf'))
     fl = 2.0 * 16 * Mt * ci * co

@@ -60,6 +60,7 @@ def main():
         res[k + opts.get('--suffix', '')] = {'launches_sampled': int(max(f[0], w[0])), 'fetch_bytes_per_launch': int(fb),
                   'write_bytes_per_launch': int(wb), 'hbm_bytes_per_launch': int(fb + wb),
                   'note': 'FETCH_SIZE x2 (gfx950 128B-request correction), WRITE_SIZE uncalibrated'}
+    res.setdefault('__sampled__', {'command': 'bench.py --steps 64 --batch 32 (tools/profile_round.sh)', 'tower_batch': 32})
     s = json.dumps(res, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], 'w').write(s + '\n')

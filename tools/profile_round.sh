@@ -2,7 +2,7 @@
 # Regenerates the judged profile summaries of a round on the GPU box:
 #   bash tools/profile_round.sh r01        (writes gpurun_out/prof/<tag>_*; copy into profiles/)
 # Kernel trace and every PMC group are separate rocprofv3 runs (never combined with sys traces).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -27,14 +27,14 @@ python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_S
     --only kalman_scan_kernel --suffix '@S=256,T=64' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
 python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json \
     --only kalman_fuse_kernel --suffix '@P=78643200' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
-cp $OUT/${TAG}_pmc_traffic.json $R/profiles/pmc_traffic.json   # the bench line below quotes these numbers
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # the bench line below quotes these numbers (newest rNN file)
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/sq$i -- python $R/bench.py $SHORT > /dev/null 2> $OUT/sq$i.err )
 done
 python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)"
-# the un-profiled bench line (quotes the fresh PMC traffic copied to profiles/pmc_traffic.json above)
+# the un-profiled bench line (quotes the fresh PMC traffic copied to profiles/ above)
 python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
 rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
 ls -la $OUT
