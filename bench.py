@@ -137,7 +137,7 @@ def pipeline_io_bytes(eng):
                                  WinogradConvOp)
     def tb(t):
         n, h, w, c = t.shape
-        return n * h * w * c * (4 if t.dtype == 'f32' else 1)
+        return n * h * w * c * {'f32': 4, 'f16': 2, 'u8': 1}[t.dtype]
     total = 0
     for op in eng.heavy_ops:
         if isinstance(op, FirstConvOp):
@@ -327,17 +327,33 @@ class Telemetry(object):
     host thread while a timed region runs (file reads only: nothing touches the GPU queues).
     Falls back to one `rocm-smi` call before and after when sysfs is not exposed."""
 
-    def __init__(self, dev_index, period=0.1):
+    def __init__(self, dev_index, period=0.1, sysfs='/sys/class/drm'):
         import glob
         self.period = period
         self.samples = []
         self.dir = None
         self._stop = None
         self._thr = None
-        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device'))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, 'pp_dpm_sclk'))]
-        if dev_index < len(cards):
-            self.dir = cards[dev_index]
+        # The box exposes ONE GPU to the process but sysfs lists every card of the host (and the partition nodes,
+        # which have no pp_dpm_sclk): find OUR card by PCI address; if that fails, watch every card and report the
+        # busiest one (`source` says which rule was used).
+        cards = sorted(glob.glob(os.path.join(sysfs, 'card[0-9]*', 'device')))
+        self.cards = [c for c in cards if os.path.exists(os.path.join(c, 'pp_dpm_sclk'))]
+        self.how = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+            for c in self.cards:
+                if os.path.basename(os.path.realpath(c)).lower() == want:
+                    self.dir, self.how = c, 'PCI address ' + want
+        except Exception:
+            pass
+        if self.dir is None and len(self.cards) == 1:
+            self.dir, self.how = self.cards[0], 'the only card with pp_dpm_sclk'
+        self.watch_all = self.dir is None and bool(self.cards)
+        if self.watch_all:
+            self.dir, self.how = self.cards[0], 'busiest of %d cards (PCI match failed)' % len(self.cards)
         self.hwmon = None
         if self.dir:
             hm = sorted(glob.glob(os.path.join(self.dir, 'hwmon', 'hwmon*')))
@@ -351,8 +367,27 @@ class Telemetry(object):
         except OSError:
             return None
 
-    def read_once(self):
+    def _hwmon_of(self, d):
+        import glob
+        hm = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*')))
+        return hm[0] if hm else None
+
+    def settle(self):
+        """watch_all: keep the card with the highest mean gpu_busy_percent over the samples taken so far."""
+        if not self.watch_all or not self.all_samples:
+            return
+        best = max(self.all_samples, key=lambda c: sum(x.get('busy_pct', 0) for x in self.all_samples[c]))
+        self.dir, self.samples = best, self.all_samples[best]
+
+    def read_once(self, d=None):
         out = {}
+        if d is not None:
+            keep = (self.dir, self.hwmon)
+            self.dir, self.hwmon = d, self._hwmon_of(d)
+            try:
+                return self.read_once()
+            finally:
+                self.dir, self.hwmon = keep
         if not self.dir:
             return out
         txt = self._read(os.path.join(self.dir, 'pp_dpm_sclk'))
@@ -405,8 +440,14 @@ class Telemetry(object):
         if self.dir:
             self._stop = threading.Event()
 
+            self.all_samples = {c: [] for c in self.cards} if self.watch_all else {}
+
             def loop():
                 while not self._stop.wait(self.period):
+                    if self.watch_all:
+                        for c in self.cards:
+                            self.all_samples[c].append(self.read_once(c))
+                        continue
                     smp = self.read_once()
                     if smp:
                         self.samples.append(smp)
@@ -418,6 +459,8 @@ class Telemetry(object):
         if self._thr is not None:
             self._stop.set()
             self._thr.join()
+            self.settle()
+            self.hwmon = self._hwmon_of(self.dir)
         self.after = self.read_once() or self.smi_once()
         return False
 
@@ -425,7 +468,7 @@ class Telemetry(object):
         def agg(key):
             v = [x[key] for x in self.samples if key in x]
             return {'min': round(min(v), 1), 'mean': round(sum(v) / len(v), 1), 'max': round(max(v), 1)} if v else None
-        return {'source': ('sysfs ' + self.dir) if self.dir else 'rocm-smi before/after (no sysfs nodes)',
+        return {'source': ('sysfs %s (%s)' % (self.dir, self.how)) if self.dir else 'rocm-smi before/after (no sysfs nodes)',
                 'before': self.before, 'after': self.after, 'samples_during_timed_region': len(self.samples),
                 'sclk_mhz': agg('sclk_mhz') or agg('sclk_mhz_hwmon'), 'power_w': agg('power_w'),
                 'busy_pct': agg('busy_pct')}
@@ -601,7 +644,7 @@ def bench_c5(args, device):
         k = by_kernel.setdefault(r[1], [0, 0.0, 0.0, 0.0])
         k[0] += 1; k[1] += r[2]; k[2] += r[3]; k[3] += r[4]
     heavy_ms = sum(r[3] for r in rows)
-    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').endswith(' 1'))
+    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6'))
     k16 = {k: v for k, v in by_kernel.items() if is16(k)}
     dom = max(k16, key=lambda k: k16[k][2])
     n_dom, fl_dom, ms_dom, ex_dom = k16[dom]

@@ -92,6 +92,8 @@ typedef struct kfn_conv_desc {
   int32_t x_dtype;       /* KFN_ACT_F32 / KFN_ACT_F16: element type of the input activations in memory */
   int32_t y_dtype;       /* ... of the output activations.  KFN_ACT_F16 needs operand_dtype == KFN_OPERAND_F16
                           * (BASELINE config 5: fp16 activations end to end); ldx / ldy count ELEMENTS. */
+  int32_t k_step;        /* 0 = auto; 16 / 32 = LDS k-step in 4-byte words (fp16 operands: 32 / 64 channels per
+                          * stage).  32 exists for the fp16-activation kernels only. */
 } kfn_conv_desc;
 
 #define KFN_ACT_F32 0
@@ -194,6 +196,11 @@ int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void
 int kfn_first_conv_u8(const uint8_t* img, int N, int H, int W,
                       const float* w1, const float* b1, float* y1, int C1,
                       const float* w2, const float* b2, float* y2, int C2, void* stream);
+/* The same with the FIRST head's output element type chosen (KFN_ACT_F32 | KFN_ACT_F16): BASELINE config 5 keeps
+ * SCoordNet's activations in fp16 from conv1a on (C1 == 64); the second head (feat1) stays fp32. */
+int kfn_first_conv_u8_ex(const uint8_t* img, int N, int H, int W,
+                         const float* w1, const float* b1, void* y1, int C1, int y1_dtype,
+                         const float* w2, const float* b2, float* y2, int C2, void* stream);
 
 /* ---- KFNet.BuildCoordVolume + reshape (KFNet/KFNet.py:343-359, :372) -----------------
  * vol[n, y, x, i, j, c] = f2[n,y,x,c] - f1[n, y+i-w/2, x+j-w/2, c]  (0 outside).

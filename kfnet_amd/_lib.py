@@ -14,6 +14,9 @@ ABI_VERSION = 4
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
+ACT_F32, ACT_F16 = 0, 1
+WINO_ORDER_AUTO, WINO_ORDER_M_FAST, WINO_ORDER_N_FAST = 0, 1, 2
+CFG_128x256 = 9
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -25,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
         'transposed', 'relu', 'epilogue', 'config', 'operand_dtype', 'wino_order', 'wino_form',
-        'x_dtype', 'y_dtype')]
+        'x_dtype', 'y_dtype', 'k_step')]
 
 
 class KalmanDesc(C.Structure):
@@ -65,6 +68,7 @@ SYMBOLS = {
     'kfn_conv2d_winograd_s2': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_s2_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    'kfn_first_conv_u8_ex': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'kfn_cost_volume_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'kfn_pad_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -16,7 +16,7 @@ from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, Winog
                      WinogradS2ConvOp, WindowFcConvOp, as_f16,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
-                     pack_winograd_s2_kernel)
+                     pack_winograd_s2_kernel, current_scope)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -172,6 +172,16 @@ class Network(object):
         op.epilogue = epilogue
         return op
 
+    def _act_dtype(self, filters):
+        """Element type of a convolution's output in memory.  fp16 only in the fp16-operand mode (BASELINE config
+        5), under the variable scopes Graph.f16_activation_scopes names, for outputs of >= 64 channels (the narrow
+        heads -- 'prediction', 4 channels -- stay fp32)."""
+        g = self.graph
+        if g.conv_operands != 'f16' or filters < 64 or filters % 8 != 0:
+            return 'f32'
+        scope = current_scope()
+        return 'f16' if any(scope == sc or scope.startswith(sc + '/') for sc in g.f16_activation_scopes) else 'f32'
+
     # ---- hot-path layers -----------------------------------------------------------
     @layer
     def conv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING,
@@ -187,7 +197,7 @@ class Network(object):
             n, h, w, cin = img.shape
             if not (k == 3 and strides == 1 and relu and cin == 3 and filters % 16 == 0):
                 raise NotImplementedError('fused first layer supports 3x3 stride-1 ReLU convs on 3 channels')
-            y = g.tensor((n, h, w, filters), name=name)
+            y = g.tensor((n, h, w, filters), dtype=self._act_dtype(filters) if filters == 64 else 'f32', name=name)
             kern = g.variable(name + '/kernel', (3, 3, 3, filters), pack_first_kernel)
             bias = g.variable(name + '/bias', (filters,), pack_bias)
             op = g.first_conv.get(id(img))
@@ -200,13 +210,16 @@ class Network(object):
             op.add_head(name, y, kern, bias)
             return y
         n, h, w, cin = input.shape
-        y = g.tensor((n, _same_out(h, strides), _same_out(w, strides), filters), name=name)
+        f16 = g.conv_operands == 'f16' and cin % 32 == 0
+        if input.dtype == 'f16' and not f16:
+            raise NotImplementedError('%s: an fp16 activation can only feed an fp16-operand convolution' % name)
+        y = g.tensor((n, _same_out(h, strides), _same_out(w, strides), filters),
+                     dtype=self._act_dtype(filters) if f16 else 'f32', name=name)
         bias = g.variable(name + '/bias', (filters,), pack_bias) if biased else None
         wmin = g.winograd_min_channels
-        f16 = g.conv_operands == 'f16' and cin % 32 == 0
         # (measured, 16 frames: conv3b 2.07 vs 2.31 ms direct fp16, conv4b 1.81 vs 2.59, conv5 1.00 vs 1.25; at
         #  Cin = 256 the direct kernel is as fast -- conv2b 2.56 vs 2.48 -- and stays)
-        if (f16 and k == 3 and strides == 1 and g.winograd_fused and cin >= 512
+        if (f16 and input.dtype == 'f32' and y.dtype == 'f32' and k == 3 and strides == 1 and g.winograd_fused and cin >= 512
                 and WinogradFusedConvOp.supported(input.shape, cin, filters, _lib.OPERAND_F16)):
             # BASELINE config 5: the four-wave Winograd kernel on fp16 MFMAs (transform in fp32, V and U rounded to fp16)
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_fused_kernel))
@@ -214,7 +227,7 @@ class Network(object):
             return y
         # (the fp16 instantiation of the polyphase stride-2 kernel exists and is tested, but at fp16 MFMA rates it is
         #  latency-bound and the direct fp16 kernel is faster: conv3a 1.20 vs 1.68 ms -- Graph.winograd_s2_f16 = False)
-        if (f16 and k == 3 and strides == 2 and g.winograd_s2_f16 and cin >= 64
+        if (f16 and input.dtype == 'f32' and y.dtype == 'f32' and k == 3 and strides == 2 and g.winograd_s2_f16 and cin >= 64
                 and filters >= 128 and WinogradS2ConvOp.supported(input.shape, cin, filters)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_s2_kernel))
             self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, operand_dtype=_lib.OPERAND_F16))

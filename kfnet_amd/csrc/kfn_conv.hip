@@ -139,10 +139,19 @@ constexpr int PREC_F32 = 0, PREC_F16 = 1, PREC_F16X3 = 2;
 // half of every MFMA; here a 32-row block is two 16-row MFMAs per 4 k, the two k-chunks of
 // a stage become the two row halves, and everything else (staging, schedule) is unchanged.
 constexpr int PREC_F32_N16 = 3;
+// PREC_F16 with fp16 ACTIVATIONS in memory (BASELINE config 5 end to end, forward convs only):
+//   _X  the input tensor holds halfs: one 16-byte load per LDS quad (8 channels), no conversion while staging;
+//   _Y  the output tensor holds halfs: the accumulators (+ bias, ReLU) are rounded once (RNE), the tile is
+//       transposed through the idle operand LDS and leaves as 16-byte runs of 8 channels;
+//   _XY both.  k-step 16 or 32 (= 32 / 64 channels per stage).
+constexpr int PREC_F16_X = 4, PREC_F16_Y = 5, PREC_F16_XY = 6;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  constexpr bool F16 = (PREC == PREC_F16 || PREC == PREC_F16X3);   // operands live in LDS as halfs
+  constexpr bool X16 = (PREC == PREC_F16_X || PREC == PREC_F16_XY);   // activations read as halfs
+  constexpr bool Y16 = (PREC == PREC_F16_Y || PREC == PREC_F16_XY);   // activations written as halfs
+  constexpr bool F16 = (PREC == PREC_F16 || PREC == PREC_F16X3 || X16 || Y16);   // operands live in LDS as halfs
+  constexpr unsigned XB = X16 ? 2u : 4u;                               // bytes per input element
   constexpr bool N16 = (PREC == PREC_F32_N16);
   constexpr int CB = N16 ? 16 : 32;          // columns per MFMA sub-tile
   static_assert(!N16 || BK == 16, "the 16-column variant maps the two k-chunks of a 16-deep stage to row halves");
@@ -151,8 +160,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr bool TRANSPOSED = (MODE == MODE_DECONV);
   constexpr bool WINO = (MODE == MODE_WINO);
   constexpr bool CVOL = (MODE == MODE_CVOL);
-  static_assert(!F16 || (BK == 16 && (MODE == MODE_CONV || MODE == MODE_DECONV)), "F16: conv/deconv at BK=16 only");
-  constexpr int NSRC = WINO ? 4 : ((CVOL || F16) ? 2 : 1);  // global loads per A quad
+  static_assert(!F16 || ((BK == 16 || ((X16 || Y16) && BK == 32)) && (MODE == MODE_CONV || MODE == MODE_DECONV)),
+                "F16: conv/deconv at BK=16 (fp16 activations: also 32)");
+  static_assert(!(X16 || Y16) || MODE == MODE_CONV, "fp16 activations: forward convolutions only");
+  constexpr int NSRC = WINO ? 4 : ((CVOL || (F16 && !X16)) ? 2 : 1);  // global loads per A quad
   constexpr int QCH = F16 ? 8 : 4;                           // channels per 16-byte LDS quad
   constexpr int KCH = F16 ? 2 * BK : BK;                     // channels per stage
   constexpr int BM = 32 * TM * WM;
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // offsets only have to span the few images of ONE tile (activations may exceed 2 GiB).
   const int HoWo = p.Ho * p.Wo;
   const int n_first = TRANSPOSED ? 0 : fdiv(CVOL ? (m0 >> 6) : m0, p.fd_img);
-  const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_base = (unsigned long long)n_first * p.H * p.W * p.ldx * (unsigned long long)XB;
   const unsigned long long a_rest = p.x_bytes - a_base;
   // The range check of a buffer load looks at the per-lane offset only (the scalar offset is excluded), and
   // the per-row offset of the input pixel (iy0, ix0) may lie up to (pad_t rows + pad_l pixels) BEFORE the
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // first image and every row offset shifted up by the same amount, so that row offsets are non-negative
   // and the tap / channel offset can ride in the scalar operand.
   const unsigned a_shift = (TRANSPOSED || WINO) ? 0u
-                           : (unsigned)(((CVOL ? 5 : p.pad_t) * p.W + (CVOL ? 5 : p.pad_l)) * p.ldx) * 4u;
+                           : (unsigned)(((CVOL ? 5 : p.pad_t) * p.W + (CVOL ? 5 : p.pad_l)) * p.ldx) * XB;
   char* const a_ptr = const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base;
   const unsigned long long a_span = a_rest + a_shift;
   const int a_records = (int)(a_span < 0x7fffffffull ? a_span : 0x7fffffffull);
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
       } else {
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * 4u + a_shift;
+        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * XB + a_shift;
         // valid taps = [ky_lo, ky_hi) x [kx_lo, kx_hi)
         const int ky_lo = iy0 < 0 ? -iy0 : 0, ky_hi = (p.H - iy0 < p.kh) ? p.H - iy0 : p.kh;
         const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = (p.W - ix0 < p.kw) ? p.W - ix0 : p.kw;
@@ -437,6 +448,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       } else {              // shifted f1
         ga[k] = buf_load_s(rsA, a_ok2[CVOL ? i : 0] ? a_off[i] : OOB, adelta);
       }
+    } else if (X16 && k < AP * NSRC) {   // fp16 activations: the quad's 8 channels are one 16-byte load
+      ga[k] = buf_load_s(rsA, a_ok[k] ? a_off[k] : OOB, adelta);
     } else if (F16 && k < AP * NSRC) {   // two consecutive float4 = the 8 channels of one fp16 quad
       const int i = k / NSRC;
       if (TRANSPOSED) {
@@ -493,6 +506,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         v = f32x4{lo.x, lo.y, hi.x, hi.y};
       } else if (CVOL) {
         v = ga[i * NSRC] - ga[i * NSRC + (CVOL ? 1 : 0)];   // diff_feat = feat_map2 - shift(feat_map1)
+      } else if (X16) {
+        v = ga[i];
       } else if (F16) {
         const f32x4 c0 = ga[i * NSRC], c1 = ga[i * NSRC + (F16 ? 1 : 0)];   // channels 0-3, 4-7
         const f16x8 h = {(_Float16)c0.x, (_Float16)c0.y, (_Float16)c0.z, (_Float16)c0.w,
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers ----------------------
     {
       const int ky = ld_tap / p.kw, kx = ld_tap - ky * p.kw;
-      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
@@ -569,7 +584,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const bool live = ld_tap < 32;
       const int tp = live ? ld_tap : 0;
       const int ky = tp / p.kw, kx = tp - ky * p.kw;
-      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, live, adelta, bdelta, ky, kx, tp);
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const bool live = ld_tap < 32;
       const int tp = live ? ld_tap : 0;
       const int ky = tp / p.kw, kx = tp - ky * p.kw;
-      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * 4u;
+      const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
       static_for<NCH>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -750,6 +765,61 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
     }
   };
+  if constexpr (Y16) {
+    // fp16 output: bias + ReLU in fp32, ONE rounding to half (RNE), then the BM x BN tile is transposed through
+    // the operand LDS (idle now) so that it leaves as 16-byte runs of 8 channels -- 8 lanes cover 128 contiguous
+    // bytes of a pixel -- instead of one 2-byte store per accumulator element (global stores are issue-bound).
+    // Lanes (n, n+1) of a 32x32 block hold neighbouring channels of the same 16 rows: the even lane takes row
+    // e of both, the odd lane row e+1 of both (one DPP quad_perm exchange per row pair), each packs its pair and
+    // writes one dword; rows are BN halfs = BN/2 dwords apart, unpadded (the b128 read-back is conflict-free).
+    constexpr int RD = BN / 2;           // dwords per tile row
+    constexpr int CPR = BN / 8;          // 16-byte chunks per tile row
+    static_assert((BM * CPR) % NT == 0, "tile chunks must divide evenly over the workgroup");
+    unsigned* Ct = reinterpret_cast<unsigned*>(smem);
+    __syncthreads();                     // every wave is done reading the operand buffers
+    const bool odd = (li & 1) != 0;
+    const bool relu16 = p.relu != 0;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + (wn * TN + ni) * 32 + li;
+      const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+      const int cdw = ((wn * TN + ni) * 32 + (li & ~1)) >> 1;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          float v0 = acc[mi][ni][e] + bv, v1 = acc[mi][ni][e + 1] + bv;
+          v0 = relu16 ? fmaxf(v0, 0.f) : v0;
+          v1 = relu16 ? fmaxf(v1, 0.f) : v1;
+          const float send = odd ? v0 : v1;
+          const float recv = __builtin_bit_cast(
+              float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */,
+                                                 0xF, 0xF, false));
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const f16x2 pk = {(_Float16)(odd ? recv : v0), (_Float16)(odd ? v1 : recv)};
+          const int row = (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh + (odd ? 1 : 0);
+          Ct[row * RD + cdw] = __builtin_bit_cast(unsigned, pk);
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned row_b16 = (unsigned)p.ldy * 2u;
+    const int rows16 = p.M - m0;
+    const unsigned long long span16 = (unsigned long long)(rows16 < BM ? rows16 : BM) * row_b16;
+    const __amdgpu_buffer_rsrc_t rsY16 = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.y) + (unsigned long long)m0 * row_b16, 0, (int)span16, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (BM * CPR) / NT; ++j) {
+      const int id = tid + j * NT;
+      const int row = id / CPR, ch = id % CPR;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Ct + row * RD + ch * 4);
+      const int n = n0 + ch * 8;
+      // rows past M fail the range check; chunks past Cout (a partial last column tile) are dropped here
+      const unsigned voff = (n < p.Cout) ? (unsigned)row * row_b16 + (unsigned)n * 2u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsY16, voff, 0, 0);
+    }
+    return;
+  }
   if constexpr (HEAD_EPI) {
     switch (p.epilogue) {
       case KFN_EPI_L2NORM: epilogue(std::integral_constant<int, KFN_EPI_L2NORM>{}); break;
@@ -783,7 +853,9 @@ const TileCfg* find_cfg(int cfg) {
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int F16 = PREC_F32>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = (F16 == PREC_F32_N16 ? 16 : 32) * TN * WN, NT = 64 * WM * WN;
-  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
+  constexpr size_t smem_ops = (size_t)2 * (BM + BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
+  constexpr size_t smem_epi = (F16 == PREC_F16_Y || F16 == PREC_F16_XY) ? (size_t)BM * BN * 2 : 0;   // fp16 output tile
+  constexpr size_t smem = smem_ops > smem_epi ? smem_ops : smem_epi;
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
   a.tiles_n = kfn::ceil_div(a.Cout, BN);
@@ -827,6 +899,31 @@ int dispatch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   }
 }
 
+// fp16 ACTIVATIONS (kfn_conv_desc.x_dtype / y_dtype = KFN_ACT_F16): the wide-tile instantiations only.
+template <int BK, int PREC>
+int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
+  switch (cfg) {
+    case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-activation instantiation", cfg);
+  }
+}
+// tile for an fp16-activation layer: the four instantiations above, wide outputs on 128x128
+int f16io_config(const kfn_conv_desc* d, int M) {
+  int cfg = d->config;
+  if (cfg == KFN_CFG_AUTO) {
+    cfg = d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_192x64;
+    (void)M;
+  }
+  return cfg;
+}
+int f16io_bk(const kfn_conv_desc* d) {
+  if (d->k_step == 16 || d->Cin % 64 != 0) return 16;
+  return 32;
+}
+
 // Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) over the CUs.
 int auto_config(int M, int Cout, int num_cu, bool wino = false, bool n16 = false) {
   double best = -1.0;
@@ -851,7 +948,7 @@ int g_num_cu = 0;
 // CU (VGPR-limited to 3 waves/SIMD): measured +3 % (160x128), +16 % (192x64), +33 % (256x32)
 // over BK = 32 on the direct kernel.  The Winograd GEMMs need the 128x128 tile for that
 // (166 VGPRs; the 160x128 one has 205): 128x128x16 beats 160x128x32 by 1-7 %.
-// (BK = 32 stays instantiated for the fp32 modes and is reachable only by editing pick_bk.)
+// (k-step 32 is instantiated for the fp16-activation kernels only.)
 int pick_bk(int cin, int mode) {
   (void)cin; (void)mode;
   return 16;
@@ -928,10 +1025,11 @@ extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int
   int Ho, Wo, pt, pl;
   out_shape(d, &Ho, &Wo, &pt, &pl);
   const int M = d->N * Ho * Wo;
-  *config = pick_config(d, M);
+  const bool y16 = d->y_dtype == KFN_ACT_F16;
+  *config = y16 ? f16io_config(d, M) : pick_config(d, M);
   const TileCfg* c = find_cfg(*config);
   KFN_REQUIRE(c, "kfn_conv2d_plan: unknown config %d", *config);
-  *bk = pick_bk(d->Cin, d->transposed ? MODE_DECONV : MODE_CONV);
+  *bk = y16 ? f16io_bk(d) : pick_bk(d->Cin, d->transposed ? MODE_DECONV : MODE_CONV);
   *tiles = kfn::ceil_div(M, c->bm) * kfn::ceil_div(d->Cout, c->bn);
   return KFN_OK;
 }
@@ -953,7 +1051,20 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   out_shape(d, &a.Ho, &a.Wo, &a.pad_t, &a.pad_l);
   const long M = (long)d->N * a.Ho * a.Wo;
   const long in_pix = (long)d->N * d->H * d->W;
-  const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * 4L;
+  const bool x16 = d->x_dtype == KFN_ACT_F16, y16 = d->y_dtype == KFN_ACT_F16;
+  KFN_REQUIRE((d->x_dtype == KFN_ACT_F32 || x16) && (d->y_dtype == KFN_ACT_F32 || y16),
+              "kfn_conv2d_nhwc: unknown activation dtype %d / %d", d->x_dtype, d->y_dtype);
+  if (x16 || y16) {
+    KFN_REQUIRE(d->operand_dtype == KFN_OPERAND_F16 && !d->transposed,
+                "kfn_conv2d_nhwc: fp16 activations need operand_dtype KFN_OPERAND_F16 and a forward convolution");
+    KFN_REQUIRE(!x16 || d->ldx % 8 == 0, "kfn_conv2d_nhwc: fp16 input needs ldx %% 8 == 0 (ldx=%d)", d->ldx);
+    KFN_REQUIRE(!y16 || (d->ldy % 8 == 0 && d->Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                         d->epilogue == KFN_EPI_NONE),
+                "kfn_conv2d_nhwc: fp16 output needs Cout %% 8 == 0, ldy %% 8 == 0, a 16-byte aligned y and no head epilogue");
+  }
+  KFN_REQUIRE(d->k_step == 0 || d->k_step == 16 || d->k_step == 32, "kfn_conv2d_nhwc: k_step must be 0, 16 or 32");
+  const long xb = x16 ? 2L : 4L;
+  const long x_bytes = ((in_pix - 1) * d->ldx + d->Cin) * xb;
   a.Ktot = d->kh * d->kw * d->Cin;
   const bool x3 = d->operand_dtype == KFN_OPERAND_F16X3;
   const bool f16 = d->operand_dtype == KFN_OPERAND_F16 || x3;
@@ -965,7 +1076,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   // 32-bit byte offsets (+ the OOB marker 2^31): weights below 2 GiB, and the images one
   // 160-row tile can touch below 2 GiB (the A descriptor is re-based per tile).
   KFN_REQUIRE(!d->transposed || x_bytes < (1L << 31), "kfn_conv2d_nhwc: transposed conv input above 2 GiB");
-  const long img_bytes = (long)d->H * d->W * d->ldx * 4L;
+  const long img_bytes = (long)d->H * d->W * d->ldx * xb;
   const long imgs_per_tile = 160 / ((long)a.Ho * a.Wo) + 2;
   KFN_REQUIRE(M < (1L << 31) && w_bytes < (1L << 31) && img_bytes * imgs_per_tile < (1L << 31),
               "kfn_conv2d_nhwc: tensor too large for 32-bit buffer addressing (image %ld B, w %ld B)", img_bytes,
@@ -982,15 +1093,28 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
     KFN_REQUIRE(!d->transposed, "kfn_conv2d_nhwc: f16x3 operands are implemented for forward convolutions only");
     return dispatch_cfg<16, MODE_CONV, PREC_F16X3>(cfg, a, s);
   }
+  if (x16 || y16) {
+    // fp16 activations end to end (BASELINE config 5): wide tiles, k-step 32 (64 channels per stage) when Cin allows
+    if (y16) {
+      const int c16 = f16io_config(d, a.M);
+      if (f16io_bk(d) == 32)
+        return x16 ? dispatch_f16io<32, PREC_F16_XY>(c16, a, s) : dispatch_f16io<32, PREC_F16_Y>(c16, a, s);
+      return x16 ? dispatch_f16io<16, PREC_F16_XY>(c16, a, s) : dispatch_f16io<16, PREC_F16_Y>(c16, a, s);
+    }
+    // fp16 in, fp32 out (the heads: 'prediction' with its exp epilogue): the narrow tiles
+    switch (cfg) {
+      case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, 16, MODE_CONV, PREC_F16_X>(a, s);
+      case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, 16, MODE_CONV, PREC_F16_X>(a, s);
+      case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, 16, MODE_CONV, PREC_F16_X>(a, s);
+      case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_X>(a, s);
+      default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-input instantiation", cfg);
+    }
+  }
   if (f16) {
     if (d->transposed) return dispatch_cfg<16, MODE_DECONV, PREC_F16>(cfg, a, s);
     return dispatch_cfg<16, MODE_CONV, PREC_F16>(cfg, a, s);
   }
-  if (d->transposed) {
-    if (pick_bk(d->Cin, MODE_DECONV) == 32) return dispatch_cfg<32, MODE_DECONV>(cfg, a, s);
-    return dispatch_cfg<16, MODE_DECONV>(cfg, a, s);
-  }
-  if (pick_bk(d->Cin, MODE_CONV) == 32) return dispatch_cfg<32, MODE_CONV>(cfg, a, s);
+  if (d->transposed) return dispatch_cfg<16, MODE_DECONV>(cfg, a, s);
   return dispatch_cfg<16, MODE_CONV>(cfg, a, s);
 }
 
@@ -1119,8 +1243,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   KFN_REQUIRE(phases >= 1 && phases <= 3, "kfn_conv2d_winograd: phases must be 1 (GEMMs), 2 (output) or 3");
   if (phases & 1) {
-    rc = (pick_bk(d->Cin, MODE_WINO) == 32) ? dispatch_cfg<32, MODE_WINO>(cfg, a, s)
-                                            : dispatch_cfg<16, MODE_WINO>(cfg, a, s);
+    rc = dispatch_cfg<16, MODE_WINO>(cfg, a, s);
     if (rc != KFN_OK) return rc;
   }
   if (!(phases & 2)) return KFN_OK;

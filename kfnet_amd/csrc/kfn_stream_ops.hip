@@ -20,9 +20,11 @@ constexpr int FT_TW3 = (FT_W + 2) * 3;
 // channels [4s, 4s+4) (27 float4 weights in registers), so a pixel's C floats leave the
 // wave as one contiguous LP*16-byte run and the 64/LP pixels a wave handles per round are
 // x-adjacent: fully coalesced stores (the layer is store-bound: 98 MB/frame written).
-template <int LP>
+// OUT16: the head's output tensor holds IEEE halfs (BASELINE config 5, fp16 activations): the four channels of a
+// lane are rounded once (RNE) and leave as one 8-byte store, a pixel's C halfs as one contiguous LP*8-byte run.
+template <int LP, bool OUT16 = false>
 __device__ __forceinline__ void first_head(const float* tile, const float* __restrict__ w,
-                                           const float* __restrict__ b, float* __restrict__ y,
+                                           const float* __restrict__ b, void* __restrict__ yv,
                                            int n, int H, int W, int x0, int y0, int tid) {
   constexpr int C = LP * 4;
   constexpr int SLOTS = 256 / LP;            // pixels in flight per block round
@@ -51,15 +53,22 @@ __device__ __forceinline__ void first_head(const float* tile, const float* __res
     }
     if (gx < W && gy < H) {
       f32x4 v = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
-      *reinterpret_cast<f32x4*>(y + (((size_t)n * H + gy) * W + gx) * C + s * 4) = v;
+      const size_t e = (((size_t)n * H + gy) * W + gx) * C + s * 4;
+      if constexpr (OUT16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<f16x4*>(static_cast<_Float16*>(yv) + e) = h;
+      } else {
+        *reinterpret_cast<f32x4*>(static_cast<float*>(yv) + e) = v;
+      }
     }
   }
 }
 
-template <int LP1, int LP2>
+template <int LP1, int LP2, bool OUT16_1 = false>
 __global__ __launch_bounds__(256) void first_conv_kernel(
     const uint8_t* __restrict__ img, int N, int H, int W,
-    const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y1,
+    const float* __restrict__ w1, const float* __restrict__ b1, void* __restrict__ y1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y2) {
   __shared__ float tile[(FT_H + 2) * FT_TW3];
   const int tid = threadIdx.x;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(
     tile[i] = v;
   }
   __syncthreads();
-  first_head<LP1>(tile, w1, b1, y1, n, H, W, x0, y0, tid);
+  first_head<LP1, OUT16_1>(tile, w1, b1, y1, n, H, W, x0, y0, tid);
   if constexpr (LP2 > 0) first_head<LP2>(tile, w2, b2, y2, n, H, W, x0, y0, tid);
 }
 
@@ -299,17 +308,36 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
 
 }  // namespace
 
+extern "C" int kfn_first_conv_u8_ex(const uint8_t* img, int N, int H, int W, const float* w1, const float* b1,
+                                    void* y1, int C1, int y1_dtype, const float* w2, const float* b2, float* y2,
+                                    int C2, void* stream);
+
 extern "C" int kfn_first_conv_u8(const uint8_t* img, int N, int H, int W, const float* w1,
                                  const float* b1, float* y1, int C1, const float* w2,
                                  const float* b2, float* y2, int C2, void* stream) {
+  return kfn_first_conv_u8_ex(img, N, H, W, w1, b1, y1, C1, KFN_ACT_F32, w2, b2, y2, C2, stream);
+}
+
+extern "C" int kfn_first_conv_u8_ex(const uint8_t* img, int N, int H, int W, const float* w1, const float* b1,
+                                    void* y1, int C1, int y1_dtype, const float* w2, const float* b2, float* y2,
+                                    int C2, void* stream) {
   KFN_REQUIRE(img && w1 && y1, "kfn_first_conv_u8: null argument");
+  KFN_REQUIRE(y1_dtype == KFN_ACT_F32 || y1_dtype == KFN_ACT_F16, "kfn_first_conv_u8: unknown output dtype %d", y1_dtype);
   KFN_REQUIRE(N > 0 && H > 0 && W > 0, "kfn_first_conv_u8: bad shape");
   KFN_REQUIRE(C2 == 0 || (w2 && y2), "kfn_first_conv_u8: second head needs w2/y2");
   dim3 grid(kfn::ceil_div(W, FT_W), kfn::ceil_div(H, FT_H), N), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define KFN_FIRST(L1, L2)                                                                     \
   hipLaunchKernelGGL((first_conv_kernel<L1, L2>), grid, block, 0, s, img, N, H, W, w1, b1, y1, w2, b2, y2)
-  if (C1 == 64 && C2 == 16) KFN_FIRST(16, 4);
+  if (y1_dtype == KFN_ACT_F16) {
+    // fp16 activations (BASELINE config 5): the wide head (SCoordNet conv1a) writes halfs, a second head stays fp32
+    if (C1 == 64 && C2 == 16)
+      hipLaunchKernelGGL((first_conv_kernel<16, 4, true>), grid, block, 0, s, img, N, H, W, w1, b1, y1, w2, b2, y2);
+    else if (C1 == 64 && C2 == 0)
+      hipLaunchKernelGGL((first_conv_kernel<16, 0, true>), grid, block, 0, s, img, N, H, W, w1, b1, y1, w2, b2, y2);
+    else
+      return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_first_conv_u8: fp16 output is instantiated for head widths 64(+16) only");
+  } else if (C1 == 64 && C2 == 16) KFN_FIRST(16, 4);
   else if (C1 == 64 && C2 == 0) KFN_FIRST(16, 0);
   else if (C1 == 16 && C2 == 0) KFN_FIRST(4, 0);
   else if (C1 == 32 && C2 == 0) KFN_FIRST(8, 0);

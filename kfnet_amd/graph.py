@@ -33,13 +33,16 @@ def current_scope():
     return '/'.join(_scope_stack)
 
 
+ELEM_BYTES = {'f32': 4, 'f16': 2, 'u8': 1}
+
+
 class _Shape(list):
     def as_list(self):
         return list(self)
 
 
 class Storage(object):
-    """A flat device buffer of `numel` elements of `dtype` ('f32' | 'u8')."""
+    """A flat device buffer of `numel` elements of `dtype` ('f32' | 'f16' | 'u8')."""
 
     def __init__(self, numel, dtype='f32'):
         self.numel = int(numel)
@@ -49,7 +52,7 @@ class Storage(object):
     def allocate(self, device):
         import torch
         if self.buf is None:
-            dt = torch.float32 if self.dtype == 'f32' else torch.uint8
+            dt = {'f32': torch.float32, 'f16': torch.float16, 'u8': torch.uint8}[self.dtype]
             self.buf = torch.zeros(self.numel, dtype=dt, device=device)
         return self.buf
 
@@ -116,8 +119,7 @@ class Tensor(object):
 
     @property
     def ptr(self):
-        esz = 4 if self.dtype == 'f32' else 1
-        return self.root_storage.ptr + (self.elem_off + self.ch_off) * esz
+        return self.root_storage.ptr + (self.elem_off + self.ch_off) * ELEM_BYTES[self.dtype]
 
     def is_whole(self):
         return self.base is None and self._off == 0 and self._ld == self.shape[3]
@@ -160,7 +162,7 @@ class Tensor(object):
         import torch
         n, h, w, c = self.shape
         arr = np.ascontiguousarray(arr).reshape(n, h, w, c)
-        want = np.float32 if self.dtype == 'f32' else np.uint8
+        want = {'f32': np.float32, 'f16': np.float16, 'u8': np.uint8}[self.dtype]
         if arr.dtype != want:
             raise TypeError('tensor %r wants %s, got %s' % (self.name, want, arr.dtype))
         assert self.ld == c and self.ch_off == 0, 'upload needs a channel-dense tensor'
@@ -339,6 +341,7 @@ class ConvOp(Op):
         self.epilogue = epilogue
         self.config = config
         self.operand_dtype = operand_dtype
+        self.k_step = 0           # 0 = the library's choice
         self._desc = None
 
     def desc(self):
@@ -347,7 +350,9 @@ class ConvOp(Op):
         d = _lib.ConvDesc(N=_scaled(n, self.x.graph), H=h, W=w, Cin=cin, ldx=self.x.ld, Cout=cout,
                           cout_pad=-(-cout // 32) * 32, ldy=self.y.ld, kh=self.kh, kw=self.kw,
                           stride=self.stride, transposed=int(self.transposed), relu=int(self.relu),
-                          epilogue=self.epilogue, config=self.config, operand_dtype=self.operand_dtype)
+                          epilogue=self.epilogue, config=self.config, operand_dtype=self.operand_dtype,
+                          x_dtype=_lib.ACT_F16 if self.x.dtype == 'f16' else _lib.ACT_F32,
+                          y_dtype=_lib.ACT_F16 if self.y.dtype == 'f16' else _lib.ACT_F32, k_step=self.k_step)
         return d
 
     def flops(self):
@@ -361,6 +366,8 @@ class ConvOp(Op):
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
                 6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2),
                 10: (2, 1, 4, 1), 11: (1, 1, 4, 1)}   # 10/11: 16-column variants (PREC tag 3)
+    # template tag PREC of conv_mfma_kernel for fp16 activations: (x is f16, y is f16) -> 4 / 5 / 6
+    PREC_F16_IO = {(True, False): 4, (False, True): 5, (True, True): 6}
 
     def kernel_name(self, lib):
         """Template instantiation this op launches, spelled like rocprofv3 prints it."""
@@ -368,6 +375,9 @@ class ConvOp(Op):
         cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
         _lib.check(lib.kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
         t = self.CFG_TILE[cfg.value]
+        io = (self.x.dtype == 'f16', self.y.dtype == 'f16')
+        if self.operand_dtype == _lib.OPERAND_F16 and io != (False, False):
+            return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 0, %d>' % (t + (bk.value if io[1] else 16, self.PREC_F16_IO[io]))
         if self.operand_dtype == _lib.OPERAND_F16:
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, 1>' % (t + (1 if self.transposed else 0,))
         if self.operand_dtype == _lib.OPERAND_F16X3:
@@ -543,13 +553,19 @@ class FirstConvOp(Op):
         h1 = self.heads[0]
         for hd in self.heads:
             assert hd[1].is_whole(), 'first-layer outputs must be whole buffers'
+        # an fp16 head (BASELINE config 5: SCoordNet conv1a) must be the first one
+        if len(self.heads) == 2 and self.heads[1][1].dtype == 'f16':
+            self.heads.reverse()
+            h1 = self.heads[0]
+        dt1 = _lib.ACT_F16 if h1[1].dtype == 'f16' else _lib.ACT_F32
         if len(self.heads) == 2:
             h2 = self.heads[1]
-            rc = lib.kfn_first_conv_u8(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3],
-                                       h2[2].ptr, h2[3].ptr, h2[1].ptr, h2[1].shape[3], stream)
+            assert h2[1].dtype == 'f32', 'only one first-layer head can write fp16'
+            rc = lib.kfn_first_conv_u8_ex(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3], dt1,
+                                          h2[2].ptr, h2[3].ptr, h2[1].ptr, h2[1].shape[3], stream)
         else:
-            rc = lib.kfn_first_conv_u8(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3],
-                                       None, None, None, 0, stream)
+            rc = lib.kfn_first_conv_u8_ex(self.img.ptr, n, h, w, h1[2].ptr, h1[3].ptr, h1[1].ptr, h1[1].shape[3], dt1,
+                                          None, None, None, 0, stream)
         _lib.check(rc, 'kfn_first_conv_u8')
 
 
@@ -880,6 +896,11 @@ class Graph(object):
         # 'f16x3': forward convs split every operand into hi+lo halfs (3 fp16 MFMAs per product,
         # fp32 accumulate): fp32-class accuracy at the fp16 MFMA rate (experimental, opt-in).
         self.conv_operands = 'f32'
+        # 'f16' mode only: convolutions under these variable scopes keep their ACTIVATIONS in fp16 in memory
+        # (outputs with >= 64 channels; every consumer there is another convolution).  SCoordNet is 94 % of the
+        # FLOPs and of the activation traffic; the flow-feature tower and OFlowNet (cost-volume gather, concat
+        # views, patch-resident tail) stay fp32 in memory.  () = fp32 activations everywhere (round 2's form).
+        self.f16_activation_scopes = ('ScoreNet',)
         self.f16x3_min_channels = 64
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
 

@@ -23,7 +23,7 @@ def sync():
 
 
 def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config=0, ldx=None, ldy=None,
-             x_off=0, y_off=0, f16=False, x3=False):
+             x_off=0, y_off=0, f16=False, x3=False, x16=False, y16=False, k_step=0):
     """x [N,H,W,Cin] np fp32; w TF layout; returns y np [N,Ho,Wo,Cout] computed by the HIP library.
     ldx/ldy > C exercise the strided-view paths (input/output living in wider buffers)."""
     import torch
@@ -39,11 +39,13 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
         wp = pack_conv_kernel(w)
     ldx = ldx or cin
     ldy = ldy or cout
-    xb = np.full((n * h * wd, ldx), 7.0, dtype=np.float32)
+    # x16 / y16: the activation tensors hold IEEE halfs in memory (kfn_conv_desc.x_dtype / y_dtype)
+    xb = np.full((n * h * wd, ldx), 7.0, dtype=np.float16 if x16 else np.float32)
     xb[:, x_off:x_off + cin] = x.reshape(-1, cin)
     xd = dev(xb)
     GUARD = 96   # rows behind the tensor: the last (partial) tile must not write past row M
-    yd = torch.full((n * ho * wo + GUARD, ldy), -123.0, dtype=torch.float32, device='cuda')
+    yd = torch.full((n * ho * wo + GUARD, ldy), -123.0, dtype=torch.float16 if y16 else torch.float32, device='cuda')
+    xsz, ysz = (2 if x16 else 4), (2 if y16 else 4)
     if x3:
         m = wp * np.float32(1024.0)
         hi = m.astype(np.float16)
@@ -54,12 +56,12 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     bd = dev(b.astype(np.float32)) if b is not None else None
     d = _lib.ConvDesc(N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, cout_pad=wp.shape[0], ldy=ldy, kh=kh, kw=kw,
                       stride=stride, transposed=int(transposed), relu=int(relu), epilogue=epilogue, config=config,
-                      operand_dtype=2 if x3 else int(f16))
-    rc = lib.kfn_conv2d_nhwc(C.byref(d), xd.data_ptr() + 4 * x_off, wd_.data_ptr(),
-                             bd.data_ptr() if bd is not None else None, yd.data_ptr() + 4 * y_off, stream())
+                      operand_dtype=2 if x3 else int(f16), x_dtype=int(x16), y_dtype=int(y16), k_step=k_step)
+    rc = lib.kfn_conv2d_nhwc(C.byref(d), xd.data_ptr() + xsz * x_off, wd_.data_ptr(),
+                             bd.data_ptr() if bd is not None else None, yd.data_ptr() + ysz * y_off, stream())
     _lib.check(rc, 'kfn_conv2d_nhwc')
     sync()
-    yh = yd.cpu().numpy()
+    yh = yd.cpu().numpy().astype(np.float32)
     assert np.all(yh[n * ho * wo:] == -123.0), 'conv wrote past the last output row'
     yh = yh[:n * ho * wo]
     out = yh[:, y_off:y_off + cout].reshape(n, ho, wo, cout)

@@ -497,6 +497,88 @@ def test_conv_fp16_operands(case, config):
     assert np.abs(y - full).max() < 2e-2 and np.abs(y - full).max() > 0   # it really is reduced precision
 
 
+F16_ACT_CASES = [
+    # N, H, W, Cin, Cout, k, stride
+    (1, 16, 24, 64, 64, 3, 1),        # conv1b class: Cout 64 -> the 192x64 tile, one 64-channel stage per tap
+    (2, 13, 17, 64, 256, 3, 2),       # conv2a class: stride 2, odd size (pad (1,1)), partial last row tile
+    (1, 12, 20, 256, 256, 3, 1),      # conv2b class: two column tiles
+    (1, 9, 11, 128, 72, 3, 1),        # Cout % 64 != 0: the chunks past Cout of the last column tile are dropped
+    (3, 6, 10, 256, 128, 1, 1),       # conv7 class: 1x1
+    (1, 60, 80, 96, 160, 3, 1),       # Cin % 64 != 0 -> k-step 16; M = 4800
+    (7, 1, 1, 128, 128, 3, 1),        # 1x1 images: only the centre tap is live
+]
+
+
+@pytest.mark.parametrize('case', F16_ACT_CASES)
+@pytest.mark.parametrize('config,k_step', [(0, 0), (2, 16), (2, 32), (9, 16), (9, 32), (7, 0), (3, 0)])
+def test_conv_fp16_activations(case, config, k_step):
+    """x_dtype = y_dtype = KFN_ACT_F16 (BASELINE config 5, fp16 activations end to end): the input tensor holds
+    halfs, the output is ONE RNE rounding of the fp32 result.  Reference: an fp64 convolution of the fp16 input and
+    fp16-rounded weights; tolerance = the fp32 accumulation bound + half an fp16 ulp of the result."""
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co, k, s = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float16)
+    wt = (rng.normal(size=(k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=k_step)
+    ref = O.conv2d_same(x.astype(np.float64), wt.astype(np.float16).astype(np.float64), b, s, True)
+    tol = _conv_tol(x.astype(np.float32), wt) + np.abs(ref) * 2.0 ** -11 + 1e-7
+    assert y.shape == ref.shape
+    assert np.all(np.abs(y - ref) <= tol), float((np.abs(y - ref) - tol).max())
+
+
+@pytest.mark.parametrize('x16,y16', [(True, False), (False, True)])
+def test_conv_fp16_activations_mixed_and_strided(x16, y16):
+    """fp16 in -> fp32 out (the 'prediction' head, with its exp epilogue on a narrow tile) and fp32 in -> fp16 out,
+    through strided views (ldx / ldy count ELEMENTS, the untouched columns must keep their contents)."""
+    from kfnet_amd import _lib
+    from tests.gpu_util import run_conv
+    rng = np.random.default_rng(77)
+    ci, co = 128, (4 if x16 else 64)
+    x = rng.normal(size=(2, 9, 12, ci)).astype(np.float16 if x16 else np.float32)
+    wt = (rng.normal(size=(1, 1, ci, co)) / np.sqrt(ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    y = run_conv(x, wt, b, 1, not x16, f16=True, x16=x16, y16=y16, ldx=ci + 64, x_off=32, ldy=co + 24, y_off=8,
+                 epilogue=_lib.EPI_EXP_CH3 if x16 else 0)
+    xr = x.astype(np.float16).astype(np.float64)
+    ref = O.conv2d_same(xr, wt.astype(np.float16).astype(np.float64), b, 1, not x16)
+    if x16:
+        ref[..., 3] = np.exp(ref[..., 3])
+    tol = _conv_tol(x.astype(np.float32), wt) * (4.0 if x16 else 1.0) + (np.abs(ref) * 2.0 ** -11 if y16 else 0.0)
+    assert np.all(np.abs(y - ref) <= tol)
+
+
+def test_first_conv_fp16_head():
+    """kfn_first_conv_u8_ex with an fp16 first head (config 5: SCoordNet conv1a) beside an fp32 second head: the
+    fp16 head equals the fp32 kernel's result rounded once; the second head is bit-identical to the fp32 call."""
+    import torch
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_first_kernel
+    from tests.gpu_util import dev, stream, sync
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    N, H, W = 2, 37, 70
+    img = rng.integers(0, 256, size=(N, H, W, 3)).astype(np.uint8)
+    w1 = (rng.normal(size=(3, 3, 3, 64)) / 5).astype(np.float32)
+    w2 = (rng.normal(size=(3, 3, 3, 16)) / 5).astype(np.float32)
+    b1, b2 = rng.normal(size=64).astype(np.float32), rng.normal(size=16).astype(np.float32)
+    di, dw1, dw2, db1, db2 = dev(img), dev(pack_first_kernel(w1)), dev(pack_first_kernel(w2)), dev(b1), dev(b2)
+    y1 = torch.empty((N, H, W, 64), dtype=torch.float32, device='cuda')
+    y2 = torch.empty((N, H, W, 16), dtype=torch.float32, device='cuda')
+    _lib.check(lib.kfn_first_conv_u8(di.data_ptr(), N, H, W, dw1.data_ptr(), db1.data_ptr(), y1.data_ptr(), 64,
+                                     dw2.data_ptr(), db2.data_ptr(), y2.data_ptr(), 16, stream()), 'first')
+    h1 = torch.full((N, H, W, 64), -5.0, dtype=torch.float16, device='cuda')
+    z2 = torch.empty((N, H, W, 16), dtype=torch.float32, device='cuda')
+    _lib.check(lib.kfn_first_conv_u8_ex(di.data_ptr(), N, H, W, dw1.data_ptr(), db1.data_ptr(), h1.data_ptr(), 64,
+                                        _lib.ACT_F16, dw2.data_ptr(), db2.data_ptr(), z2.data_ptr(), 16, stream()), 'first16')
+    sync()
+    assert torch.equal(z2, y2)
+    assert torch.equal(h1, y1.half())
+    ref = O.conv2d_same(O.preprocess(img, np.float64), w1, b1, 1, True)
+    assert np.abs(y1.cpu().numpy() - ref).max() < 1e-4
+
+
 def test_deconv_fp16_operands():
     from tests.gpu_util import run_conv
     rng = np.random.default_rng(31)

@@ -215,3 +215,28 @@ def test_epilogue_on_a_winograd_routed_layer_reroutes_to_the_direct_kernel():
     assert any(isinstance(op, WinogradConvOp) for op in net.feat_tower.ops)
     with pytest.raises(KeyError):
         net.feat_tower.set_epilogue('no_such_layer', _lib.EPI_L2NORM)
+
+
+def test_bench_telemetry_picks_the_busy_card_and_parses_sysfs(tmp_path):
+    """bench.py's clock / power sampler on a fake sysfs tree: partition nodes (no pp_dpm_sclk) are ignored;
+    when the PCI address cannot be matched (no GPU here) every card is watched and the busiest reported."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kfn_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for i, (busy, mhz, uw) in enumerate([(0, 132, 90000000), (97, 2104, 912000000)]):
+        d = tmp_path / ('card%d' % i) / 'device'
+        (d / 'hwmon' / 'hwmon3').mkdir(parents=True)
+        (d / 'pp_dpm_sclk').write_text('0: 132Mhz %s\n1: %dMhz %s\n' % ('*' if mhz == 132 else '', mhz, '' if mhz == 132 else '*'))
+        (d / 'gpu_busy_percent').write_text('%d\n' % busy)
+        (d / 'hwmon' / 'hwmon3' / 'power1_average').write_text('%d\n' % uw)
+    (tmp_path / 'card9' / 'device').mkdir(parents=True)      # a partition node
+    t = bench.Telemetry(0, period=0.02, sysfs=str(tmp_path))
+    with t:
+        time.sleep(0.2)
+    s = t.summary()
+    assert s['samples_during_timed_region'] >= 3 and 'card1' in s['source'] and 'busiest of 2' in s['source']
+    assert s['sclk_mhz']['mean'] == 2104.0 and s['power_w']['max'] == 912.0 and s['busy_pct']['min'] == 97
+    assert s['after']['sclk_mhz'] == 2104.0
