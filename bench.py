@@ -638,6 +638,7 @@ def bench_c5(args, device):
     med = float(np.median(times))
     PF = min(T, 16)     # frames per sequence of the parity sample
     rec16 = eng.process_sequences(dev)[:, :PF].cpu().numpy().copy()
+    flow16 = eng.debug(S * T)['flow'].reshape(S, T, eng.h, eng.w, 2)[:, :PF].copy()
     rows = per_kernel_profile(eng, dev[0])
     by_kernel = {}
     for r in rows:
@@ -688,15 +689,17 @@ def bench_c5(args, device):
         flow32 = eng32.debug(S * PF)['flow'].reshape(S, PF, eng32.h, eng32.w, 2)
         from kfnet_amd.tools.parity import masked_parity, merge_parity
         mp = merge_parity([masked_parity(rec16[s_], r32[s_], flow32[s_], coord_tol=2e-2, conf_rel_tol=5e-2,
-                                         delta=C5_DELTA_PX, reset_period=500) for s_ in range(S)])
+                                         delta=C5_DELTA_PX, reset_period=500, test_flow=flow16[s_]) for s_ in range(S)])
         mp['sequences'] = S
-        mp['note'] = ('fp16 path vs the fp32 HIP path (itself held to the oracle at 1e-4 in tests/) on the first %d frames '
-                      'of every sequence.  The tolerance (coord max-abs <= 2e-2, confidence max-rel <= 5e-2) is stated on '
-                      'the pixels whose fp32 sample position pixel_map + flow stays >= %.2f px away from the steps of the '
-                      'reference sampler (x in {0, W-1}, y in {0, H-1}: tools/util.py:36-93 returns 0 outside, the border '
-                      'value inside) and that have not read such a pixel since the last reset (kfnet_amd/tools/parity.py); '
-                      '`masked_fraction` of the pixels is excluded, `unmasked_outside_tolerance` must be 0'
-                      % (PF, C5_DELTA_PX))
+        mp['note'] = ('fp16 path vs the fp32 HIP path (itself held to the oracle at 1e-4 in tests/) on the first %d frames of '
+                      'every sequence.  The reference sampler (tools/util.py:36-93) returns 0 for a sample at x < 0 or x >= W-1 '
+                      '(same in y) and the border value just inside: where the two paths\' flows (equal to flow_max_abs_diff_px) '
+                      'put a sample on different sides of such a step (`crossings`, all within crossing_max_step_distance_px '
+                      '< %.2f px of it) the pixel differs by the whole state value and hands that on to the pixels that sample '
+                      'it later.  The tolerance (coord max-abs <= 2e-2, confidence max-rel <= 5e-2) holds on EVERY pixel that '
+                      'is not such a descendant (`unmasked_outside_tolerance` = 0; the descendants are `masked_fraction` of the '
+                      'pixel-frames, kfnet_amd/tools/parity.py); `outside_tolerance_fraction` of all pixel-frames actually '
+                      'deviate by more' % (PF, C5_DELTA_PX))
         out['parity_vs_fp32_path'] = mp
     print(json.dumps(out))
 

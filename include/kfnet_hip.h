@@ -253,6 +253,23 @@ int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow
 int kfn_oflow_tail(const float* x, const float* w6_packed, const float* b6, const float* wp, const float* bp,
                    float* flow_xy, float* opt_logits, int P, int c_in, int c_mid, void* stream);
 
+/* ---- OFlowNet's two window-grid ends, window-resident (csrc/kfn_oflow_fused.hip) -------------------------
+ * Both take the per-pixel maps of the factored cost volume (see kfn_cost_volume_gather): T [N,H,W,9*32] and
+ * Gp [N,H+4,W+4,9*32], and evaluate conv0's cells (cnn_wrapper/OFlowNet.py:19 on the volume of
+ * KFNet/KFNet.py:343-359) where they need them -- conv0's [N*H*W,8,8,32] output never exists in memory.
+ *   kfn_oflow_head : conv0 -> conv1a (3x3 stride 2, 32 -> 32, ReLU; OFlowNet.py:20) -> y [N*H*W,4,4,32].
+ *                    w1_packed [144][64] per-lane fragments (kfnet_amd.graph.pack_oflow_head_kernel).
+ *   kfn_oflow_tail2: upconv0 (conv2d_transpose 3x3 stride 2, 32 -> 16, ReLU; OFlowNet.py:37) of x5 = conv5's
+ *                    output [N*H*W,4,4,32], concat0 = [upconv0 | conv0], conv6, 'prediction', softmax, soft-argmax
+ *                    (as kfn_oflow_tail) -> flow_xy [N*H*W,2].  wu_packed [72][64] (pack_oflow_upconv_kernel),
+ *                    w6_packed / wp as for kfn_oflow_tail.
+ * relu0 = conv0's activation flag.  One wave per window; all weights in registers; exact fp32 MFMAs. */
+int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* w1_packed,
+                   const float* b1, float* y, void* stream);
+int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
+                    const float* wu_packed, const float* bu, const float* w6_packed, const float* b6,
+                    const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream);
+
 /* ---- the recurrent part: warp + Kalman predict/update + NIS + transform/emit ----------
  * One launch scans T frames of S independent sequences (one workgroup per sequence,
  * state resident in LDS when it fits).  Per frame and pixel, in this order:

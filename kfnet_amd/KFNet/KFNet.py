@@ -162,6 +162,61 @@ class KFNet():
         temp_unc = self.temp.channels(3, 1) if emit_temp else None
         return temp_coord, temp_unc, state.channels(0, 3), state.channels(3, 1)
 
+    def _fuse_oflow_window(self, tt, gp, conv0, gather_op, cin):
+        """OFlowNet's two window-grid ends as window-resident launches (csrc/kfn_oflow_fused.hip):
+        [gather -> conv0.y] + conv1a  ->  kfn_oflow_head;   upconv0 + concat0 + oflow_tail  ->  kfn_oflow_tail2.
+        conv0's output, upconv0's output and concat0 are then never written.  Applied only when the graph has
+        exactly the reference's wiring (cnn_wrapper/OFlowNet.py:19-20,36-41); otherwise nothing changes."""
+        from ..graph import (OFlowHeadOp, OFlowTail2Op, OFlowTailOp, pack_bias, pack_oflow_head_kernel,
+                             pack_oflow_upconv_kernel)
+        g = self.graph
+        net_ops = self.oflownet.ops
+        if not g.fuse_oflow_window:
+            return
+        y0 = conv0.y
+        tails = [op for op in net_ops if isinstance(op, OFlowTailOp)]
+        if len(tails) != 1 or tails[0].logits is not None:
+            return
+        tail = tails[0]
+        cat = tail.x                                    # concat0 [P,8,8,48] = [upconv0 | conv0]
+        if not (y0.base is None and y0.storage is cat.storage and y0.ch_off == 16 and y0.ld == 48 and y0.shape[3] == 32):
+            return
+        c1a = [op for op in net_ops if type(op) is ConvOp and op.x is y0]
+        up0 = [op for op in net_ops if type(op) is ConvOp and op.transposed and op.y.base is None
+               and op.y.storage is cat.storage and op.y.ch_off == 0]
+        if len(c1a) != 1 or len(up0) != 1:
+            return
+        c1a, up0 = c1a[0], up0[0]
+        ok = (c1a.kh == 3 and c1a.kw == 3 and c1a.stride == 2 and not c1a.transposed and c1a.relu
+              and c1a.epilogue == _lib.EPI_NONE and c1a.y.is_whole() and c1a.y.shape[1:] == (4, 4, 32)
+              and c1a.kernel.storage is None and cin == 32
+              and up0.kh == 3 and up0.stride == 2 and up0.relu and up0.y.shape[3] == 16 and up0.x.is_whole()
+              and up0.x.shape[1:] == (4, 4, 32) and up0.kernel.storage is None and up0.x.dtype == 'f32')
+        # nobody else may read the tensors that disappear
+        gone = (y0, cat, up0.y)
+        for op in g.ops:
+            if op in (c1a, up0, tail, gather_op):
+                continue
+            if any(getattr(op, attr, None) in gone for attr in ('x', 'src', 'logits')):
+                ok = False
+        if not ok:
+            return
+        c1a.kernel.pack = pack_oflow_head_kernel
+        up0.kernel.pack = pack_oflow_upconv_kernel
+        for b in (c1a.bias, up0.bias):
+            if b is not None:
+                b.pack = pack_bias
+        head = OFlowHeadOp(tt, gp, conv0.relu, c1a.kernel, c1a.bias, c1a.y, cin)
+        tail2 = OFlowTail2Op(tt, gp, conv0.relu, up0.x, up0.kernel, up0.bias, tail.k6, tail.b6, tail.kp, tail.bpred,
+                             tail.flow)
+        for lst in (g.ops, net_ops):
+            lst.remove(gather_op)
+            lst.remove(up0)
+            lst[lst.index(c1a)] = head
+            lst[lst.index(tail)] = tail2
+        if cat.storage in g.storages:
+            g.storages.remove(cat.storage)
+
     def BuildKFCoord(self, last_coord, last_uncertainty, measure_coord, measure_uncertainty):
         """KFNet/KFNet.py:148-162 as a stand-alone launch (kfn_kalman_fuse) on packed
         [.,.,.,4] tensors; inside GetKFCoordRecursive it is fused into the scan kernel."""
@@ -254,9 +309,14 @@ class KFNet():
         if len(cv) != 1 or len(c0) != 1 or c0[0].kh != 3 or c0[0].stride != 1 or c0[0].transposed:
             return
         conv0 = c0[0]
+        net_ops = self.oflownet.ops
+        if (conv0.operand_dtype == _lib.OPERAND_F16 and g.factor_cost_volume and conv0.bias is not None
+                and conv0.kernel.storage is None):
+            # fp16-operand mode (BASELINE config 5): OFlowNet's window-grid ends run on the fp32 window-resident
+            # kernels all the same, which need the factored form of conv0 (fp32 class convolutions, 15 GFLOP / batch)
+            conv0.operand_dtype = _lib.OPERAND_F32
         if conv0.operand_dtype != _lib.OPERAND_F32:
             return   # the loader-generated volume exists for the fp32 kernel only
-        net_ops = self.oflownet.ops
         if g.factor_cost_volume and conv0.bias is not None:
             # conv0 is linear and V[p,cell] = f2[p] - f1[p+cell-4]: two per-pixel convolutions
             # with the 9 border-class kernels + one gather replace the per-cell 3x3 conv
@@ -283,6 +343,7 @@ class KFNet():
                     g.params.pop(prm.name, None)
             if vol.storage in g.storages:
                 g.storages.remove(vol.storage)
+            self._fuse_oflow_window(tt, gp, conv0, new_ops[3], c)
             return
         fused = CostVolumeConvOp(feat_map1, feat_map2, conv0.y, conv0.kernel, conv0.bias, conv0.relu, window_size)
         g.ops[g.ops.index(conv0)] = fused

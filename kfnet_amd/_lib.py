@@ -76,6 +76,8 @@ SYMBOLS = {
     'kfn_flow_softargmax': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'kfn_flow_head': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'kfn_oflow_tail': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'kfn_oflow_head': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'kfn_oflow_tail2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_kalman_scan': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_kalman_scan_ex': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_eval_metrics': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp]),

@@ -16,7 +16,7 @@ from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, Winog
                      WinogradS2ConvOp, WindowFcConvOp, as_f16,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
-                     pack_winograd_s2_kernel, current_scope)
+                     pack_winograd_s2_kernel, current_scope, pack_conv_kernel_chunked)
 
 # Zero padding in default. 'VALID' gives no padding.
 DEFAULT_PADDING = 'SAME'
@@ -233,7 +233,9 @@ class Network(object):
             self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, operand_dtype=_lib.OPERAND_F16))
             return y
         if f16:
-            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_conv_kernel))
+            # fp16 activations on either side: the tap-innermost kernels with chunk-major weights
+            pk = pack_conv_kernel_chunked if (input.dtype == 'f16' or y.dtype == 'f16') else pack_conv_kernel
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pk))
             self._emit(ConvOp(name, input, y, kern, bias, k, k, strides, relu, operand_dtype=_lib.OPERAND_F16))
             return y
         if g.conv_operands == 'f16x3' and cin % 32 == 0 and cin >= g.f16x3_min_channels:

@@ -152,6 +152,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr bool Y16 = (PREC == PREC_F16_Y || PREC == PREC_F16_XY);   // activations written as halfs
   constexpr bool F16 = (PREC == PREC_F16 || PREC == PREC_F16X3 || X16 || Y16);   // operands live in LDS as halfs
   constexpr unsigned XB = X16 ? 2u : 4u;                               // bytes per input element
+  // fp16-activation kernels walk the K dimension TAP-INNERMOST: all live taps of one channel chunk, then the next
+  // chunk.  A tile's rows re-read the same ~(BM + halo) pixels for every tap; with the taps innermost that
+  // working set is (pixels x KCH channels) -- a few KB, L1/L2 resident -- instead of (pixels x Cin), which at
+  // Cin >= 512 falls out of the 4 MiB L2 of an XCD between two taps (64 resident workgroups x 180 KB).
+  // Their weights are packed CHUNK-MAJOR for it, [K/32][cout_pad][32 halfs] (graph.pack_conv_kernel_chunked): the
+  // B tile of a stage is one (k-step 32: two) contiguous run of BN x 64 bytes, every fetched line fully used.
+  // The fp32 kernels keep the tap-outermost order (and with it their summation order) and the [Cout][K] layout.
+  constexpr bool TAP_INNER = X16 || Y16;
   constexpr bool N16 = (PREC == PREC_F32_N16);
   constexpr int CB = N16 ? 16 : 32;          // columns per MFMA sub-tile
   static_assert(!N16 || BK == 16, "the 16-column variant maps the two k-chunks of a 16-deep stage to row halves");
@@ -361,7 +369,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int i = 0; i < BP; ++i) {
     const int r = r0 + i * RPP;
     const int n = n0 + r;
-    b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * QCH) * (F16 ? 2u : 4u) : OOB;
+    if constexpr (TAP_INNER)   // chunk-major weights: 64-byte rows of a [cout_pad][32] block, the k-step-32 quads 4..7 in the next block
+      b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(((q >> 2) * p.cout_pad + n) * 64 + (q & 3) * 16) : OOB;
+    else
+      b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * QCH) * (F16 ? 2u : 4u) : OOB;
   }
 
   // ---- which taps touch at least one in-range input pixel of this tile? -----------
@@ -420,7 +431,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     }
   };
   refresh_ok();
+  const int first_tap = ld_tap;
   auto advance = [&]() {
+    if constexpr (TAP_INNER) {
+      const unsigned rest = (ld_tap < 31) ? (tapmask & ~((2u << ld_tap) - 1u)) : 0u;
+      if (rest) {
+        ld_tap = __builtin_ctz(rest);
+      } else {
+        ++ld_ci;
+        ld_c0 += KCH;
+        ld_tap = (ld_ci >= kchunks) ? 32 : first_tap;
+      }
+      refresh_ok();
+      return;
+    }
     ++ld_ci;
     ld_c0 += KCH;
     if (ld_c0 >= p.Cin) ld_c0 = 0;
@@ -573,7 +597,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     {
       const int ky = ld_tap / p.kw, kx = ld_tap - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
-      const unsigned bdelta = (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
+      const unsigned bdelta = TAP_INNER ? (unsigned)((ld_tap * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
+                                        : (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
       advance();
@@ -585,7 +610,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const int tp = live ? ld_tap : 0;
       const int ky = tp / p.kw, kx = tp - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
-      const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
+      const unsigned bdelta = TAP_INNER ? (unsigned)((tp * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
+                                        : (unsigned)(tp * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, live, adelta, bdelta, ky, kx, tp);
       advance();
@@ -609,7 +635,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const int tp = live ? ld_tap : 0;
       const int ky = tp / p.kw, kx = tp - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
-      const unsigned bdelta = (unsigned)(tp * p.Cin + ld_c0) * 4u;
+      const unsigned bdelta = TAP_INNER ? (unsigned)((tp * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
+                                        : (unsigned)(tp * p.Cin + ld_c0) * 4u;
       static_for<NCH>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int slot = c & 1;
@@ -910,18 +937,27 @@ int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-activation instantiation", cfg);
   }
 }
-// tile for an fp16-activation layer: the four instantiations above, wide outputs on 128x128
+// Tile and k-step of an fp16-activation layer (measured at config 5's shapes, tools/mb_f16.py,
+// profiles/r03_c5_layer_microbench.log): with chunk-major weights the 128x256 tile at k-step 16 (48 KiB of LDS, two
+// workgroups per CU) wins on every layer with >= 256 output channels (1000-1040 TFLOP/s; 128x128 900-940; k-step
+// 32 -- 96 KiB, one workgroup per CU -- 790-870).  desc->config / desc->k_step override either.
+void f16io_plan(const kfn_conv_desc* d, int* cfg, int* bk) {
+  int c = d->config, k = d->k_step;
+  if (c == KFN_CFG_AUTO) c = d->Cout >= 256 ? KFN_CFG_128x256 : (d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_128x64);
+  if (k == 0 || d->Cin % 64 != 0) k = 16;
+  *cfg = c;
+  *bk = k;
+}
 int f16io_config(const kfn_conv_desc* d, int M) {
-  int cfg = d->config;
-  if (cfg == KFN_CFG_AUTO) {
-    cfg = d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_192x64;
-    (void)M;
-  }
-  return cfg;
+  (void)M;
+  int c, k;
+  f16io_plan(d, &c, &k);
+  return c;
 }
 int f16io_bk(const kfn_conv_desc* d) {
-  if (d->k_step == 16 || d->Cin % 64 != 0) return 16;
-  return 32;
+  int c, k;
+  f16io_plan(d, &c, &k);
+  return k;
 }
 
 // Tile choice: maximise (useful MFMA work) / (CU-rounds * tile work) over the CUs.

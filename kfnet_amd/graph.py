@@ -216,6 +216,16 @@ def pack_conv_kernel(w):
     return out
 
 
+def pack_conv_kernel_chunked(w, chunk=32):
+    """TF HWIO [kh,kw,Cin,Cout] -> [K/chunk][cout_pad][chunk] with K = (kh,kw,ci) order: the layout of the
+    fp16-activation convolution kernels (conv_mfma_kernel PREC 4-6, csrc/kfn_conv.hip), whose B tile of a stage is
+    then one contiguous run -- every fetched cache line is fully used."""
+    m = pack_conv_kernel(w)                            # [cout_pad][K]
+    cp, K = m.shape
+    assert K % chunk == 0
+    return np.ascontiguousarray(m.reshape(cp, K // chunk, chunk).transpose(1, 0, 2))
+
+
 _WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
 
 
@@ -786,6 +796,84 @@ class OFlowTailOp(Op):
         _lib.check(rc, 'kfn_oflow_tail')
 
 
+def pack_oflow_head_kernel(w):
+    """TF HWIO [3,3,32,32] (OFlowNet conv1a) -> the per-lane fragments [144][64] of kfn_oflow_head: fragment
+    t = (tap*8 + j)*2 + nb of lane (kq = lane // 16, n = lane % 16) is w[tap][kq*8 + j][nb*16 + n]."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 32, 32)
+    wt = w.reshape(9, 4, 8, 2, 16)                     # [tap][kq][j][nb][n]
+    return np.ascontiguousarray(wt.transpose(0, 2, 3, 1, 4).reshape(144, 64))
+
+
+def pack_oflow_upconv_kernel(w):
+    """TF conv2d_transpose kernel [3,3,Cout=16,Cin=32] (OFlowNet upconv0) -> the per-lane fragments [72][64] of
+    kfn_oflow_tail2: fragment t = tap*8 + j of lane (kq, n) is w[tap][n][kq*8 + j]."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 16, 32)
+    wt = w.reshape(9, 16, 4, 8)                        # [tap][n][kq][j]
+    return np.ascontiguousarray(wt.transpose(0, 3, 2, 1).reshape(72, 64))
+
+
+class OFlowHeadOp(Op):
+    """conv0 (from the factored cost-volume maps) + conv1a in one window-resident launch (kfn_oflow_head)."""
+
+    def __init__(self, t, gp, relu0, k1, b1, y, cin):
+        self.name = 'oflow_head[conv0+conv1a]'
+        self.t, self.gp, self.relu0, self.k1, self.b1, self.y, self.cin = t, gp, relu0, k1, b1, y, cin
+
+    def kernel_name(self, lib):
+        return 'oflow_head_kernel'
+
+    def flops(self):
+        """Nominal FLOPs of the two layers this launch completes: conv0 on every window cell + conv1a."""
+        n, h, w, _ = self.t.shape
+        return 2.0 * n * h * w * (64 * 9 * self.cin * 32 + 16 * 9 * 32 * 32)
+
+    def mfma_flops(self):
+        n, h, w, _ = self.t.shape
+        return 2.0 * n * h * w * 16 * 9 * 32 * 32
+
+    def launch(self, lib, stream):
+        n, h, w, c9 = self.t.shape
+        n = _scaled(n, self.t.graph)
+        assert c9 == 288 and self.t.ld == c9 and self.gp.ld == c9 and self.y.is_whole() and self.y.shape[1:] == (4, 4, 32)
+        _lib.check(lib.kfn_oflow_head(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.k1.ptr,
+                                      self.b1.ptr if self.b1 is not None else None, self.y.ptr, stream), 'kfn_oflow_head')
+
+
+class OFlowTail2Op(Op):
+    """upconv0 + conv0 (recomputed from the maps) + conv6 + 'prediction' + softmax + soft-argmax in one
+    window-resident launch (kfn_oflow_tail2); neither concat0 nor upconv0's output exist in memory."""
+
+    def __init__(self, t, gp, relu0, x5, ku, bu, k6, b6, kp, bpred, flow, logits=None):
+        self.name = 'oflow_tail2[upconv0+conv6+prediction+softargmax]'
+        self.t, self.gp, self.relu0, self.x5 = t, gp, relu0, x5
+        self.ku, self.bu, self.k6, self.b6, self.kp, self.bpred, self.flow, self.logits = ku, bu, k6, b6, kp, bpred, flow, logits
+
+    def kernel_name(self, lib):
+        return 'oflow_tail2_kernel'
+
+    def flops(self):
+        """Nominal (dense, 9-tap) FLOPs of upconv0 (counted per INPUT cell like every transposed conv),
+        conv6 and 'prediction' per window."""
+        n, h, w, _ = self.t.shape
+        return 2.0 * n * h * w * (16 * 9 * 32 * 16 + 64 * 9 * (48 * 16 + 16))
+
+    def mfma_flops(self):
+        n, h, w, _ = self.t.shape
+        return 2.0 * n * h * w * (9 * 16 * 32 * 16 + 64 * 9 * 48 * 16)
+
+    def launch(self, lib, stream):
+        n, h, w, c9 = self.t.shape
+        n = _scaled(n, self.t.graph)
+        assert c9 == 288 and self.t.ld == c9 and self.gp.ld == c9 and self.x5.is_whole() and self.x5.shape[1:] == (4, 4, 32)
+        _lib.check(lib.kfn_oflow_tail2(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.x5.ptr, self.ku.ptr,
+                                       self.bu.ptr if self.bu is not None else None, self.k6.ptr,
+                                       self.b6.ptr if self.b6 is not None else None, self.kp.ptr,
+                                       self.bpred.ptr if self.bpred is not None else None, self.flow.ptr,
+                                       self.logits.ptr if self.logits is not None else None, stream), 'kfn_oflow_tail2')
+
+
 class CopyChannelsOp(Op):
     def __init__(self, src, dst):
         self.name = 'copy_channels'
@@ -871,6 +959,10 @@ class Graph(object):
         self.fuse_flow_head = True  # OFlowNet prediction conv + softmax + soft-argmax in one kernel
         self.fuse_oflow_tail = True  # ... and conv6 in front of it (kfn_oflow_tail: the 8x8x48 patch stays in LDS)
         self.fuse_cost_volume = True  # BuildCoordVolume generated inside OFlowNet conv0's loader
+        # OFlowNet's window-grid ends window-resident (kfn_oflow_head: conv0 + conv1a; kfn_oflow_tail2: upconv0 + conv0 +
+        # conv6 + prediction + soft-argmax): conv0's [P,8,8,32] output, concat0 and the gather launch disappear.
+        # Needs the factored cost volume and the fused tail.
+        self.fuse_oflow_window = True
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
         # (0 disables).  Below ~128 channels the [tiles][16][Cout] workspace traffic outweighs
         # the 2.25x MFMA saving.

@@ -10,9 +10,11 @@ can land on different sides of a step; the affected pixel then differs by the fu
 state (not by round-off), keeps that difference in the recurrent state and hands it on to every
 pixel that later samples from it.
 
-`sampler_taint` marks, from the REFERENCE run's flow alone, the pixels such an event can reach:
-  * frame t, pixel p is a SEED if its sample position lies within `delta` px of one of the four
-    steps (|x| < delta, |x - (W-1)| < delta, same in y);
+`sampler_taint` marks the pixels such an event can reach:
+  * frame t, pixel p is a SEED if the two runs' sample positions lie on DIFFERENT sides of a step
+    (`crossing_seeds`, needs both flows) -- or, from the reference run's flow alone, if its sample
+    position lies within `delta` px of one of the four steps (|x| < delta, |x - (W-1)| < delta, same
+    in y; conservative: every pixel of a border row/column with a small flow is such a seed);
   * the taint propagates exactly as the state does: p is tainted at t if it is a seed at t or its
     sample at t lies inside the grid and one of the (up to) four corner pixels it reads was tainted
     at t-1; a reset frame (t % reset_period == 0: the state is overwritten by the measurement,
@@ -31,15 +33,38 @@ def sample_positions(flow):
     return xs, ys
 
 
-def sampler_taint(flow, delta=0.05, reset_period=500, t0=0):
+def inside_grid(flow):
+    """bool [T,h,w]: does the sample land where the reference sampler returns data (0 <= x < W-1, 0 <= y < H-1)?"""
+    T, h, w, _ = flow.shape
+    xs, ys = sample_positions(np.asarray(flow, dtype=np.float32))
+    return (xs >= 0) & (xs < w - 1) & (ys >= 0) & (ys < h - 1)
+
+
+def step_distance(flow):
+    """Distance [T,h,w] (px) of every sample position from the nearest of the sampler's four steps."""
+    T, h, w, _ = flow.shape
+    xs, ys = sample_positions(np.asarray(flow, dtype=np.float32))
+    return np.minimum.reduce([np.abs(xs), np.abs(xs - (w - 1)), np.abs(ys), np.abs(ys - (h - 1))])
+
+
+def crossing_seeds(ref_flow, test_flow, reset_period=500, t0=0):
+    """bool [T,h,w]: the two runs' samples fall on different sides of a sampler step (one reads the state, the
+    other gets 0).  Reset frames sample nothing."""
+    seeds = inside_grid(ref_flow) != inside_grid(test_flow)
+    for t in range(seeds.shape[0]):
+        if reset_period > 0 and (t0 + t) % reset_period == 0:
+            seeds[t] = False
+    return seeds
+
+
+def sampler_taint(flow, delta=0.05, reset_period=500, t0=0, seeds=None):
     """bool [T,h,w]: pixels whose state can differ by more than round-off between two evaluations
-    whose flows agree to better than `delta` px (see module docstring).  `flow` is the reference
-    run's [T,h,w,2]; frame t of the array is global frame t0 + t."""
+    (see module docstring).  `flow` is the reference run's [T,h,w,2]; frame t of the array is global frame
+    t0 + t.  `seeds` = crossing_seeds(...) when both flows are known, else the `delta` neighbourhood of the steps."""
     flow = np.asarray(flow, dtype=np.float32)
     T, h, w, _ = flow.shape
     xs, ys = sample_positions(flow)
-    seed = ((np.abs(xs) < delta) | (np.abs(xs - (w - 1)) < delta) |
-            (np.abs(ys) < delta) | (np.abs(ys - (h - 1)) < delta))
+    seed = seeds if seeds is not None else (step_distance(flow) < delta)
     inside = (xs >= 0) & (xs < w - 1) & (ys >= 0) & (ys < h - 1)   # elsewhere the sample is 0: reads no state
     x0 = np.clip(np.floor(xs).astype(np.int64), 0, w - 1)
     y0 = np.clip(np.floor(ys).astype(np.int64), 0, h - 1)
@@ -57,11 +82,22 @@ def sampler_taint(flow, delta=0.05, reset_period=500, t0=0):
     return taint
 
 
-def masked_parity(rec, ref, ref_flow, coord_tol=2e-2, conf_rel_tol=5e-2, delta=0.05, reset_period=500, t0=0):
+def masked_parity(rec, ref, ref_flow, coord_tol=2e-2, conf_rel_tol=5e-2, delta=0.05, reset_period=500, t0=0,
+                  test_flow=None):
     """Compare records `rec` with `ref` ([T,h,w,4]: T.x and 1/sigma, KFNet/eval.py:115,123-126)
-    away from the sampler's steps.  Returns a dict of plain floats."""
+    away from the sampler's steps.  With `test_flow` (the compared run's own flow) the mask is seeded by the
+    ACTUAL step crossings and `delta` becomes a checked claim (every crossing lies within delta of a step and the
+    flows agree to better than delta); without it, by the delta neighbourhood.  Returns a dict of plain floats."""
     rec, ref = np.asarray(rec), np.asarray(ref)
-    taint = sampler_taint(ref_flow, delta, reset_period, t0)
+    seeds = None
+    extra = {}
+    if test_flow is not None:
+        seeds = crossing_seeds(ref_flow, test_flow, reset_period, t0)
+        sd = step_distance(ref_flow)
+        extra = {'crossings': int(seeds.sum()),
+                 'crossing_max_step_distance_px': float(sd[seeds].max()) if seeds.any() else 0.0,
+                 'flow_max_abs_diff_px': float(np.abs(np.asarray(ref_flow) - np.asarray(test_flow)).max())}
+    taint = sampler_taint(ref_flow, delta, reset_period, t0, seeds=seeds)
     dc = np.abs(rec[..., :3] - ref[..., :3]).max(-1)
     dr = np.abs(rec[..., 3] - ref[..., 3]) / np.abs(ref[..., 3])
     bad = (dc > coord_tol) | (dr > conf_rel_tol)
@@ -76,6 +112,9 @@ def masked_parity(rec, ref, ref_flow, coord_tol=2e-2, conf_rel_tol=5e-2, delta=0
         'masked_outside_tolerance': int((bad & taint).sum()),
         'all_pixels_coord_max_abs': float(dc.max()), 'all_pixels_conf_max_rel': float(dr.max()),
         'coord_abs_p999': float(np.quantile(dc, 0.999)), 'conf_rel_p999': float(np.quantile(dr, 0.999)),
+        'outside_tolerance_fraction': float(bad.mean()),
+        'mask': 'descendants of actual step crossings' if seeds is not None else 'descendants of the delta neighbourhood',
+        **extra,
     }
 
 
@@ -86,8 +125,13 @@ def merge_parity(parts):
     out['frames'] = int(sum(p['frames'] for p in parts))
     out['pixels'] = int(n)
     out['masked_fraction'] = float(sum(p['masked_fraction'] * p['pixels'] for p in parts) / n)
-    for k in ('unmasked_outside_tolerance', 'masked_outside_tolerance'):
-        out[k] = int(sum(p[k] for p in parts))
+    for k in ('unmasked_outside_tolerance', 'masked_outside_tolerance', 'crossings'):
+        if k in parts[0]:
+            out[k] = int(sum(p[k] for p in parts))
+    out['outside_tolerance_fraction'] = float(sum(p['outside_tolerance_fraction'] * p['pixels'] for p in parts) / n)
+    for k in ('crossing_max_step_distance_px', 'flow_max_abs_diff_px'):
+        if k in parts[0]:
+            out[k] = float(max(p[k] for p in parts))
     for k in ('unmasked_coord_max_abs', 'unmasked_conf_max_rel', 'all_pixels_coord_max_abs',
               'all_pixels_conf_max_rel', 'coord_abs_p999', 'conf_rel_p999'):
         out[k] = float(max(p[k] for p in parts))

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from kfnet_amd import _lib
-from kfnet_amd.graph import pack_conv_kernel, pack_deconv_kernel
+from kfnet_amd.graph import pack_conv_kernel, pack_conv_kernel_chunked, pack_deconv_kernel
 
 
 def dev(arr):
@@ -52,6 +52,8 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
         wp_dev = np.stack([hi, (m - hi.astype(np.float32)).astype(np.float16)])
     else:
         wp_dev = wp.astype(np.float16) if f16 else wp
+        if x16 or y16:      # fp16 activations: chunk-major weights
+            wp_dev = pack_conv_kernel_chunked(w).astype(np.float16)
     wd_ = dev(wp_dev)
     bd = dev(b.astype(np.float32)) if b is not None else None
     d = _lib.ConvDesc(N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, cout_pad=wp.shape[0], ldy=ldy, kh=kh, kw=kw,

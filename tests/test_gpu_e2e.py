@@ -25,8 +25,10 @@ COORD_TOL = 1e-4
 CONF_RTOL = 1e-4
 
 
-# bound on the fraction of pixels config 5's tolerance statement excludes (measured: see profiles/r03_c5_parity.json)
-C5_MASKED_FRACTION_BOUND = 5e-3
+# config 5's tolerance statement (test_config5_tolerance_at_bench_scale; numbers in profiles/r03_bench_c5.json)
+C5_DELTA_PX = 0.05                 # flows agree / crossings lie within this distance of a sampler step
+C5_MASKED_FRACTION_BOUND = 1e-2    # descendants of step crossings (measured 2.5e-3 over 4 x 16 frames)
+C5_OUTSIDE_FRACTION_BOUND = 2e-4   # pixel-frames actually outside the tolerance (measured 8.6e-5)
 
 
 def _check(rec, ref):
@@ -279,13 +281,22 @@ def test_config5_fp16_convs_fp32_kalman():
 
 def test_config5_tolerance_at_bench_scale():
     """Config 5's tolerance as it is actually true, at the scale bench.py --config c5
-    reports: 4 sequences x 16 frames of 540x960, fp16-operand path against the fp32 HIP path (which
-    the tests above hold to the oracle at 1e-4).  The reference sampler (tools/util.py:36-93) is a
-    step function of the flow at x in {0, W-1} / y in {0, H-1}; a 1e-3 px flow difference can put
-    the two paths on different sides, and the recurrent state carries that on.  Statement: every
-    pixel whose fp32 sample position stays >= 0.05 px from those steps -- and has not read a pixel
-    that did not, since the last reset -- meets coord max-abs <= 2e-2 and confidence max-rel
-    <= 5e-2; the excluded fraction is reported and bounded."""
+    reports: 4 sequences x 16 frames of 540x960, fp16 path (fp16 MFMA operands, fp16 activations in
+    SCoordNet) against the fp32 HIP path (which the tests above hold to the oracle at 1e-4).
+
+    The reference sampler (tools/util.py:36-93) is a step function of the flow at x in {0, W-1} /
+    y in {0, H-1}: a sample just outside evaluates to 0, just inside to the border value.  The two
+    paths' flows agree to ~3e-3 px, so now and then (3 times in 522 240 pixel-frames here) a sample
+    within 1e-3 px of a step lands on different sides in the two paths; that pixel then differs by
+    the whole state value, the recurrent state keeps the difference, and pixels that later sample
+    it inherit a share.  Statement, all four parts asserted:
+      1. the flows agree to better than delta = 0.05 px and every crossing lies within delta of a step;
+      2. every pixel that is NOT a descendant of a crossing (kfnet_amd/tools/parity.py propagates
+         the taint exactly as the state propagates) meets coord max-abs <= 2e-2, confidence
+         max-rel <= 5e-2 -- no deviation is left unexplained by a crossing;
+      3. the descendants are <= 1 % of the pixel-frames (measured 0.25 %); a sound mask cannot be
+         smaller, the bilinear sampler spreads a state over up to 4 pixels per frame until the reset;
+      4. the pixel-frames actually outside the tolerance are <= 2e-4 of all (measured 8.6e-5)."""
     import torch
     from kfnet_amd.engine import KFNetEngine
     from kfnet_amd.synth import synthetic_sequence
@@ -296,21 +307,26 @@ def test_config5_tolerance_at_bench_scale():
     seqs = np.stack([synthetic_sequence(T, 540, 960, seed=3 + s) for s in range(S)])
     dev = torch.from_numpy(seqs).cuda()
     T4 = np.eye(4, dtype=np.float32)
-    recs = {}
+    recs, flows = {}, {}
     for mode in ('f32', 'f16'):
         eng = KFNetEngine(W, image_size=(540, 960), batch=8, transform=T4, reset_period=500, max_chunk=S * T,
                           conv_operands=mode)
         recs[mode] = eng.process_sequences(dev).cpu().numpy().copy()
-        if mode == 'f32':
-            flow = eng.debug(S * T)['flow'].reshape(S, T, eng.h, eng.w, 2).copy()
+        flows[mode] = eng.debug(S * T)['flow'].reshape(S, T, eng.h, eng.w, 2).copy()
+        if mode == 'f16':
+            assert any(getattr(op, 'y', None) is not None and op.y.dtype == 'f16' for op in eng.heavy_ops), \
+                'config 5 must keep SCoordNet activations in fp16'
         del eng
         torch.cuda.empty_cache()
-    mp = merge_parity([masked_parity(recs['f16'][s], recs['f32'][s], flow[s], coord_tol=2e-2, conf_rel_tol=5e-2,
-                                     delta=0.05, reset_period=500) for s in range(S)])
+    mp = merge_parity([masked_parity(recs['f16'][s], recs['f32'][s], flows['f32'][s], coord_tol=2e-2,
+                                     conf_rel_tol=5e-2, delta=C5_DELTA_PX, reset_period=500, test_flow=flows['f16'][s])
+                       for s in range(S)])
     print('config 5 at bench scale:', mp)
     assert mp['pixels'] == S * T * 68 * 120
+    assert mp['flow_max_abs_diff_px'] < C5_DELTA_PX and mp['crossing_max_step_distance_px'] < C5_DELTA_PX, mp
     assert mp['unmasked_outside_tolerance'] == 0, mp
     assert mp['masked_fraction'] <= C5_MASKED_FRACTION_BOUND, mp
+    assert mp['outside_tolerance_fraction'] <= C5_OUTSIDE_FRACTION_BOUND, mp
     assert mp['all_pixels_coord_max_abs'] > 1e-6     # and it is measurably not the fp32 path
 
 

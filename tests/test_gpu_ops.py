@@ -863,3 +863,115 @@ def test_cost_volume_factored_vs_oracle(shape):
         ref = O.conv2d_same(vol, wt, b, 1, True).reshape(H * W * 64, co)
         g = got[n * H * W * 64:(n + 1) * H * W * 64, off:off + co]
         assert np.abs(g - ref).max() < 2e-5
+
+
+def _factored_maps(f, wt, b, N, H, W):
+    """T [N,H,W,288] and Gp [N,H+4,W+4,288] of the factored cost volume (as the graph computes them: kfn_pad_nhwc +
+    two kfn_conv2d_nhwc launches with the class kernels) for frame pairs (f[n], f[n+1])."""
+    import torch
+    from tests.gpu_util import dev, stream
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_cvol_bias, pack_cvol_g_kernel, pack_cvol_t_kernel
+    lib = _lib.load()
+    Cc, co, c9 = 32, 32, 288
+    fd = dev(f)
+    wg, wtt, b9 = dev(pack_cvol_g_kernel(wt)), dev(pack_cvol_t_kernel(wt)), dev(pack_cvol_bias(b))
+    f1p = torch.empty(N * (H + 4) * (W + 4) * Cc, device='cuda')
+    Gp = torch.empty(N * (H + 4) * (W + 4) * c9, device='cuda')
+    T = torch.empty(N * H * W * c9, device='cuda')
+    st = stream()
+    _lib.check(lib.kfn_pad_nhwc(fd.data_ptr(), f1p.data_ptr(), N, H, W, Cc, 2, st), 'pad')
+    dg = _lib.ConvDesc(N=N, H=H + 4, W=W + 4, Cin=Cc, ldx=Cc, Cout=c9, cout_pad=c9, ldy=c9, kh=3, kw=3, stride=1)
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(dg), f1p.data_ptr(), wg.data_ptr(), None, Gp.data_ptr(), st), 'G')
+    dt = _lib.ConvDesc(N=N, H=H, W=W, Cin=Cc, ldx=Cc, Cout=c9, cout_pad=c9, ldy=c9, kh=1, kw=1, stride=1)
+    _lib.check(lib.kfn_conv2d_nhwc(C.byref(dt), fd.data_ptr() + H * W * Cc * 4, wtt.data_ptr(), b9.data_ptr(),
+                                   T.data_ptr(), st), 'T')
+    return T, Gp, (fd, wg, wtt, b9, f1p)
+
+
+def _oracle_conv0(f, wt, b, N, H, W):
+    """relu(conv0(BuildCoordVolume(f[n], f[n+1]))) for every pair: [N*H*W, 8, 8, 32] (fp64)."""
+    out = []
+    for n in range(N):
+        vol, _ = O.coord_volume(f[n:n + 1].astype(np.float64), f[n + 1:n + 2].astype(np.float64), 8)
+        out.append(O.conv2d_same(vol, wt, b, 1, True))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 60, 80), (3, 5, 4), (2, 3, 2)])
+def test_oflow_head_vs_oracle(shape):
+    """kfn_oflow_head (conv0 from the factored maps + conv1a, one wave per window) == the oracle's
+    conv2d(stride 2, relu) of relu(conv0(cost volume)): image borders (zero fill of the shifted f1), window borders
+    (conv0's SAME padding) and conv1a's bottom / right SAME padding included."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_oflow_head_kernel
+    lib = _lib.load()
+    N, H, W = shape
+    rng = np.random.default_rng(91)
+    f = rng.normal(size=(N + 1, H, W, 32)).astype(np.float32)
+    w0 = (rng.normal(size=(3, 3, 32, 32)) / np.sqrt(9 * 32)).astype(np.float32)
+    b0 = rng.normal(size=32).astype(np.float32)
+    w1 = (rng.normal(size=(3, 3, 32, 32)) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
+    b1 = (rng.normal(size=32) * 0.1).astype(np.float32)
+    T, Gp, keep = _factored_maps(f, w0, b0, N, H, W)
+    P = N * H * W
+    y = torch.full((P * 16 * 32 + 64,), -7.0, device='cuda')
+    dw1, db1 = dev(pack_oflow_head_kernel(w1)), dev(b1)
+    _lib.check(lib.kfn_oflow_head(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, dw1.data_ptr(), db1.data_ptr(), y.data_ptr(),
+                                  stream()), 'oflow_head')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[P * 512:] == -7.0)
+    ref = O.conv2d_same(_oracle_conv0(f, w0, b0, N, H, W), w1, b1, 2, True)          # [P,4,4,32]
+    err = np.abs(got[:P * 512].reshape(ref.shape) - ref).max()
+    assert err < 4e-5 * max(1.0, float(np.abs(ref).max())), err
+
+
+@pytest.mark.parametrize('shape', [(2, 7, 9), (1, 60, 80), (3, 5, 4)])
+def test_oflow_tail2_vs_oracle(shape):
+    """kfn_oflow_tail2 (upconv0 of conv5's patch ++ recomputed conv0 -> conv6 -> prediction -> softmax -> soft-argmax)
+    == the oracle's conv2d_transpose / concat / conv2d chain on the materialised tensors."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_oflow_tail_kernel, pack_oflow_upconv_kernel
+    lib = _lib.load()
+    N, H, W = shape
+    P = N * H * W
+    rng = np.random.default_rng(57)
+    f = rng.normal(size=(N + 1, H, W, 32)).astype(np.float32)
+    w0 = (rng.normal(size=(3, 3, 32, 32)) / np.sqrt(9 * 32)).astype(np.float32)
+    b0 = rng.normal(size=32).astype(np.float32)
+    x5 = np.maximum(rng.normal(size=(P, 4, 4, 32)), 0).astype(np.float32)
+    wu = (rng.normal(size=(3, 3, 16, 32)) * np.sqrt(2.0 / (4 * 32))).astype(np.float32)     # [kh,kw,Cout,Cin]
+    bu = (rng.normal(size=16) * 0.1).astype(np.float32)
+    w6 = (rng.normal(size=(3, 3, 48, 16)) * np.sqrt(2.0 / (9 * 48))).astype(np.float32)
+    b6 = (rng.normal(size=16) * 0.1).astype(np.float32)
+    wp = (rng.normal(size=(3, 3, 16, 1)) * 0.5).astype(np.float32)
+    bp = np.array([0.3], np.float32)
+    T, Gp, keep = _factored_maps(f, w0, b0, N, H, W)
+    flow = torch.zeros(P * 2, device='cuda')
+    logits = torch.zeros(P * 64, device='cuda')
+    d5, du, dbu, d6, db6, dwp, dbp = (dev(x5), dev(pack_oflow_upconv_kernel(wu)), dev(bu), dev(pack_oflow_tail_kernel(w6)),
+                                      dev(b6), dev(wp[..., 0]), dev(bp))
+    _lib.check(lib.kfn_oflow_tail2(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, d5.data_ptr(), du.data_ptr(), dbu.data_ptr(),
+                                   d6.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), flow.data_ptr(),
+                                   logits.data_ptr(), stream()), 'oflow_tail2')
+    sync()
+    up = O.conv2d_transpose_same(x5.astype(np.float64), wu, bu, 2, True)                    # [P,8,8,16]
+    cat = np.concatenate([up, _oracle_conv0(f, w0, b0, N, H, W)], -1)                       # concat0 = [upconv0, conv0]
+    mid = O.conv2d_same(cat, w6, b6, 1, True)
+    ref_logits = O.conv2d_same(mid, wp, bp, 1, False)[..., 0].reshape(P, 64)
+    pr = O.softmax(ref_logits)
+    offs = O.coord_volume(np.zeros((1, 2, 2, 1)), np.zeros((1, 2, 2, 1)), 8)[1]
+    tol = 1e-5 * max(1.0, float(np.abs(ref_logits).max()))
+    assert np.abs(logits.cpu().numpy().reshape(P, 64) - ref_logits).max() < tol
+    assert np.abs(flow.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max() < 20 * tol
+    flow2 = torch.zeros(P * 2, device='cuda')          # without the optional logits output
+    _lib.check(lib.kfn_oflow_tail2(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, d5.data_ptr(), du.data_ptr(), dbu.data_ptr(),
+                                   d6.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), flow2.data_ptr(), None,
+                                   stream()), 'oflow_tail2')
+    sync()
+    assert torch.equal(flow, flow2)

@@ -59,3 +59,28 @@ def test_taint_propagates_along_the_flow():
     t = sampler_taint(flow, delta=0.05, reset_period=500)
     # x = 0 exactly (zero flow in column 0) sits ON the step: also seeds
     assert t[1, 2, 0] and t[2, 3, 4] and not t[2, 3, 5] and not t[0].any()
+
+
+def test_crossing_seeds_explain_every_large_difference():
+    """With BOTH flows known the mask is seeded by the actual crossings (samples on different sides of a step):
+    far fewer pixels than the delta neighbourhood, and still every large difference is a descendant."""
+    from kfnet_amd.tools.parity import crossing_seeds
+    T, H, W = 24, 12, 17
+    flow, sig, meas = _inputs(T, H, W, seed=5)
+    rng = np.random.default_rng(9)
+    pert = rng.uniform(-1e-3, 1e-3, size=flow.shape).astype(np.float32)
+    for (t, y, x) in [(3, 4, 5), (13, 1, 9), (22, 3, 3)]:
+        flow[t, y, x, 0] = -x + 3e-4
+        pert[t, y, x, 0] = -8e-4
+        flow[t, y, x, 1] = 0.3
+    flow2 = flow + pert
+    z = np.zeros((H, W, 4), np.float32)
+    a, _ = _scan(flow, sig, meas, z, 0, 10)
+    b, _ = _scan(flow2, sig, meas, z, 0, 10)
+    seeds = crossing_seeds(flow, flow2, reset_period=10)
+    assert seeds.sum() >= 3 and seeds[3, 4, 5] and seeds[13, 1, 9] and seeds[22, 3, 3]
+    r = masked_parity(b, a, flow, coord_tol=2e-2, conf_rel_tol=1e9, delta=2e-3, reset_period=10, test_flow=flow2)
+    r_delta = masked_parity(b, a, flow, coord_tol=2e-2, conf_rel_tol=1e9, delta=2e-3, reset_period=10)
+    assert r['unmasked_outside_tolerance'] == 0 and r['masked_outside_tolerance'] > 0
+    assert r['masked_fraction'] <= r_delta['masked_fraction']
+    assert r['crossing_max_step_distance_px'] < 2e-3 and r['flow_max_abs_diff_px'] <= 1.01e-3
