@@ -134,6 +134,7 @@ typedef struct kfn_conv_desc {
 #define KFN_CFG_128x256 9  /* 4 waves, wave tile 64x128: the Winograd GEMMs' tile (fewest loads per MFMA) */
 #define KFN_CFG_256x16 10  /* 16-column tiles on v_mfma_f32_16x16x4_f32 for the 16-channel layers */
 #define KFN_CFG_128x16 11  /* (fp32 operands, no fused head epilogue)                               */
+#define KFN_CFG_256x64 12  /* 4 waves side by side in M, wave tile 64x64: the fp16-activation kernels on 64-channel layers */
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);

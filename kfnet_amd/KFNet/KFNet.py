@@ -18,7 +18,7 @@ from ..cnn_wrapper.network import Network
 from ..cnn_wrapper.OFlowNet import OFlowNet
 from ..cnn_wrapper.SCoordNet import SCoordNet
 from ..graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, CostVolumeOp, DerivedConvOp, Graph, KalmanScanOp, MemcpyOp,
-                     PadOp, Tensor, pack_cvol_bias, pack_cvol_g_kernel, pack_cvol_t_kernel, variable_scope)
+                     PadOp, Tensor, as_f16, pack_cvol_bias, pack_cvol_g_kernel, pack_cvol_t_kernel, variable_scope)
 
 
 class KFNetDataSpec():
@@ -325,12 +325,15 @@ class KFNet():
             f1p = g.tensor((n, h + 4, w + 4, c), name='feat_map1_padded')
             gp = g.tensor((n, h + 4, w + 4, 9 * co), name='conv0_G')
             tt = g.tensor((n, h, w, 9 * co), name='conv0_T')
-            wg = g.derived_variable(conv0.kernel, 'cvol_G', pack_cvol_g_kernel)
-            wt = g.derived_variable(conv0.kernel, 'cvol_T', pack_cvol_t_kernel)
+            # fp16-operand mode: the two class convolutions round their operands like every other convolution there
+            h16 = g.conv_operands == 'f16' and c % 32 == 0
+            od = _lib.OPERAND_F16 if h16 else _lib.OPERAND_F32
+            wg = g.derived_variable(conv0.kernel, 'cvol_G', as_f16(pack_cvol_g_kernel) if h16 else pack_cvol_g_kernel)
+            wt = g.derived_variable(conv0.kernel, 'cvol_T', as_f16(pack_cvol_t_kernel) if h16 else pack_cvol_t_kernel)
             b9 = g.derived_variable(conv0.bias, 'cvol_b9', pack_cvol_bias)
             new_ops = [PadOp(feat_map1, f1p, 2),
-                       DerivedConvOp('conv0[G]', f1p, gp, wg, None, 3, 3, 1, False),
-                       DerivedConvOp('conv0[T]', feat_map2, tt, wt, b9, 1, 1, 1, False),
+                       DerivedConvOp('conv0[G]', f1p, gp, wg, None, 3, 3, 1, False, operand_dtype=od),
+                       DerivedConvOp('conv0[T]', feat_map2, tt, wt, b9, 1, 1, 1, False, operand_dtype=od),
                        CostVolumeGatherOp(tt, gp, conv0.y, conv0.relu, c)]
             i = g.ops.index(conv0)
             g.ops[i:i + 1] = new_ops

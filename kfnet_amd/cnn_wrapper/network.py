@@ -232,6 +232,15 @@ class Network(object):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_winograd_s2_kernel))
             self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, operand_dtype=_lib.OPERAND_F16))
             return y
+        if (f16 and k == 3 and strides == 1 and h == 2 and w == 2 and g.window_fc and biased and (4 * cin) % 32 == 0
+                and filters % 8 == 0 and input.dtype == 'f32' and y.dtype == 'f32'):
+            # OFlowNet's 2x2 level in the fp16-operand mode: the same dense window matrix, operands rounded to fp16
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), as_f16(pack_window_fc_kernel))
+            bias.pack = pack_bias_x4
+            op = WindowFcConvOp(name, input, y, kern, bias, relu)
+            op.operand_dtype = _lib.OPERAND_F16
+            self._emit(op)
+            return y
         if f16:
             # fp16 activations on either side: the tap-innermost kernels with chunk-major weights
             pk = pack_conv_kernel_chunked if (input.dtype == 'f16' or y.dtype == 'f16') else pack_conv_kernel

@@ -52,6 +52,33 @@ inline int set_max_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Wave-wide (64 lanes) sum / max on the VALU: four DPP butterfly steps leave every lane of a 16-lane row with the
+// row's total (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- each step adds a lane's
+// value to its partner's, so all lanes of a row evaluate the same tree), the four row totals are read into
+// scalars and combined as (r0 + r1) + (r2 + r3).  ~12 instructions; six __shfl_xor steps are six dependent
+// ds_bpermute round trips through the LDS crossbar (~100 cycles each).  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+
 // TF 'SAME' padding rule (tf.layers.conv2d, cnn_wrapper/network.py:126-135):
 // out = ceil(in/stride); pad_total = max((out-1)*stride + k - in, 0); before = total/2.
 inline void same_pad(int in, int k, int stride, int* out, int* before) {

@@ -869,7 +869,8 @@ const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x1
                          {KFN_CFG_256x32, 256, 32, 0.70, 0.45},   {KFN_CFG_128x32, 128, 32, 0.60, 0.45},
                          {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0},
                          {KFN_CFG_128x256, 128, 256, 0.0, 0.82},
-                         {KFN_CFG_256x16, 256, 16, 0.50, 0.0},    {KFN_CFG_128x16, 128, 16, 0.45, 0.0}};
+                         {KFN_CFG_256x16, 256, 16, 0.50, 0.0},    {KFN_CFG_128x16, 128, 16, 0.45, 0.0},
+                         {KFN_CFG_256x64, 256, 64, 0.0, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -934,16 +935,18 @@ int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, BK, MODE_CONV, PREC>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-activation instantiation", cfg);
   }
 }
 // Tile and k-step of an fp16-activation layer (measured at config 5's shapes, tools/mb_f16.py,
 // profiles/r03_c5_layer_microbench.log): with chunk-major weights the 128x256 tile at k-step 16 (48 KiB of LDS, two
 // workgroups per CU) wins on every layer with >= 256 output channels (1000-1040 TFLOP/s; 128x128 900-940; k-step
-// 32 -- 96 KiB, one workgroup per CU -- 790-870).  desc->config / desc->k_step override either.
+// 32 -- 96 KiB, one workgroup per CU -- 790-870); 64-channel layers (conv1b) take 256x64, four waves side by side in M
+// (576 vs 524 TFLOP/s on 128x64).  desc->config / desc->k_step override either.
 void f16io_plan(const kfn_conv_desc* d, int* cfg, int* bk) {
   int c = d->config, k = d->k_step;
-  if (c == KFN_CFG_AUTO) c = d->Cout >= 256 ? KFN_CFG_128x256 : (d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_128x64);
+  if (c == KFN_CFG_AUTO) c = d->Cout >= 256 ? KFN_CFG_128x256 : (d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_256x64);
   if (k == 0 || d->Cin % 64 != 0) k = 16;
   *cfg = c;
   *bk = k;

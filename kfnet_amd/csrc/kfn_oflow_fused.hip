@@ -45,16 +45,6 @@ constexpr int T3_BYTES = 25 * LD3 * 4;
 constexpr int TAIL_WAVE_BYTES = T1_BYTES + T2_BYTES + T3_BYTES;
 constexpr int HEAD_WAVE_BYTES = 81 * LDA * 4;
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
@@ -349,13 +339,13 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
       }
     }
     if (logits_out) logits_out[(size_t)p * 64 + lane] = lg;
-    // ---- softmax over the 64 cells + soft-argmax (same operation order as flow_head_kernel) -----------
-    const float mx = wave_max(lg);
+    // ---- softmax over the 64 cells + soft-argmax (DPP reductions: kfn_common.h) -----------
+    const float mx = kfn::wave_max_dpp(lg);
     const float ex = expf(lg - mx);
-    const float se = wave_sum(ex);
+    const float se = kfn::wave_sum_dpp(ex);
     const float pr = ex / se;
-    const float sx = wave_sum(pr * (float)(cj - 4));
-    const float sy = wave_sum(pr * (float)(ci - 4));
+    const float sx = kfn::wave_sum_dpp(pr * (float)(cj - 4));
+    const float sy = kfn::wave_sum_dpp(pr * (float)(ci - 4));
     if (lane == 0) {
       flow[(size_t)p * 2 + 0] = sx;
       flow[(size_t)p * 2 + 1] = sy;

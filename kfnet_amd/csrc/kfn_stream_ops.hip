@@ -5,6 +5,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------
 // uint8 image -> (x-128)*0.00625 -> 3x3 SAME conv (Cin = 3) + bias + ReLU, two heads.
@@ -86,6 +87,149 @@ __global__ __launch_bounds__(256) void first_conv_kernel(
   __syncthreads();
   first_head<LP1, OUT16_1>(tile, w1, b1, y1, n, H, W, x0, y0, tid);
   if constexpr (LP2 > 0) first_head<LP2>(tile, w2, b2, y2, n, H, W, x0, y0, tid);
+}
+
+// ------------------------------------------------------------------------------------
+// The same layer, LANE = PIXEL (round 3).  In the kernel above C/4 lanes share a pixel and all of them read the
+// same 27 inputs from LDS: per pixel 4.2 ds_read2_b32 wave-instructions and 17 v_pk_fma_f32 -- the LDS pipe and the
+// VALU are both at ~17 cycles per pixel and CU, and the layer runs at 3.5 TB/s although it only has to stream its
+// output.  Here a wave owns one 64-pixel row of the 64x4 tile: a lane reads its 27 inputs ONCE (27 conflict-free
+// ds_read_b32 per 64 pixels), the weights are wave-uniform and come from scalar registers, 80 accumulators per lane;
+// the results are transposed through a per-wave LDS staging buffer (36 dwords per pixel: conflict-free
+// ds_write_b128) so that they leave as 16-byte stores in which 8 (fp32 half of 32 channels, or all 64 fp16
+// channels) or 4 (16-channel head) neighbouring lanes cover one pixel's contiguous run.  The halo is filled with
+// aligned dword loads of the uint8 rows (4 values per load; the byte-wise form remains for images whose rows are
+// not a multiple of 4 bytes).
+// ------------------------------------------------------------------------------------
+constexpr int PX_SP = 36;                       // dwords per pixel of the staging buffer
+constexpr int PX_STAGE = 64 * PX_SP;            // per wave
+constexpr int PX_LDS_BYTES = ((FT_H + 2) * FT_TW3 + 4 * PX_STAGE) * 4;
+
+__device__ __constant__ float kZeroBias[64] = {0.f};
+
+template <int C>
+__device__ __forceinline__ void px_accumulate(const float* tile_row, const float* __restrict__ w, const float* __restrict__ b,
+                                              float (&acc)[C]) {
+  const float* bb = b ? b : kZeroBias;            // ONE uniform select (a test per channel becomes a branch per channel)
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = bb[c];
+  // A REAL loop over the 27 taps (C FMAs per trip): fully unrolled, the scheduler hoists the scalar weight loads
+  // of many taps to the top and spills ~800 scalar registers into VGPR lanes.
+  int off = 0, j = 0;
+#pragma unroll 1
+  for (int t = 0; t < 27; ++t) {
+    const float xv = tile_row[off];
+    const float* wk = w + t * C;                     // wave-uniform: scalar loads
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+    ++off;
+    if (++j == 9) {
+      j = 0;
+      off += FT_TW3 - 9;
+    }
+  }
+}
+
+// 32 fp32 channels (NQ = 8 quads per pixel) or 16 (NQ = 4) of this wave's 64 pixels: LDS transpose, then
+// 64/NQ pixels per store instruction.  `cstride` = channels per pixel in memory, `c0` = first channel.
+template <int NQ>
+__device__ __forceinline__ void px_store_f32(float* stage, const float* vals, float* __restrict__ y, size_t row_elem0,
+                                             int cstride, int c0, int lane, int valid_px) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    *reinterpret_cast<f32x4*>(stage + lane * PX_SP + q * 4) = f32x4{vals[q * 4], vals[q * 4 + 1], vals[q * 4 + 2], vals[q * 4 + 3]};
+  __builtin_amdgcn_wave_barrier();
+  constexpr int PPI = 64 / NQ;                  // pixels per store instruction
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int px = i * PPI + lane / NQ, q = lane % NQ;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * PX_SP + q * 4);
+    if (px < valid_px) *reinterpret_cast<f32x4*>(y + row_elem0 + (size_t)px * cstride + c0 + q * 4) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int C2, bool OUT16_1>
+__global__ __launch_bounds__(256) void first_conv_px_kernel(
+    const uint8_t* __restrict__ img, int N, int H, int W, unsigned img_bytes,
+    const float* __restrict__ w1, const float* __restrict__ b1, void* __restrict__ y1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y2) {
+  constexpr int C1 = 64;
+  extern __shared__ __attribute__((aligned(16))) float px_smem[];
+  float* tile = px_smem;                                   // [(FT_H+2)][FT_TW3] preprocessed halo
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* stage = px_smem + (FT_H + 2) * FT_TW3 + wv * PX_STAGE;
+  const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, n = blockIdx.z;
+  // ---- halo: aligned dwords of the uint8 rows, 4 values each -----------------------------------
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, (int)img_bytes, 0x00020000);
+    constexpr int DPR = (FT_TW3 + 3) / 4 + 1;              // dwords that cover a 198-byte run at any alignment
+    for (int i = tid; i < (FT_H + 2) * DPR; i += 256) {
+      const int yy = i / DPR, j = i - yy * DPR;
+      const int gy = y0 + yy - 1;
+      const long s = ((long)(n * H + gy) * W + x0 - 1) * 3;             // byte index of tile[yy][0]
+      const long a = (s & ~3L) + 4L * j;
+      const bool row_ok = (unsigned)gy < (unsigned)H;
+      const unsigned word = row_ok && a >= 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)a, 0, 0) : 0u;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int idx = (int)(a + bb - s);
+        if (idx >= 0 && idx < FT_TW3) {
+          const int gx = x0 - 1 + idx / 3;
+          float v = 0.f;
+          if (row_ok && (unsigned)gx < (unsigned)W) v = ((float)((word >> (8 * bb)) & 255u) - 128.0f) * 0.00625f;
+          tile[yy * FT_TW3 + idx] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int gy = y0 + wv;                                  // this wave's image row
+  if (gy >= H) return;                                     // (no block-level barrier below)
+  const int valid_px = (W - x0 < 64) ? W - x0 : 64;
+  const float* tile_row = tile + wv * FT_TW3 + lane * 3;
+  const size_t pix0 = ((size_t)n * H + gy) * W + x0;
+  {
+    float acc[C1];
+    px_accumulate<C1>(tile_row, w1, b1, acc);
+#pragma unroll
+    for (int c = 0; c < C1; ++c) acc[c] = fmaxf(acc[c], 0.f);
+    if constexpr (OUT16_1) {
+      // 64 halfs = 32 dwords per pixel: one pass, 8 lanes per pixel
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        u32x4s pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f16x2 h = {(_Float16)acc[q * 8 + 2 * e], (_Float16)acc[q * 8 + 2 * e + 1]};
+          pk[e] = __builtin_bit_cast(unsigned, h);
+        }
+        *reinterpret_cast<u32x4s*>(stage + lane * PX_SP + q * 4) = pk;
+      }
+      __builtin_amdgcn_wave_barrier();
+      _Float16* yh = static_cast<_Float16*>(y1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int px = i * 8 + lane / 8, q = lane % 8;
+        const u32x4s v = *reinterpret_cast<const u32x4s*>(stage + px * PX_SP + q * 4);
+        if (px < valid_px) *reinterpret_cast<u32x4s*>(yh + (pix0 + px) * C1 + q * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      float* yf = static_cast<float*>(y1);
+      px_store_f32<8>(stage, acc, yf, pix0 * C1, C1, 0, lane, valid_px);
+      px_store_f32<8>(stage, acc + 32, yf, pix0 * C1, C1, 32, lane, valid_px);
+    }
+  }
+  if constexpr (C2 > 0) {
+    static_assert(C2 == 16, "second head: 16 channels");
+    float acc[C2];
+    px_accumulate<C2>(tile_row, w2, b2, acc);
+#pragma unroll
+    for (int c = 0; c < C2; ++c) acc[c] = fmaxf(acc[c], 0.f);
+    px_store_f32<4>(stage, acc, y2, pix0 * C2, C2, 0, lane, valid_px);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -329,6 +473,29 @@ extern "C" int kfn_first_conv_u8_ex(const uint8_t* img, int N, int H, int W, con
   hipStream_t s = (hipStream_t)stream;
 #define KFN_FIRST(L1, L2)                                                                     \
   hipLaunchKernelGGL((first_conv_kernel<L1, L2>), grid, block, 0, s, img, N, H, W, w1, b1, y1, w2, b2, y2)
+  // lane-per-pixel form for the 64(+16)-channel layers whose rows are whole dwords (every size the path uses)
+  const long img_total = (long)N * H * W * 3;
+  if (C1 == 64 && (C2 == 16 || C2 == 0) && (W * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 &&
+      img_total < (1L << 31) && (reinterpret_cast<uintptr_t>(y1) & 15) == 0 && (C2 == 0 || (reinterpret_cast<uintptr_t>(y2) & 15) == 0)) {
+    static std::atomic<uint64_t> attr_done[4] = {};
+    const bool h16 = y1_dtype == KFN_ACT_F16;
+    const int which = (C2 == 16 ? 0 : 1) + (h16 ? 2 : 0);
+#define KFN_FIRST_PX(C2V, O16)                                                                                        \
+    do {                                                                                                               \
+      int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(first_conv_px_kernel<C2V, O16>), PX_LDS_BYTES,   \
+                                        attr_done[which]);                                                             \
+      if (rc != KFN_OK) return rc;                                                                                     \
+      hipLaunchKernelGGL((first_conv_px_kernel<C2V, O16>), grid, block, PX_LDS_BYTES, s, img, N, H, W,                 \
+                         (unsigned)img_total, w1, b1, y1, w2, b2, y2);                                                 \
+    } while (0)
+    if (C2 == 16 && !h16) KFN_FIRST_PX(16, false);
+    else if (C2 == 16) KFN_FIRST_PX(16, true);
+    else if (!h16) KFN_FIRST_PX(0, false);
+    else KFN_FIRST_PX(0, true);
+#undef KFN_FIRST_PX
+    KFN_LAUNCH_CHECK("first_conv_px_kernel");
+    return KFN_OK;
+  }
   if (y1_dtype == KFN_ACT_F16) {
     // fp16 activations (BASELINE config 5): the wide head (SCoordNet conv1a) writes halfs, a second head stays fp32
     if (C1 == 64 && C2 == 16)

@@ -375,7 +375,7 @@ class ConvOp(Op):
 
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
                 6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2),
-                10: (2, 1, 4, 1), 11: (1, 1, 4, 1)}   # 10/11: 16-column variants (PREC tag 3)
+                10: (2, 1, 4, 1), 11: (1, 1, 4, 1), 12: (2, 2, 4, 1)}   # 10/11: 16-column variants (PREC tag 3)
     # template tag PREC of conv_mfma_kernel for fp16 activations: (x is f16, y is f16) -> 4 / 5 / 6
     PREC_F16_IO = {(True, False): 4, (False, True): 5, (True, True): 6}
 
@@ -416,7 +416,7 @@ class WindowFcConvOp(ConvOp):
             return
         if self.kernel.storage is not None:
             raise _lib.KfnError('%s: weights already packed as a window matrix' % self.name)
-        self.kernel.pack = pack_conv_kernel
+        self.kernel.pack = as_f16(pack_conv_kernel) if self.operand_dtype == _lib.OPERAND_F16 else pack_conv_kernel
         if self.bias is not None:
             self.bias.pack = pack_bias
         self.__class__ = ConvOp

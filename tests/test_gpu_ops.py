@@ -108,8 +108,11 @@ def test_conv_bad_args_fail_loudly():
     assert rc == -1 and b'Cin' in lib.kfn_last_error()
 
 
-@pytest.mark.parametrize('hw', [(8, 64), (9, 70), (48, 96)])
+@pytest.mark.parametrize('hw', [(8, 64), (9, 70), (48, 96), (37, 132), (5, 4), (540 // 8, 960)])
 def test_first_conv_u8(hw):
+    """W*3 % 4 == 0 takes the lane-per-pixel kernel (aligned dword halo loads; (37,132): a partial last tile in x and
+    y, (5,4): an image narrower than the halo), the other widths the byte-wise kernel; a single-head call and guard
+    words behind both outputs."""
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib
     import torch
@@ -121,8 +124,9 @@ def test_first_conv_u8(hw):
     b1 = rng.normal(size=64).astype(np.float32)
     w2 = (rng.normal(size=(3, 3, 3, 16)) / 5).astype(np.float32)
     b2 = rng.normal(size=16).astype(np.float32)
-    y1 = torch.zeros(2 * H * W * 64, device='cuda')
-    y2 = torch.zeros(2 * H * W * 16, device='cuda')
+    n1, n2 = 2 * H * W * 64, 2 * H * W * 16
+    y1 = torch.full((n1 + 256,), -3.0, device='cuda')
+    y2 = torch.full((n2 + 256,), -3.0, device='cuda')
     di, dw1, db1, dw2, db2 = dev(img), dev(w1.reshape(27, 64)), dev(b1), dev(w2.reshape(27, 16)), dev(b2)
     _lib.check(lib.kfn_first_conv_u8(di.data_ptr(), 2, H, W, dw1.data_ptr(), db1.data_ptr(), y1.data_ptr(), 64,
                                      dw2.data_ptr(), db2.data_ptr(), y2.data_ptr(), 16, stream()), 'first')
@@ -130,8 +134,18 @@ def test_first_conv_u8(hw):
     xp = O.preprocess(img, np.float64)
     r1 = O.conv2d_same(xp, w1, b1, 1, True)
     r2 = O.conv2d_same(xp, w2, b2, 1, True)
-    assert np.abs(y1.cpu().numpy().reshape(r1.shape) - r1).max() < 2e-5
-    assert np.abs(y2.cpu().numpy().reshape(r2.shape) - r2).max() < 2e-5
+    g1, g2 = y1.cpu().numpy(), y2.cpu().numpy()
+    assert np.all(g1[n1:] == -3.0) and np.all(g2[n2:] == -3.0)
+    assert np.abs(g1[:n1].reshape(r1.shape) - r1).max() < 2e-5
+    assert np.abs(g2[:n2].reshape(r2.shape) - r2).max() < 2e-5
+    # one head only, no bias
+    y1b = torch.full((n1 + 256,), -3.0, device='cuda')
+    _lib.check(lib.kfn_first_conv_u8(di.data_ptr(), 2, H, W, dw1.data_ptr(), None, y1b.data_ptr(), 64, None, None, None,
+                                     0, stream()), 'first (one head)')
+    sync()
+    g1b = y1b.cpu().numpy()
+    assert np.all(g1b[n1:] == -3.0)
+    assert np.abs(g1b[:n1].reshape(r1.shape) - O.conv2d_same(xp, w1, None, 1, True)).max() < 2e-5
 
 
 def test_cost_volume_bit_exact():
@@ -510,7 +524,7 @@ F16_ACT_CASES = [
 
 
 @pytest.mark.parametrize('case', F16_ACT_CASES)
-@pytest.mark.parametrize('config,k_step', [(0, 0), (2, 16), (2, 32), (9, 16), (9, 32), (7, 0), (3, 0)])
+@pytest.mark.parametrize('config,k_step', [(0, 0), (2, 16), (2, 32), (9, 16), (9, 32), (7, 0), (3, 0), (12, 16), (12, 32)])
 def test_conv_fp16_activations(case, config, k_step):
     """x_dtype = y_dtype = KFN_ACT_F16 (BASELINE config 5, fp16 activations end to end): the input tensor holds
     halfs, the output is ONE RNE rounding of the fp32 result.  Reference: an fp64 convolution of the fp16 input and
@@ -549,16 +563,18 @@ def test_conv_fp16_activations_mixed_and_strided(x16, y16):
     assert np.all(np.abs(y - ref) <= tol)
 
 
-def test_first_conv_fp16_head():
+@pytest.mark.parametrize('W', [70, 132])
+def test_first_conv_fp16_head(W):
     """kfn_first_conv_u8_ex with an fp16 first head (config 5: SCoordNet conv1a) beside an fp32 second head: the
-    fp16 head equals the fp32 kernel's result rounded once; the second head is bit-identical to the fp32 call."""
+    fp16 head equals the fp32 kernel's result rounded once; the second head is bit-identical to the fp32 call.
+    W = 70: byte-wise kernel, W = 132: lane-per-pixel kernel."""
     import torch
     from kfnet_amd import _lib
     from kfnet_amd.graph import pack_first_kernel
     from tests.gpu_util import dev, stream, sync
     lib = _lib.load()
     rng = np.random.default_rng(3)
-    N, H, W = 2, 37, 70
+    N, H = 2, 37
     img = rng.integers(0, 256, size=(N, H, W, 3)).astype(np.uint8)
     w1 = (rng.normal(size=(3, 3, 3, 64)) / 5).astype(np.float32)
     w2 = (rng.normal(size=(3, 3, 3, 16)) / 5).astype(np.float32)

@@ -52,7 +52,7 @@ for (name, lv, ci, co, k, s) in LAYERS:
         t = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x32.data_ptr(), u.data_ptr(), None, y32.data_ptr(), st), 'w'))
         res.append('f32act wino3 %.3f ms %4.0f TF' % (t, fl / t / 1e9))
         del u
-    cfgs = [(2, '128x128'), (9, '128x256')] if co >= 128 else [(7, '192x64'), (3, '128x64')]
+    cfgs = [(2, '128x128'), (9, '128x256')] if co >= 128 else [(7, '192x64'), (3, '128x64'), (12, '256x64')]
     for cfg, cn in cfgs:
         for ks in ((16, 32) if ci % 64 == 0 else (16,)):
             t = conv(x16, y16, cfg, ks, 1, 1)
