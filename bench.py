@@ -43,13 +43,13 @@ C5_DELTA_PX = 0.05            # config 5's tolerance is stated >= this far from 
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA (measured 2495)
 
 
-def latest_pmc_traffic():
-    """(path, dict) of the newest per-round PMC summary profiles/rNN_pmc_traffic.json (written by
+def latest_pmc_traffic(suffix='pmc_traffic'):
+    """(path, dict) of the newest per-round PMC summary profiles/rNN_<suffix>.json (written by
     tools/profile_round.sh from separate rocprofv3 --pmc passes), or (None, {})."""
     import glob
     import re
-    cands = [p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json'))
-             if re.match(r'r\d\d_pmc_traffic\.json$', os.path.basename(p))]
+    cands = [p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % suffix))
+             if re.match(r'r\d\d_%s\.json$' % suffix, os.path.basename(p))]
     if not cands:
         return None, {}
     path = max(cands)
@@ -614,6 +614,17 @@ def bench_c2(args, device):
     print(json.dumps(out))
 
 
+def c5_traffic(kernel, batch):
+    """HBM-side bytes per launch of config 5's dominant kernel from the newest profiles/rNN_c5_pmc_traffic.json
+    (separate rocprofv3 --pmc passes of `bench.py --config c5`, tools/profile_round.sh) -- quoted, not measured here."""
+    path, tj = latest_pmc_traffic('c5_pmc_traffic')
+    t = tj.get(kernel)
+    if t is None:
+        return None
+    return dict(t, quoted_from=os.path.relpath(path, ROOT), sampled={'command': 'bench.py --config c5', 'tower_batch': 16},
+                this_run_tower_batch=batch)
+
+
 def bench_c5(args, device):
     """BASELINE configs[4]: 960x540 input (68x120 grid), S independent sequences of T frames,
     fp16 conv operands (fp32 accumulate) + fp32 Kalman scan advancing all sequences in one
@@ -634,7 +645,9 @@ def bench_c5(args, device):
     dev = torch.from_numpy(seqs).to(device)
     eng.process_sequences(dev)
     torch.cuda.synchronize()
-    times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, args.min_seconds)
+    tele = Telemetry(device.index if device.index is not None else 0)
+    with tele:
+        times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, args.min_seconds)
     med = float(np.median(times))
     PF = min(T, 16)     # frames per sequence of the parity sample
     rec16 = eng.process_sequences(dev)[:, :PF].cpu().numpy().copy()
@@ -654,24 +667,27 @@ def bench_c5(args, device):
     out = {'metric': 'frames/sec on 960x540 seq', 'value': round(S * T / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
            'steps': S * T, 'warmup': S * T, 'ms_per_step': round(med * 1e3 / (S * T), 4), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f16 conv operands (f32 accumulate), f32 first layer / flow head / Kalman',
+           'dtype': 'f16 conv operands (f32 accumulate), f16 activations in SCoordNet, f32 first-layer arithmetic / OFlowNet '
+                    'window kernels / Kalman',
            'data': 'synthetic (rolled random texture uint8 frames, seeded random weights)',
-           'repetitions': len(times),
+           'repetitions': len(times), 'gpu_telemetry': tele.summary(),
            'config': {'workload': 'BASELINE configs[4]: %d sequences x %d frames of %dx%d (grid 68x120), fp16 convs + '
                                   'fp32 Kalman, one batched scan launch' % (S, T, H, W), 'tower_batch': B},
            # the dominant fp16-operand kernel; achieved = ALGORITHMIC (nominal direct-convolution) FLOPs of its layers /
            # its time -- the Winograd / polyphase kernels execute 16/36 resp. 25/36 of them (executed_tflops)
            'roofline': {'kernel': dom, 'bound': 'mfma', 'achieved': round(fl_dom / (ms_dom * 1e-3) / 1e12, 1),
                         'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(fl_dom / (ms_dom * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
+                        'frac': round(fl_dom / (ms_dom * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': c5_traffic(dom, B),
                         'executed_tflops': round(ex_dom / (ms_dom * 1e-3) / 1e12, 1),
                         'launches_per_batch': n_dom, 'share_of_step_time': round(ms_dom / heavy_ms, 4),
                         'all_fp16_operand_launches_algorithmic_tflops': round(fl16 / (ms16 * 1e-3) / 1e12, 1),
                         'all_fp16_operand_launches_share_of_step_time': round(ms16 / heavy_ms, 4),
-                        'note': 'wino3_kernel<true> / wino_s2_kernel<true> = the four-wave Winograd F(2x2,3x3) and the '
-                                'polyphase F(2,2) stride-2 kernels on v_mfma_f32_32x32x8_f16 (input transform in fp32, V and '
-                                'U rounded to fp16, fp32 accumulation); conv_mfma_kernel<..., 1> = direct fp16-operand '
-                                'implicit GEMM; activations are fp32 in HBM'},
+                        'note': 'conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,PREC>: PREC 6 = direct implicit GEMM on '
+                                'v_mfma_f32_32x32x16_f16 with fp16 activations in AND out of HBM (tap-innermost K order, '
+                                'chunk-major weights, LDS-transposed 16-byte output runs), PREC 4 = fp16 in / fp32 out, PREC 1 = '
+                                'fp16 operands rounded while staging fp32 activations (OFlowNet, feature tower); '
+                                'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
+                                'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},
            'kernels_ms_per_batch': {k: {'launches': v[0], 'ms': round(v[2], 4),
                                         'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[1] else None}
                                     for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])[:8]},

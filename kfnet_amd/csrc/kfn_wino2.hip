@@ -72,6 +72,7 @@ struct Wino2Args {
   int bw;             // ceil(Tw / BW) column blocks
   int tiles_m, tiles_n;
   int relu;
+  int wide_store;     // Cout, ldy multiples of 4 and y 16-byte aligned: LDS-transposed 16-byte stores
   int dbg;            // timing experiments only (KFN_WINO2_DBG): 1 = every A row read from row 0, 2 = every B fragment = fragment 0
   unsigned long long x_bytes;
   unsigned long long y_bytes;
@@ -149,6 +150,7 @@ __device__ __forceinline__ void bt_d_b(f32x2 (&v)[32]) {
     for (int h = 0; h < 2; ++h) bt_pass(v[2 * (0 + c) + h], v[2 * (4 + c) + h], v[2 * (8 + c) + h], v[2 * (12 + c) + h]);
 }
 
+template <bool WIDE>   // WIDE: LDS-transposed 16-byte output stores (Cout, ldy multiples of 4, y 16-byte aligned)
 __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];   // [2][BUF_BYTES] raw patches
 
@@ -387,22 +389,58 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, ok ? voff_y : OOBV, soff, 0);
     }
   };
+  auto out_transform = [&](auto&& put) __attribute__((always_inline)) {
 #pragma unroll
-  for (int ep = 0; ep < 8; ++ep) {
-    const int e0 = 2 * ep;
-    f32x2 r0[4], r1[4];
+    for (int ep = 0; ep < 8; ++ep) {
+      const int e0 = 2 * ep;
+      f32x2 r0[4], r1[4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const f32x2 m0 = {acc[0 + nu][e0], acc[0 + nu][e0 + 1]}, m1 = {acc[4 + nu][e0], acc[4 + nu][e0 + 1]};
-      const f32x2 m2 = {acc[8 + nu][e0], acc[8 + nu][e0 + 1]}, m3 = {acc[12 + nu][e0], acc[12 + nu][e0 + 1]};
-      r0[nu] = pk_add(pk_add(m0, m1), m2);
-      r1[nu] = pk_sub(pk_sub(m1, m2), m3);
+      for (int nu = 0; nu < 4; ++nu) {
+        const f32x2 m0 = {acc[0 + nu][e0], acc[0 + nu][e0 + 1]}, m1 = {acc[4 + nu][e0], acc[4 + nu][e0 + 1]};
+        const f32x2 m2 = {acc[8 + nu][e0], acc[8 + nu][e0 + 1]}, m3 = {acc[12 + nu][e0], acc[12 + nu][e0 + 1]};
+        r0[nu] = pk_add(pk_add(m0, m1), m2);
+        r1[nu] = pk_sub(pk_sub(m1, m2), m3);
+      }
+      const f32x2 o0 = pk_add(pk_add(r0[0], r0[1]), r0[2]), o1 = pk_sub(pk_sub(r0[1], r0[2]), r0[3]);
+      const f32x2 o2 = pk_add(pk_add(r1[0], r1[1]), r1[2]), o3 = pk_sub(pk_sub(r1[1], r1[2]), r1[3]);
+      const int trow = e0 >> 2, ec = e0 & 3;
+      put(o0.x, trow, ec, 0, 0); put(o1.x, trow, ec, 0, 1); put(o2.x, trow, ec, 1, 0); put(o3.x, trow, ec, 1, 1);
+      put(o0.y, trow, ec + 1, 0, 0); put(o1.y, trow, ec + 1, 0, 1); put(o2.y, trow, ec + 1, 1, 0); put(o3.y, trow, ec + 1, 1, 1);
     }
-    const f32x2 o0 = pk_add(pk_add(r0[0], r0[1]), r0[2]), o1 = pk_sub(pk_sub(r0[1], r0[2]), r0[3]);
-    const f32x2 o2 = pk_add(pk_add(r1[0], r1[1]), r1[2]), o3 = pk_sub(pk_sub(r1[1], r1[2]), r1[3]);
-    const int trow = e0 >> 2, ec = e0 & 3;
-    emit(o0.x, trow, ec, 0, 0); emit(o1.x, trow, ec, 0, 1); emit(o2.x, trow, ec, 1, 0); emit(o3.x, trow, ec, 1, 1);
-    emit(o0.y, trow, ec + 1, 0, 0); emit(o1.y, trow, ec + 1, 0, 1); emit(o2.y, trow, ec + 1, 1, 0); emit(o3.y, trow, ec + 1, 1, 1);
+  };
+  if constexpr (WIDE) {
+    // Global stores are ISSUE bound (~60 cycles per store instruction per CU whatever its width): 128 dword stores
+    // per wave cost more than a third of a 64-channel layer's whole K loop.  As in kfn_wino3.hip the wave
+    // transposes its 128 pixels x 32 channels through 16 KiB of the (now idle) staging buffers -- [pixel][32
+    // channels], written by ds_write_b32, read back as 1 KiB runs -- and issues 16 stores of 16 bytes per lane: 8
+    // lanes cover the 128 contiguous bytes of a pixel.  (LDS operations of one wave complete in order: the stray
+    // prefetch reads of the last chunk cannot be overtaken by these writes.)
+    char* const stg = smem2;
+    const int st_w = lh * 1024 + li * 4;   // block pixel (oy, ox) = (2 trow + a, 8 lh + 2 ec + b) -> row oy*16 + ox
+    out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
+      *reinterpret_cast<float*>(stg + st_w + ((2 * trow + a) * 16 + 2 * ec + b) * 128) = v;
+    });
+    const int oxl = lane >> 3, nq = lane & 7;            // store lane: pixel column oxl (+8), channel quad nq
+    const unsigned voff_q = (unsigned)((oxl * p.ldy + n0 + nq * 4) * 4);
+    const bool q_ok = n0 + nq * 4 < p.Cout;
+    const int ox0 = 2 * cb * BW;
+    const unsigned voff_h[2] = {(q_ok && ox0 + oxl < p.W) ? voff_q : OOBV, (q_ok && ox0 + 8 + oxl < p.W) ? voff_q : OOBV};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + i * 1024 + lane * 16);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int trow = i >> 2, a = (i >> 1) & 1, hx = i & 1;
+      const int img_rel = trow < brk ? 0 : 1;
+      const int ty = trow < brk ? ty0 + trow : trow - brk;
+      const int oy = 2 * ty + a;
+      const bool row_in = vr0 + trow < p.vrows && oy < p.H;        // uniform
+      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + ox0 + 8 * hx) * pix_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             rsY, row_in ? voff_h[hx] : OOBV, soff, 0);
+    }
+    return;
+  } else {
+    out_transform(emit);
   }
 }
 
@@ -477,12 +515,17 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
+  a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   a.dbg = KFN_WINO2_DBG;   // build-time timing hooks (-DKFN_WINO2_DBG=1: hot A, 2: hot B); 0 in the product build
   a.x_bytes = (unsigned long long)x_bytes;
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)u_bytes;
-  hipLaunchKernelGGL(wino2_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64), 2 * BUF_BYTES,
-                     (hipStream_t)stream, a);
+  if (a.wide_store)
+    hipLaunchKernelGGL(wino2_kernel<true>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64), 2 * BUF_BYTES,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(wino2_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64), 2 * BUF_BYTES,
+                       (hipStream_t)stream, a);
   KFN_LAUNCH_CHECK("wino2_kernel");
   return KFN_OK;
 }

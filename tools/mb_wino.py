@@ -26,7 +26,8 @@ for (name, H, W, ci, co) in LAYERS:
         continue
     x = torch.randn(N * H * W * ci, device='cuda')
     u = torch.randn(16 * co * ci, device='cuda') * 0.02
-    y = torch.empty(N * H * W * co, device='cuda')
+    y = torch.empty(N * H * W * co + 4, device='cuda')
+    YOFF = 4 * int(os.environ.get('MB_Y_MISALIGN', '0'))   # 1: y 4 bytes off a 16-byte boundary -> the kernels' dword-store epilogue
     Mt = N * (H // 2) * (W // 2)
     F16 = os.environ.get('MB_F16', '') == '1'       # fp16 operands (BASELINE config 5): four-wave form only
     if F16:
@@ -35,7 +36,7 @@ for (name, H, W, ci, co) in LAYERS:
         u = u.half()
     d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1, wino_order=ORDER,
                       config=int(os.environ.get('KFN_WINO_CFG', '0')), operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32)
-    t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 'wf'))
+    t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr() + YOFF, st), 'wf'))
     fl = 2.0 * 16 * Mt * ci * co
     t_gemm = t_out = float('nan')
     if ci >= 128 and not FUSED_ONLY:

@@ -37,4 +37,22 @@ python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(
 # the un-profiled bench line (quotes the fresh PMC traffic copied to profiles/ above)
 python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
 rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
+# ---- BASELINE config 5 (960x540, fp16 convs + fp16 activations, fp32 Kalman): kernel trace + the same PMC passes ----
+C5="--config c5 --no-cpu-baseline --min-seconds 0"
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/c5kt -- python $R/bench.py $C5 > $OUT/${TAG}_c5_bench_under_rocprof.json 2> $OUT/c5kt.err )
+python tools/rocpd_stats.py "$(finddb $OUT/c5kt)" $OUT/${TAG}_c5_kernel_stats.csv > /dev/null
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/c5$C -- python $R/bench.py $C5 > /dev/null 2> $OUT/c5$C.err )
+done
+python tools/pmc_traffic.py "$(finddb $OUT/c5FETCH_SIZE)" "$(finddb $OUT/c5WRITE_SIZE)" $OUT/${TAG}_c5_pmc_traffic.json > /dev/null
+i=0
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/c5sq$i -- python $R/bench.py $C5 > /dev/null 2> $OUT/c5sq$i.err )
+done
+python tools/pmc_sq.py $OUT/${TAG}_c5_pmc_sq_counters.json "$(finddb $OUT/c5sq1)" "$(finddb $OUT/c5sq2)" "$(finddb $OUT/c5sq3)"
+cp $OUT/${TAG}_c5_pmc_traffic.json $R/profiles/${TAG}_c5_pmc_traffic.json    # quoted by the c5 bench line below
+python bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
+python bench.py --config c2 > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
+rm -rf $OUT/c5kt $OUT/c5FETCH_SIZE $OUT/c5WRITE_SIZE $OUT/c5sq1 $OUT/c5sq2 $OUT/c5sq3
 ls -la $OUT
