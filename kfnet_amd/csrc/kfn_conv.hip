@@ -473,7 +473,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         ga[k] = buf_load_s(rsA, a_ok2[CVOL ? i : 0] ? a_off[i] : OOB, adelta);
       }
     } else if (X16 && k < AP * NSRC) {   // fp16 activations: the quad's 8 channels are one 16-byte load
+#if defined(KFN_CONV_HOT) && (KFN_CONV_HOT & 1)   // timing experiment only (tools/mb/build_hot.sh): every A load hits a 64 KiB window
+      ga[k] = buf_load_s(rsA, a_shift + (a_off[k] & 0xFFF0u), 0u);   // inside the tensor: the descriptor is based a_shift below it
+#else
       ga[k] = buf_load_s(rsA, a_ok[k] ? a_off[k] : OOB, adelta);
+#endif
     } else if (F16 && k < AP * NSRC) {   // two consecutive float4 = the 8 channels of one fp16 quad
       const int i = k / NSRC;
       if (TRANSPOSED) {
@@ -502,7 +506,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       // f16x3: the packed weights are [hi | lo], lo starts w_lo_bytes after hi
       const unsigned part_off = (X3 && (kk % NPART)) ? p.w_lo_bytes : 0u;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, live ? (int)p.w_bytes : 0, 0x00020000);
+#if defined(KFN_CONV_HOT) && (KFN_CONV_HOT & 2)   // timing experiment only: every B load re-reads the first K chunk
+      gb[kk] = buf_load_s(rs, b_off[i], part_off);
+#else
       gb[kk] = buf_load_s(rs, b_off[i], (F16 ? bdelta >> 1 : bdelta) + part_off);
+#endif
     }
   };
 

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Timing-experiment builds of the conv kernels with "hot" operands (NOT product builds, results are wrong on purpose):
+#   tools/mb/libkfnet_hot1.so  every A (activation) load of the fp16-activation kernels hits a 64 KiB window
+#   tools/mb/libkfnet_hot2.so  every B (weight) load re-reads the first K chunk
+#   tools/mb/libkfnet_hot3.so  both
+# They answer "is the kernel bound by where its operands come from?" (tools/mb_f16.py with MB_LIB=<path>).
+cd "$(dirname "$0")/../.."
+for v in ${HOT_VARIANTS:-1 2 3}; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DKFN_CONV_HOT=$v -c kfnet_amd/csrc/kfn_conv.hip -o /tmp/kfn_conv_hot$v.o || exit 1
+  OBJS=$(ls kfnet_amd/csrc/build/*.o | grep -v kfn_conv.o)
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_hot$v.so /tmp/kfn_conv_hot$v.o $OBJS || exit 1
+done
+ls -la tools/mb/*.so
