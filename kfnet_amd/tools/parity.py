@@ -94,9 +94,13 @@ def masked_parity(rec, ref, ref_flow, coord_tol=2e-2, conf_rel_tol=5e-2, delta=0
     if test_flow is not None:
         seeds = crossing_seeds(ref_flow, test_flow, reset_period, t0)
         sd = step_distance(ref_flow)
+        # frames that sample something: on a reset frame the flow is computed but never used (and pairs the frame
+        # with whatever the feature ring held before the sequence started)
+        used = np.array([not (reset_period > 0 and (t0 + t) % reset_period == 0) for t in range(rec.shape[0])])
+        fd = np.abs(np.asarray(ref_flow) - np.asarray(test_flow))[used]
         extra = {'crossings': int(seeds.sum()),
                  'crossing_max_step_distance_px': float(sd[seeds].max()) if seeds.any() else 0.0,
-                 'flow_max_abs_diff_px': float(np.abs(np.asarray(ref_flow) - np.asarray(test_flow)).max())}
+                 'flow_max_abs_diff_px': float(fd.max()) if fd.size else 0.0}
     taint = sampler_taint(ref_flow, delta, reset_period, t0, seeds=seeds)
     dc = np.abs(rec[..., :3] - ref[..., :3]).max(-1)
     dr = np.abs(rec[..., 3] - ref[..., 3]) / np.abs(ref[..., 3])

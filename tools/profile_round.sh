@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 finddb() { find "$1" -name '*.db' | head -1; }
-SHORT="--steps 64 --batch 32 --min-seconds 0 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline"
+SHORT="--steps 64 --batch 32 --min-seconds 0 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline --no-config3"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err )
 python tools/rocpd_stats.py "$(finddb $OUT/kt)" $OUT/${TAG}_kernel_stats.csv > /dev/null
 # same trace with the two towers serialised on one stream: kernel durations without the
