@@ -658,7 +658,7 @@ def bench_c5(args, device):
         k = by_kernel.setdefault(r[1], [0, 0.0, 0.0, 0.0])
         k[0] += 1; k[1] += r[2]; k[2] += r[3]; k[3] += r[4]
     heavy_ms = sum(r[3] for r in rows)
-    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6'))
+    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7'))
     k16 = {k: v for k, v in by_kernel.items() if is16(k)}
     dom = max(k16, key=lambda k: k16[k][2])
     n_dom, fl_dom, ms_dom, ex_dom = k16[dom]
@@ -684,7 +684,8 @@ def bench_c5(args, device):
                         'all_fp16_operand_launches_share_of_step_time': round(ms16 / heavy_ms, 4),
                         'note': 'conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,PREC>: PREC 6 = direct implicit GEMM on '
                                 'v_mfma_f32_32x32x16_f16 with fp16 activations in AND out of HBM (tap-innermost K order, '
-                                'chunk-major weights, LDS-transposed 16-byte output runs), PREC 4 = fp16 in / fp32 out, PREC 1 = '
+                                'chunk-major weights, LDS-transposed 16-byte output runs), PREC 7 = the same with the weight '
+                                'tile going global -> LDS directly (buffer_load ... lds), PREC 4 = fp16 in / fp32 out, PREC 1 = '
                                 'fp16 operands rounded while staging fp32 activations (OFlowNet, feature tower); '
                                 'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
                                 'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},

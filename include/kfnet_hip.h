@@ -94,7 +94,13 @@ typedef struct kfn_conv_desc {
                           * (BASELINE config 5: fp16 activations end to end); ldx / ldy count ELEMENTS. */
   int32_t k_step;        /* 0 = auto; 16 / 32 = LDS k-step in 4-byte words (fp16 operands: 32 / 64 channels per
                           * stage).  32 exists for the fp16-activation kernels only. */
+  int32_t weights_path;  /* fp16 activations in AND out only: KFN_WEIGHTS_AUTO / _VIA_REGISTERS (global -> registers ->
+                          * ds_write) / _LDS_DMA (global -> LDS directly, `buffer_load ... lds`, three weight buffers) */
 } kfn_conv_desc;
+
+#define KFN_WEIGHTS_AUTO 0
+#define KFN_WEIGHTS_VIA_REGISTERS 1
+#define KFN_WEIGHTS_LDS_DMA 2
 
 #define KFN_ACT_F32 0
 #define KFN_ACT_F16 1

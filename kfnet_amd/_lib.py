@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
         'transposed', 'relu', 'epilogue', 'config', 'operand_dtype', 'wino_order', 'wino_form',
-        'x_dtype', 'y_dtype', 'k_step')]
+        'x_dtype', 'y_dtype', 'k_step', 'weights_path')]
 
 
 class KalmanDesc(C.Structure):

@@ -145,11 +145,20 @@ constexpr int PREC_F32_N16 = 3;
 //       transposed through the idle operand LDS and leaves as 16-byte runs of 8 channels;
 //   _XY both.  k-step 16 or 32 (= 32 / 64 channels per stage).
 constexpr int PREC_F16_X = 4, PREC_F16_Y = 5, PREC_F16_XY = 6;
+// PREC_F16_XY_BDMA: as _XY, with the WEIGHT tile going global -> LDS directly (`buffer_load_dwordx4 ... lds`): no
+// staging registers and no ds_write_b128 for two thirds of the operand bytes (timing builds without LDS stores run
+// 25-30 % faster: tools/mb/build_hot.sh).  A lane's 16 bytes land at wave base + lane*16, so the XOR swizzle of the
+// LDS rows moves to the SOURCE address (lane (row, slot q) fetches logical quad q ^ sw(row)); three B buffers: the
+// transfer for stage s+2 is issued in stage s, behind the LDS stores of A -- loads return in order, so the wait the
+// compiler places in front of the next stage's A stores also covers it, one stage before its barrier.
+constexpr int PREC_F16_XY_BDMA = 7;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  constexpr bool X16 = (PREC == PREC_F16_X || PREC == PREC_F16_XY);   // activations read as halfs
-  constexpr bool Y16 = (PREC == PREC_F16_Y || PREC == PREC_F16_XY);   // activations written as halfs
+  constexpr bool BDMA = (PREC == PREC_F16_XY_BDMA);
+  constexpr bool X16 = (PREC == PREC_F16_X || PREC == PREC_F16_XY || BDMA);   // activations read as halfs
+  constexpr bool Y16 = (PREC == PREC_F16_Y || PREC == PREC_F16_XY || BDMA);   // activations written as halfs
+  static_assert(!BDMA || BK == 16, "LDS-DMA weights: k-step 16");
   constexpr bool F16 = (PREC == PREC_F16 || PREC == PREC_F16X3 || X16 || Y16);   // operands live in LDS as halfs
   constexpr unsigned XB = X16 ? 2u : 4u;                               // bytes per input element
   // fp16-activation kernels walk the K dimension TAP-INNERMOST: all live taps of one channel chunk, then the next
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][BK] swizzled
-  float* Bs = smem + 2 * A_ELEMS;   // [2][BN][BK] swizzled
+  float* Bs = smem + 2 * A_ELEMS;   // [2][BN][BK] swizzled ([3] with LDS-DMA weights)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -369,7 +378,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int i = 0; i < BP; ++i) {
     const int r = r0 + i * RPP;
     const int n = n0 + r;
-    if constexpr (TAP_INNER)   // chunk-major weights: 64-byte rows of a [cout_pad][32] block, the k-step-32 quads 4..7 in the next block
+    if constexpr (BDMA)        // LDS slot q of row r receives logical quad q ^ sw(r) (the swizzle is applied at the source)
+      b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * 64 + ((q ^ swz<BK>(r)) & 3) * 16) : OOB;
+    else if constexpr (TAP_INNER)   // chunk-major weights: 64-byte rows of a [cout_pad][32] block, the k-step-32 quads 4..7 in the next block
       b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(((q >> 2) * p.cout_pad + n) * 64 + (q & 3) * 16) : OOB;
     else
       b_off[i] = (r < BN && n < p.cout_pad) ? (unsigned)(n * p.Ktot + q * QCH) * (F16 ? 2u : 4u) : OOB;
@@ -460,6 +471,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // Issue the global loads of the stage the iterator points at (all-OOB = zeros once the
   // iterator has run off the end: keeps the loop body branch-free).
   auto load_one = [&](int k, bool live, unsigned adelta, unsigned bdelta, int ky, int kx, int tap) {
+#if defined(KFN_CONV_HOT) && (KFN_CONV_HOT & 8)   // timing experiment only: no global loads in the main loop
+    if (TAP_INNER && ld_ci > 0) return;
+#endif
     if (WINO && k < AP * NSRC) {
       // per-lane: the source pixel's offset (or OOB for zero padding); uniform: channel offset; a stream
       // that has run off the end reads through a descriptor with num_records = 0 (scalar select)
@@ -518,6 +532,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // because RPP is a multiple of 16 rows.
   const int wr_off = r0 * BK + ((q ^ swz<BK>(r0)) * 4);
   auto store_one = [&](int k, int buf) {
+#if defined(KFN_CONV_HOT) && (KFN_CONV_HOT & 4)   // timing experiment only: no LDS stores in the main loop (stale operands)
+    if (TAP_INNER && n_stages > 2 && buf >= 0) return;
+#endif
     if (k < AP) {
       const int i = k;
       f32x4 v;
@@ -581,21 +598,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   // double-buffered fragments: [A hi (TM) | B hi (TN)] and, for f16x3, [A lo | B lo] behind them
   f32x4 fr[2][(TM + TN) * NPART];
-  auto read_one = [&](int k, int slot, int buf, int c) {
+  int bcur = 0;   // BDMA: B buffer of the current stage (s % 3)
+  auto read_one = [&](int k, int slot, int buf, int c, int bbuf) {
     const int part = k / (TM + TN), kk = k % (TM + TN);
     if constexpr (N16) {
       // chunk c = row half c of every 32-row block; the B fragment is the same for both halves
       const int row = (kk < TM) ? (wm * TM + kk) * 32 + 16 * c + l16 : (wn * TN + (kk - TM)) * 16 + l16;
       const float* base = (kk < TM) ? As + buf * A_ELEMS : Bs + buf * B_ELEMS;
+      (void)bbuf;
       fr[slot][k] = *reinterpret_cast<const f32x4*>(base + row * BK + ((kq16 ^ swz<BK>(row)) * 4));
     } else if (kk < TM)
       fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + part * A_PART + a_rd + kk * 32 * BK + rdq[c]);
     else
-      fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + buf * B_ELEMS + part * B_PART + b_rd + (kk - TM) * 32 * BK + rdq[c]);
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + (BDMA ? bbuf : buf) * B_ELEMS + part * B_PART + b_rd + (kk - TM) * 32 * BK + rdq[c]);
   };
 
-  constexpr int NLD = AP * NSRC + BP * NPART;  // global loads per stage
-  constexpr int NST = AP + BP * NPART;         // LDS store ops per stage (an f16x3 A op writes hi and lo)
+  constexpr int NLD = AP * NSRC + (BDMA ? 0 : BP * NPART);  // global loads per stage (into registers)
+  constexpr int NST = AP + (BDMA ? 0 : BP * NPART);         // LDS store ops per stage (an f16x3 A op writes hi and lo)
+  constexpr int NDMA = BDMA ? BP : 0;                       // weight-tile transfers global -> LDS per stage
+  // BDMA: transfer i of this wave covers rows 64 i + 16 wave .. +15 of the B tile, lane L -> byte L*16 of that 1 KiB run
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Bs + (unsigned)(wave * 16 * BK * 4));
+  auto dma_one = [&](int i, bool live, unsigned bdelta, int bbuf) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, live ? (int)p.w_bytes : 0, 0x00020000);
+    const unsigned dst = lds_b0 + (unsigned)(bbuf * B_ELEMS * 4) + (unsigned)(i * RPP * BK * 4);
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot type-check this target builtin: it would silently drop every kernel stub)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)dst, 16, b_off[i], bdelta >> 1, 0, 0);
+#else
+    (void)rs; (void)dst;
+#endif
+  };
   constexpr int NFR = (TM + TN) * NPART;       // fragment reads per chunk
   constexpr int NTERM = X3 ? 3 : 1;
   constexpr int J = (F16 ? NTERM : 4) * TM * TN;   // MFMAs per chunk
@@ -609,6 +641,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
                                         : (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) dma_one(i, true, bdelta, 0);
       advance();
 #pragma unroll
       for (int k = 0; k < NST; ++k) store_one(k, 0);
@@ -622,11 +656,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
                                         : (unsigned)(tp * p.Cin + ld_c0) * 4u;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) load_one(k, live, adelta, bdelta, ky, kx, tp);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) dma_one(i, live, bdelta, 1);
       advance();
     }
+    if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both weight tiles have landed
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NFR; ++k) read_one(k, 0, 0, 0);
+    for (int k = 0; k < NFR; ++k) read_one(k, 0, 0, 0, 0);
 
     // ---- main loop: one iteration == one BK-deep stage ---------------------------------
     // Program order inside an iteration (everything but the MFMAs is slotted BETWEEN
@@ -655,8 +692,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // side ops of this chunk, in issue order
         constexpr int n_rd = last ? 0 : NFR;
         constexpr int n_st = (c == 0) ? NST : 0;
+        constexpr int n_dma = (c == 0) ? NDMA : 0;     // behind the A stores of the same chunk (see PREC_F16_XY_BDMA)
         constexpr int n_ld = (c == LOADC) ? NLD : 0;
-        constexpr int n_side = n_rd + n_st + n_ld;
+        constexpr int n_side = n_rd + n_st + n_dma + n_ld;
         constexpr int jspan = last ? (J / 2 > 0 ? J / 2 : 1) : J;  // in the last chunk side ops ride the first half
         static_for<J>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
@@ -665,7 +703,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0); });
+            static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0, bcur == 2 ? 0 : bcur + 1); });
           }
           if constexpr (F16) {
             // t = term: f16x3 adds the two cross terms first, the hi*hi term last
@@ -685,13 +723,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           constexpr int ke = ke0 < n_side ? ke0 : n_side;
           static_for<(ke > kb ? ke - kb : 0)>([&](auto kc) {
             constexpr int k = kb + decltype(kc)::value;
-            if constexpr (k < n_rd) read_one(k, slot ^ 1, buf, c + 1);
+            if constexpr (k < n_rd) read_one(k, slot ^ 1, buf, c + 1, bcur);
             else if constexpr (k < n_rd + n_st) store_one(k - n_rd, buf ^ 1);
-            else load_one(k - n_rd - n_st, live, adelta, bdelta, ky, kx, tp);
+            else if constexpr (k < n_rd + n_st + n_dma) dma_one(k - n_rd - n_st, live, bdelta, bcur == 0 ? 2 : bcur - 1);
+            else load_one(k - n_rd - n_st - n_dma, live, adelta, bdelta, ky, kx, tp);
           });
         });
       });
       advance();
+      if constexpr (BDMA) bcur = (bcur == 2) ? 0 : bcur + 1;
     }
   }
 
@@ -811,6 +851,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     constexpr int CPR = BN / 8;          // 16-byte chunks per tile row
     static_assert((BM * CPR) % NT == 0, "tile chunks must divide evenly over the workgroup");
     unsigned* Ct = reinterpret_cast<unsigned*>(smem);
+    // (LDS-DMA weights: the transfers issued for the two stages past the end write zeros into B buffers this tile
+    //  is about to overlay -- they must have landed first)
+    if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                     // every wave is done reading the operand buffers
     const bool odd = (li & 1) != 0;
     const bool relu16 = p.relu != 0;
@@ -889,8 +932,8 @@ const TileCfg* find_cfg(int cfg) {
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int F16 = PREC_F32>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = (F16 == PREC_F32_N16 ? 16 : 32) * TN * WN, NT = 64 * WM * WN;
-  constexpr size_t smem_ops = (size_t)2 * (BM + BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
-  constexpr size_t smem_epi = (F16 == PREC_F16_Y || F16 == PREC_F16_XY) ? (size_t)BM * BN * 2 : 0;   // fp16 output tile
+  constexpr size_t smem_ops = (size_t)(2 * BM + (F16 == PREC_F16_XY_BDMA ? 3 : 2) * BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
+  constexpr size_t smem_epi = (F16 == PREC_F16_Y || F16 == PREC_F16_XY || F16 == PREC_F16_XY_BDMA) ? (size_t)BM * BN * 2 : 0;   // fp16 output tile
   constexpr size_t smem = smem_ops > smem_epi ? smem_ops : smem_epi;
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
@@ -1144,6 +1187,19 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
     // fp16 activations end to end (BASELINE config 5): wide tiles, k-step 32 (64 channels per stage) when Cin allows
     if (y16) {
       const int c16 = f16io_config(d, a.M);
+      KFN_REQUIRE(d->weights_path >= KFN_WEIGHTS_AUTO && d->weights_path <= KFN_WEIGHTS_LDS_DMA,
+                  "kfn_conv2d_nhwc: unknown weights_path %d", d->weights_path);
+      // weights global -> LDS directly: +6-8 % on the 128x256 tile (966-1026 -> 1032-1089 TFLOP/s, profiles/
+      // r03_c5_layer_microbench.log), neutral on 128x128; AUTO takes it where it pays
+      const bool dma = d->weights_path == KFN_WEIGHTS_LDS_DMA ||
+                       (d->weights_path == KFN_WEIGHTS_AUTO && c16 == KFN_CFG_128x256);
+      if (x16 && f16io_bk(d) == 16 && dma) {
+        switch (c16) {
+          case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
+          case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
+          default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
+        }
+      }
       if (f16io_bk(d) == 32)
         return x16 ? dispatch_f16io<32, PREC_F16_XY>(c16, a, s) : dispatch_f16io<32, PREC_F16_Y>(c16, a, s);
       return x16 ? dispatch_f16io<16, PREC_F16_XY>(c16, a, s) : dispatch_f16io<16, PREC_F16_Y>(c16, a, s);

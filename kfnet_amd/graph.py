@@ -387,7 +387,10 @@ class ConvOp(Op):
         t = self.CFG_TILE[cfg.value]
         io = (self.x.dtype == 'f16', self.y.dtype == 'f16')
         if self.operand_dtype == _lib.OPERAND_F16 and io != (False, False):
-            return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 0, %d>' % (t + (bk.value if io[1] else 16, self.PREC_F16_IO[io]))
+            prec = self.PREC_F16_IO[io]
+            if io == (True, True) and bk.value == 16 and cfg.value == _lib.CFG_128x256:
+                prec = 7      # weights global -> LDS directly (mirror of the AUTO rule in kfn_conv2d_nhwc)
+            return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 0, %d>' % (t + (bk.value if io[1] else 16, prec))
         if self.operand_dtype == _lib.OPERAND_F16:
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, 1>' % (t + (1 if self.transposed else 0,))
         if self.operand_dtype == _lib.OPERAND_F16X3:

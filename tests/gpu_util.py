@@ -23,7 +23,7 @@ def sync():
 
 
 def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config=0, ldx=None, ldy=None,
-             x_off=0, y_off=0, f16=False, x3=False, x16=False, y16=False, k_step=0):
+             x_off=0, y_off=0, f16=False, x3=False, x16=False, y16=False, k_step=0, weights_path=0):
     """x [N,H,W,Cin] np fp32; w TF layout; returns y np [N,Ho,Wo,Cout] computed by the HIP library.
     ldx/ldy > C exercise the strided-view paths (input/output living in wider buffers)."""
     import torch
@@ -58,7 +58,7 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     bd = dev(b.astype(np.float32)) if b is not None else None
     d = _lib.ConvDesc(N=n, H=h, W=wd, Cin=cin, ldx=ldx, Cout=cout, cout_pad=wp.shape[0], ldy=ldy, kh=kh, kw=kw,
                       stride=stride, transposed=int(transposed), relu=int(relu), epilogue=epilogue, config=config,
-                      operand_dtype=2 if x3 else int(f16), x_dtype=int(x16), y_dtype=int(y16), k_step=k_step)
+                      operand_dtype=2 if x3 else int(f16), x_dtype=int(x16), y_dtype=int(y16), k_step=k_step, weights_path=weights_path)
     rc = lib.kfn_conv2d_nhwc(C.byref(d), xd.data_ptr() + xsz * x_off, wd_.data_ptr(),
                              bd.data_ptr() if bd is not None else None, yd.data_ptr() + ysz * y_off, stream())
     _lib.check(rc, 'kfn_conv2d_nhwc')

@@ -330,6 +330,28 @@ def test_config5_tolerance_at_bench_scale():
     assert mp['all_pixels_coord_max_abs'] > 1e-6     # and it is measurably not the fp32 path
 
 
+def test_config5_batch_independence_at_full_size():
+    """Size-independent property at config 5's full geometry (540x960, fp16 path): no layer couples batch elements, so
+    a sequence's records do not depend on which other sequences share the launch, nor on the tower batch size --
+    bit-identical (the fp16-activation kernels round per element; tile membership must not matter)."""
+    import torch
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    seqs = np.stack([synthetic_sequence(5, 540, 960, seed=11 + s) for s in range(2)])
+    dev = torch.from_numpy(seqs).cuda()
+    T4 = np.eye(4, dtype=np.float32)
+    eng = KFNetEngine(W, image_size=(540, 960), batch=5, transform=T4, reset_period=500, max_chunk=10, conv_operands='f16')
+    both = eng.process_sequences(dev).cpu().numpy().copy()
+    del eng
+    torch.cuda.empty_cache()
+    eng = KFNetEngine(W, image_size=(540, 960), batch=2, transform=T4, reset_period=500, max_chunk=5, conv_operands='f16')
+    for s in range(2):
+        alone = eng.process_sequences(dev[s:s + 1]).cpu().numpy()
+        assert np.array_equal(alone[0], both[s]), 'sequence %d depends on its batch neighbours' % s
+
+
 @pytest.mark.parametrize('size,batch', [((64, 96), 2), ((480, 640), 3)])
 def test_f16x3_split_mode_meets_fp32_tolerance(size, batch):
     """conv_operands='f16x3' (operands split into hi+lo halfs, 3 fp16 MFMA products, fp32

@@ -542,6 +542,28 @@ def test_conv_fp16_activations(case, config, k_step):
     assert np.all(np.abs(y - ref) <= tol), float((np.abs(y - ref) - tol).max())
 
 
+@pytest.mark.parametrize('case', F16_ACT_CASES + [(2, 30, 40, 512, 512, 3, 1), (1, 17, 23, 256, 320, 3, 2),
+                                                  (2, 68, 120, 1024, 512, 3, 1)])
+@pytest.mark.parametrize('config', [2, 9])
+def test_conv_fp16_activations_weights_via_lds_dma(case, config):
+    """weights_path = KFN_WEIGHTS_LDS_DMA (the weight tile goes global -> LDS directly, swizzle applied at the source,
+    three weight buffers): BIT-identical to the register-staged path -- same operands, same MFMA order -- on shapes
+    with 1 to 144 K stages, partial row / column tiles and Cout below the tile width; run twice (a race between a
+    transfer and the fragment reads or the epilogue overlay would not be deterministic)."""
+    from tests.gpu_util import run_conv
+    n, h, w, ci, co, k, s = case
+    if ci % 32 != 0:
+        pytest.skip('fp16 operands need Cin % 32 == 0')
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.normal(size=(n, h, w, ci)).astype(np.float16)
+    wt = (rng.normal(size=(k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ref = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=16, weights_path=1)
+    for _ in range(3):
+        y = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=16, weights_path=2)
+        assert np.array_equal(y, ref)
+
+
 @pytest.mark.parametrize('x16,y16', [(True, False), (False, True)])
 def test_conv_fp16_activations_mixed_and_strided(x16, y16):
     """fp16 in -> fp32 out (the 'prediction' head, with its exp epilogue on a narrow tile) and fp32 in -> fp16 out,
@@ -593,6 +615,33 @@ def test_first_conv_fp16_head(W):
     assert torch.equal(h1, y1.half())
     ref = O.conv2d_same(O.preprocess(img, np.float64), w1, b1, 1, True)
     assert np.abs(y1.cpu().numpy() - ref).max() < 1e-4
+
+
+def test_fp16_activation_descriptor_validation():
+    """kfn_conv2d_nhwc tells the host what it cannot do with fp16 activations (KFN_ERR_ARG = -1) instead of computing
+    something else: fp32 operands, transposed convs, misaligned strides / pointers, head epilogues on fp16 output."""
+    import torch
+    from kfnet_amd import _lib
+    from tests.gpu_util import stream
+    lib = _lib.load()
+    x = torch.zeros(2 * 8 * 8 * 64, dtype=torch.float16, device='cuda')
+    w = torch.zeros(64 * 9 * 64, dtype=torch.float16, device='cuda')
+    y = torch.zeros(2 * 8 * 8 * 64 + 8, dtype=torch.float16, device='cuda')
+    base = dict(N=2, H=8, W=8, Cin=64, ldx=64, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1, relu=1,
+                operand_dtype=_lib.OPERAND_F16, x_dtype=_lib.ACT_F16, y_dtype=_lib.ACT_F16)
+    def call(yoff=0, **kw):
+        d = _lib.ConvDesc(**dict(base, **kw))
+        return lib.kfn_conv2d_nhwc(C.byref(d), x.data_ptr(), w.data_ptr(), None, y.data_ptr() + yoff, stream())
+    assert call() == 0
+    assert call(operand_dtype=_lib.OPERAND_F32) == -1
+    assert call(stride=2, transposed=1) == -1
+    assert call(ldx=68) == -1 and call(ldy=68) == -1 and call(Cout=60, ldy=64) == -1
+    assert call(yoff=2) == -1
+    assert call(epilogue=_lib.EPI_EXP_CH3) == -1
+    assert call(x_dtype=7) == -1 and call(k_step=24) == -1
+    assert call(config=1) == -1            # 160x128 has no fp16-activation instantiation
+    assert b'config' in lib.kfn_last_error()
+    torch.cuda.synchronize()
 
 
 def test_deconv_fp16_operands():

@@ -41,9 +41,9 @@ for (name, lv, ci, co, k, s) in LAYERS:
     y16 = torch.empty(N * Ho * Wo * co, device='cuda', dtype=torch.float16)
     fl = 2.0 * N * Ho * Wo * k * k * ci * co
     res = []
-    def conv(xd, yd, cfg, ks, xt, yt):
+    def conv(xd, yd, cfg, ks, xt, yt, wpath=0):
         d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=k, kw=k, stride=s, relu=1,
-                          config=cfg, operand_dtype=_lib.OPERAND_F16, x_dtype=xt, y_dtype=yt, k_step=ks)
+                          config=cfg, operand_dtype=_lib.OPERAND_F16, x_dtype=xt, y_dtype=yt, k_step=ks, weights_path=wpath)
         return timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d), xd.data_ptr(), w.data_ptr(), None, yd.data_ptr(), st), 'c'))
     t = conv(x32, y32, 0, 0, 0, 0)
     res.append('f32act direct %.3f ms %4.0f TF' % (t, fl / t / 1e9))
@@ -59,5 +59,8 @@ for (name, lv, ci, co, k, s) in LAYERS:
         for ks in ((16, 32) if ci % 64 == 0 else (16,)):
             t = conv(x16, y16, cfg, ks, 1, 1)
             res.append('f16act %s k%d %.3f ms %4.0f TF' % (cn, ks, t, fl / t / 1e9))
+            if ks == 16 and cfg in (2, 9):
+                t = conv(x16, y16, cfg, ks, 1, 1, 2)
+                res.append('  +B via LDS-DMA %.3f ms %4.0f TF' % (t, fl / t / 1e9))
     print('%-6s %3dx%3d C%4d->%4d s%d: ' % (name, H, W, ci, co, s) + ' | '.join(res), flush=True)
     del x32, x16, w, y32, y16
