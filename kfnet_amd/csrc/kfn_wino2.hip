@@ -516,6 +516,9 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
+#ifdef KFN_WINO2_NO_WIDE   // A/B builds only (tools/mb/build_hot.sh): the dword-store epilogue on aligned outputs too
+  a.wide_store = 0;
+#endif
   a.dbg = KFN_WINO2_DBG;   // build-time timing hooks (-DKFN_WINO2_DBG=1: hot A, 2: hot B); 0 in the product build
   a.x_bytes = (unsigned long long)x_bytes;
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);

@@ -13,7 +13,8 @@ import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 for name, n, avg in c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name='FETCH_SIZE' group by kernel_name"):
     if 'wino' in name:
-        print('   FETCH_SIZE*2  %-20s launches %3d  avg %.3f GB' % (name.split('(')[0][-20:], n, avg * 2 * 1024 / 1e9))
+        import re
+        print('   FETCH_SIZE*2  %-22s launches %3d  avg %.3f GB' % (re.search(r'(wino\w*_kernel<?\w*>?)', name).group(1), n, avg * 2 * 1024 / 1e9))
 PY
   done
 done
