@@ -95,12 +95,14 @@ typedef struct kfn_conv_desc {
   int32_t k_step;        /* 0 = auto; 16 / 32 = LDS k-step in 4-byte words (fp16 operands: 32 / 64 channels per
                           * stage).  32 exists for the fp16-activation kernels only. */
   int32_t weights_path;  /* fp16 activations in AND out only: KFN_WEIGHTS_AUTO / _VIA_REGISTERS (global -> registers ->
-                          * ds_write) / _LDS_DMA (global -> LDS directly, `buffer_load ... lds`, three weight buffers) */
+                          * ds_write) / _LDS_DMA (global -> LDS directly, `buffer_load ... lds`, three weight buffers) /
+                          * KFN_OPERANDS_LDS_DMA (the activation tile too) */
 } kfn_conv_desc;
 
 #define KFN_WEIGHTS_AUTO 0
 #define KFN_WEIGHTS_VIA_REGISTERS 1
 #define KFN_WEIGHTS_LDS_DMA 2
+#define KFN_OPERANDS_LDS_DMA 3    /* activations AND weights global -> LDS directly, three buffers each */
 
 #define KFN_ACT_F32 0
 #define KFN_ACT_F16 1

@@ -152,10 +152,18 @@ constexpr int PREC_F16_X = 4, PREC_F16_Y = 5, PREC_F16_XY = 6;
 // transfer for stage s+2 is issued in stage s, behind the LDS stores of A -- loads return in order, so the wait the
 // compiler places in front of the next stage's A stores also covers it, one stage before its barrier.
 constexpr int PREC_F16_XY_BDMA = 7;
+// PREC_F16_XY_DMA: BOTH operand tiles global -> LDS directly, three buffers each: no staging registers, no ds_write at
+// all.  Nothing in registers orders the transfers any more, so the schedule is explicit: the transfers for stage s+2
+// are issued right AFTER the barrier of stage s (their buffers were last read before the barrier of stage s-1), every
+// wave waits `vmcnt(0)` right BEFORE the barrier of stage s+1 -- a full stage later -- and the first fragment reads of
+// stage s+2 follow that barrier.  Activation rows outside the image carry an out-of-range offset: the transfer writes
+// zeros for them (checked on hardware, tools/mb/dma_probe.hip), the same free SAME padding as on the register path.
+constexpr int PREC_F16_XY_DMA = 8;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  constexpr bool BDMA = (PREC == PREC_F16_XY_BDMA);
+  constexpr bool ADMA = (PREC == PREC_F16_XY_DMA);                      // activations through LDS-DMA too
+  constexpr bool BDMA = (PREC == PREC_F16_XY_BDMA) || ADMA;
   constexpr bool X16 = (PREC == PREC_F16_X || PREC == PREC_F16_XY || BDMA);   // activations read as halfs
   constexpr bool Y16 = (PREC == PREC_F16_Y || PREC == PREC_F16_XY || BDMA);   // activations written as halfs
   static_assert(!BDMA || BK == 16, "LDS-DMA weights: k-step 16");
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][BK] swizzled
-  float* Bs = smem + 2 * A_ELEMS;   // [2][BN][BK] swizzled ([3] with LDS-DMA weights)
+  float* Bs = smem + (ADMA ? 3 : 2) * A_ELEMS;   // [2][BN][BK] swizzled ([3] with LDS-DMA; then A has three buffers as well)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -363,7 +371,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
       } else {
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + q * QCH) * XB + a_shift;
+        // (LDS-DMA: slot q of row r receives logical quad q ^ sw(r) -- the swizzle is applied at the source)
+        a_off[i] = (unsigned)(((n_img * p.H + iy0) * p.W + ix0) * p.ldx + (ADMA ? ((q ^ swz<BK>(r)) & (QPR - 1)) : q) * QCH) * XB + a_shift;
         // valid taps = [ky_lo, ky_hi) x [kx_lo, kx_hi)
         const int ky_lo = iy0 < 0 ? -iy0 : 0, ky_hi = (p.H - iy0 < p.kh) ? p.H - iy0 : p.kh;
         const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = (p.W - ix0 < p.kw) ? p.W - ix0 : p.kw;
@@ -608,14 +617,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       (void)bbuf;
       fr[slot][k] = *reinterpret_cast<const f32x4*>(base + row * BK + ((kq16 ^ swz<BK>(row)) * 4));
     } else if (kk < TM)
-      fr[slot][k] = *reinterpret_cast<const f32x4*>(As + buf * A_ELEMS + part * A_PART + a_rd + kk * 32 * BK + rdq[c]);
+      fr[slot][k] = *reinterpret_cast<const f32x4*>(As + (ADMA ? bbuf : buf) * A_ELEMS + part * A_PART + a_rd + kk * 32 * BK + rdq[c]);
     else
       fr[slot][k] = *reinterpret_cast<const f32x4*>(Bs + (BDMA ? bbuf : buf) * B_ELEMS + part * B_PART + b_rd + (kk - TM) * 32 * BK + rdq[c]);
   };
 
-  constexpr int NLD = AP * NSRC + (BDMA ? 0 : BP * NPART);  // global loads per stage (into registers)
-  constexpr int NST = AP + (BDMA ? 0 : BP * NPART);         // LDS store ops per stage (an f16x3 A op writes hi and lo)
+  constexpr int NLD = (ADMA ? 0 : AP * NSRC) + (BDMA ? 0 : BP * NPART);  // global loads per stage (into registers)
+  constexpr int NST = (ADMA ? 0 : AP) + (BDMA ? 0 : BP * NPART);         // LDS store ops per stage (an f16x3 A op writes hi and lo)
   constexpr int NDMA = BDMA ? BP : 0;                       // weight-tile transfers global -> LDS per stage
+  constexpr int NADMA = ADMA ? AP : 0;                      // activation-tile transfers
   // BDMA: transfer i of this wave covers rows 64 i + 16 wave .. +15 of the B tile, lane L -> byte L*16 of that 1 KiB run
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Bs + (unsigned)(wave * 16 * BK * 4));
@@ -626,6 +636,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)dst, 16, b_off[i], bdelta >> 1, 0, 0);
 #else
     (void)rs; (void)dst;
+#endif
+  };
+  const unsigned lds_a0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)As + (unsigned)(wave * 16 * BK * 4));
+  auto dma_a_one = [&](int i, unsigned adelta, int abuf) {
+    const unsigned dst = lds_a0 + (unsigned)(abuf * A_ELEMS * 4) + (unsigned)(i * RPP * BK * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(uintptr_t)dst, 16, a_ok[i] ? a_off[i] : OOB, adelta, 0, 0);
+#else
+    (void)dst; (void)adelta;
 #endif
   };
   constexpr int NFR = (TM + TN) * NPART;       // fragment reads per chunk
@@ -643,6 +662,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       for (int k = 0; k < NLD; ++k) load_one(k, true, adelta, bdelta, ky, kx, ld_tap);
 #pragma unroll
       for (int i = 0; i < NDMA; ++i) dma_one(i, true, bdelta, 0);
+#pragma unroll
+      for (int i = 0; i < NADMA; ++i) dma_a_one(i, adelta, 0);
       advance();
 #pragma unroll
       for (int k = 0; k < NST; ++k) store_one(k, 0);
@@ -658,6 +679,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       for (int k = 0; k < NLD; ++k) load_one(k, live, adelta, bdelta, ky, kx, tp);
 #pragma unroll
       for (int i = 0; i < NDMA; ++i) dma_one(i, live, bdelta, 1);
+#pragma unroll
+      for (int i = 0; i < NADMA; ++i) dma_a_one(i, adelta, 1);
       advance();
     }
     if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both weight tiles have landed
@@ -692,7 +715,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // side ops of this chunk, in issue order
         constexpr int n_rd = last ? 0 : NFR;
         constexpr int n_st = (c == 0) ? NST : 0;
-        constexpr int n_dma = (c == 0) ? NDMA : 0;     // behind the A stores of the same chunk (see PREC_F16_XY_BDMA)
+        constexpr int n_dma = (c == 0 && !ADMA) ? NDMA : 0;     // behind the A stores of the same chunk (see PREC_F16_XY_BDMA)
         constexpr int n_ld = (c == LOADC) ? NLD : 0;
         constexpr int n_side = n_rd + n_st + n_dma + n_ld;
         constexpr int jspan = last ? (J / 2 > 0 ? J / 2 : 1) : J;  // in the last chunk side ops ride the first half
@@ -700,10 +723,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           constexpr int j = decltype(jc)::value;
           constexpr int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
           if constexpr (last && j == J / 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers for stage s+1 have landed
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             static_for<NFR>([&](auto kc) { read_one(decltype(kc)::value, slot ^ 1, buf ^ 1, 0, bcur == 2 ? 0 : bcur + 1); });
+            if constexpr (ADMA) {
+              // stage s+2 -> the buffers stage s-1 used (every read of them came before the PREVIOUS barrier)
+              static_for<NDMA>([&](auto kc) { dma_one(decltype(kc)::value, live, bdelta, bcur == 0 ? 2 : bcur - 1); });
+              static_for<NADMA>([&](auto kc) { dma_a_one(decltype(kc)::value, adelta, bcur == 0 ? 2 : bcur - 1); });
+            }
           }
           if constexpr (F16) {
             // t = term: f16x3 adds the two cross terms first, the hi*hi term last
@@ -932,8 +961,8 @@ const TileCfg* find_cfg(int cfg) {
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int F16 = PREC_F32>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = (F16 == PREC_F32_N16 ? 16 : 32) * TN * WN, NT = 64 * WM * WN;
-  constexpr size_t smem_ops = (size_t)(2 * BM + (F16 == PREC_F16_XY_BDMA ? 3 : 2) * BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
-  constexpr size_t smem_epi = (F16 == PREC_F16_Y || F16 == PREC_F16_XY || F16 == PREC_F16_XY_BDMA) ? (size_t)BM * BN * 2 : 0;   // fp16 output tile
+  constexpr size_t smem_ops = (size_t)((F16 == PREC_F16_XY_DMA ? 3 : 2) * BM + ((F16 == PREC_F16_XY_BDMA || F16 == PREC_F16_XY_DMA) ? 3 : 2) * BN) * BK * sizeof(float) * (F16 == PREC_F16X3 ? 2 : 1);
+  constexpr size_t smem_epi = (F16 == PREC_F16_Y || F16 == PREC_F16_XY || F16 == PREC_F16_XY_BDMA || F16 == PREC_F16_XY_DMA) ? (size_t)BM * BN * 2 : 0;   // fp16 output tile
   constexpr size_t smem = smem_ops > smem_epi ? smem_ops : smem_epi;
   ConvArgs a = a0;
   a.tiles_m = kfn::ceil_div(a.M, BM);
@@ -1187,12 +1216,20 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
     // fp16 activations end to end (BASELINE config 5): wide tiles, k-step 32 (64 channels per stage) when Cin allows
     if (y16) {
       const int c16 = f16io_config(d, a.M);
-      KFN_REQUIRE(d->weights_path >= KFN_WEIGHTS_AUTO && d->weights_path <= KFN_WEIGHTS_LDS_DMA,
+      KFN_REQUIRE(d->weights_path >= KFN_WEIGHTS_AUTO && d->weights_path <= KFN_OPERANDS_LDS_DMA,
                   "kfn_conv2d_nhwc: unknown weights_path %d", d->weights_path);
       // weights global -> LDS directly: +6-8 % on the 128x256 tile (966-1026 -> 1032-1089 TFLOP/s, profiles/
       // r03_c5_layer_microbench.log), neutral on 128x128; AUTO takes it where it pays
       const bool dma = d->weights_path == KFN_WEIGHTS_LDS_DMA ||
                        (d->weights_path == KFN_WEIGHTS_AUTO && c16 == KFN_CFG_128x256);
+      if (x16 && f16io_bk(d) == 16 && d->weights_path == KFN_OPERANDS_LDS_DMA) {
+        switch (c16) {
+          case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
+        }
+      }
       if (x16 && f16io_bk(d) == 16 && dma) {
         switch (c16) {
           case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);

@@ -544,10 +544,11 @@ def test_conv_fp16_activations(case, config, k_step):
 
 @pytest.mark.parametrize('case', F16_ACT_CASES + [(2, 30, 40, 512, 512, 3, 1), (1, 17, 23, 256, 320, 3, 2),
                                                   (2, 68, 120, 1024, 512, 3, 1)])
-@pytest.mark.parametrize('config', [2, 9])
-def test_conv_fp16_activations_weights_via_lds_dma(case, config):
-    """weights_path = KFN_WEIGHTS_LDS_DMA (the weight tile goes global -> LDS directly, swizzle applied at the source,
-    three weight buffers): BIT-identical to the register-staged path -- same operands, same MFMA order -- on shapes
+@pytest.mark.parametrize('config,path', [(2, 2), (9, 2), (2, 3), (9, 3), (12, 3)])
+def test_conv_fp16_activations_weights_via_lds_dma(case, config, path):
+    """weights_path = KFN_WEIGHTS_LDS_DMA (2: the weight tile goes global -> LDS directly, swizzle applied at the source,
+    three weight buffers) and KFN_OPERANDS_LDS_DMA (3: the activation tile too, zero padding = out-of-range lanes
+    writing zeros, explicit vmcnt(0) in front of every barrier): BIT-identical to the register-staged path -- same operands, same MFMA order -- on shapes
     with 1 to 144 K stages, partial row / column tiles and Cout below the tile width; run twice (a race between a
     transfer and the fragment reads or the epilogue overlay would not be deterministic)."""
     from tests.gpu_util import run_conv
@@ -560,7 +561,7 @@ def test_conv_fp16_activations_weights_via_lds_dma(case, config):
     b = rng.normal(size=co).astype(np.float32)
     ref = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=16, weights_path=1)
     for _ in range(3):
-        y = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=16, weights_path=2)
+        y = run_conv(x, wt, b, s, True, config=config, f16=True, x16=True, y16=True, k_step=16, weights_path=path)
         assert np.array_equal(y, ref)
 
 

@@ -57,10 +57,13 @@ for (name, lv, ci, co, k, s) in LAYERS:
     cfgs = [(2, '128x128'), (9, '128x256')] if co >= 128 else [(7, '192x64'), (3, '128x64'), (12, '256x64')]
     for cfg, cn in cfgs:
         for ks in ((16, 32) if ci % 64 == 0 else (16,)):
-            t = conv(x16, y16, cfg, ks, 1, 1)
+            t = conv(x16, y16, cfg, ks, 1, 1, 1)
             res.append('f16act %s k%d %.3f ms %4.0f TF' % (cn, ks, t, fl / t / 1e9))
-            if ks == 16 and cfg in (2, 9):
-                t = conv(x16, y16, cfg, ks, 1, 1, 2)
-                res.append('  +B via LDS-DMA %.3f ms %4.0f TF' % (t, fl / t / 1e9))
+            if ks == 16 and cfg in (2, 9, 12):
+                if cfg != 12:
+                    t = conv(x16, y16, cfg, ks, 1, 1, 2)
+                    res.append('  +B via LDS-DMA %.3f ms %4.0f TF' % (t, fl / t / 1e9))
+                t = conv(x16, y16, cfg, ks, 1, 1, 3)
+                res.append('  +A,B via LDS-DMA %.3f ms %4.0f TF' % (t, fl / t / 1e9))
     print('%-6s %3dx%3d C%4d->%4d s%d: ' % (name, H, W, ci, co, s) + ' | '.join(res), flush=True)
     del x32, x16, w, y32, y16
