@@ -133,8 +133,8 @@ def per_kernel_profile(eng, dev_frames):
 def pipeline_io_bytes(eng):
     """Algorithmic HBM bytes of one batch if every launch reads its input tensor(s) and weights
     once and writes its output once (layer-by-layer execution, fp32 activations)."""
-    from kfnet_amd.graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, FirstConvOp, FlowHeadOp, PadOp,
-                                 WinogradConvOp)
+    from kfnet_amd.graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, FirstConvOp, FlowHeadOp, OFlowHeadOp,
+                                 OFlowTail2Op, PadOp, WinogradConvOp)
     def tb(t):
         n, h, w, c = t.shape
         return n * h * w * c * {'f32': 4, 'f16': 2, 'u8': 1}[t.dtype]
@@ -154,6 +154,10 @@ def pipeline_io_bytes(eng):
                 total += 2 * op.workspace_bytes()   # the [16][tiles][Cout] workspace is written and re-read
         elif isinstance(op, FlowHeadOp):
             total += tb(op.x) + tb(op.flow)
+        elif isinstance(op, OFlowHeadOp):      # conv0 from the factored maps + conv1a: maps in, conv1a's output out
+            total += tb(op.t) + tb(op.gp) + tb(op.y)
+        elif isinstance(op, OFlowTail2Op):     # maps + conv5's patch in, flow out
+            total += tb(op.t) + tb(op.gp) + tb(op.x5) + tb(op.flow)
     return total
 
 
