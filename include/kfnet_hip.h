@@ -348,6 +348,10 @@ int kfn_eval_metrics(const float* meas, const float* temp, const float* kf_raw, 
 int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis, long P,
                     void* stream);
 
+/* KFNet.GetKFCoord2 (KFNet/KFNet.py:487-502; not on eval.py's path): the same fusion with the posterior variance in
+ * the symmetric form (1-K)^2 P^- + K^2 R.  pred / meas / out packed [P,4] = (x, y, z, sigma) as for kfn_kalman_fuse. */
+int kfn_kalman_fuse2(const float* pred, const float* meas, float* out, long P, void* stream);
+
 /* ---- Network.concat fallback (cnn_wrapper/network.py:316-318): strided channel copy -- */
 int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int P, int C,
                       void* stream);

@@ -228,6 +228,29 @@ class KFNet():
         self.graph.add(KalmanFuseOp(pred, meas, out))
         return out.channels(0, 3), out.channels(3, 1)
 
+    def GetTemporalCoord2(self, coord_map1=None, uncertainty1=None):
+        """KFNet/KFNet.py:476-485: the process-model prediction (x^-, sigma^-) of every frame of the batch.  Here it
+        is an output of the scan kernel: build GetKFCoordRecursive(..., emit_temp=True) first (its last_coord /
+        last_uncertainty ARE coord_map1 / uncertainty1); returns channel views of the [B,h,w,4] prediction buffer."""
+        if getattr(self, 'temp', None) is None:
+            raise ValueError('build GetKFCoordRecursive(..., emit_temp=True) first')
+        return self.temp.channels(0, 3), self.temp.channels(3, 1)
+
+    def GetKFCoord2(self, KF_coord_map1=None, KF_uncertainty1=None):
+        """KFNet/KFNet.py:487-502: the fusion with the symmetric-form posterior variance (1-K)^2 P^- + K^2 R, as a
+        stand-alone launch (kfn_kalman_fuse2) on the prediction and measurement buffers of the batch.  Like the
+        reference's it is not part of the recursive eval path (which uses BuildKFCoord); for a batch of one frame --
+        the reference's case, one step per sess.run -- it is exactly GetKFCoord2 of the state fed to
+        GetKFCoordRecursive."""
+        from ..graph import KalmanFuseOp
+        temp_coord, temp_unc = self.GetTemporalCoord2()
+        meas = self.GetMeasureCoord2()[0].base
+        out = self.graph.tensor(self.temp.shape, name='KF2')
+        op = KalmanFuseOp(self.temp, meas, out, symmetric_variance=True)
+        self.graph.add(op)
+        self.scan_ops.append(op)
+        return out.channels(0, 3), out.channels(3, 1)
+
     def GetNIS(self, measure_coord_map, measure_uncertainty_map, temp_coord_map, temp_uncertainty_map):
         """KFNet/KFNet.py:164-184; produced by the scan kernel when emit_nis is set."""
         if getattr(self, 'nis', None) is None:

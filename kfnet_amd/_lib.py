@@ -82,6 +82,7 @@ SYMBOLS = {
     'kfn_kalman_scan_ex': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_eval_metrics': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp]),
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
+    'kfn_kalman_fuse2': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'kfn_comm_unique_id': (_i, [_vp, _sz]),
     'kfn_comm_init': (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),

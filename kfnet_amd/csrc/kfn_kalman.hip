@@ -271,6 +271,28 @@ __global__ __launch_bounds__(256) void kalman_fuse_kernel(const f32x4* __restric
   }
 }
 
+// KFNet.GetKFCoord2 (KFNet/KFNet.py:487-502): the same gain, but the posterior variance in the symmetric
+// ("Joseph") form  (1-K)^2 P^- + K^2 R  instead of BuildKFCoord's  max(1-K,0) P^-.  Not on eval.py's path (the
+// recursive graph uses BuildKFCoord); kept for the reference's API.  Operation order as in the reference.
+__global__ __launch_bounds__(256) void kalman_fuse2_kernel(const f32x4* __restrict__ pred,
+                                                           const f32x4* __restrict__ meas,
+                                                           f32x4* __restrict__ out, long P) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const f32x4 l = pred[p], z = meas[p];
+    const float mv = z.w * z.w;              // measure_variance2
+    const float tv = l.w * l.w;              // variance_12 = temp_variance2
+    const float K = tv / (tv + mv);
+    const float om = fmaxf(1.0f - K, 0.0f);
+    const float omr = 1.0f - K;
+    f32x4 kf;
+    kf.x = om * l.x + K * z.x;
+    kf.y = om * l.y + K * z.y;
+    kf.z = om * l.z + K * z.z;
+    kf.w = sqrtf((omr * omr) * tv + (K * K) * mv);
+    out[p] = kf;
+  }
+}
+
 template <int KT, int PPT, bool DBL, bool PREFETCH>
 int launch_scan(const KalmanArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
@@ -357,5 +379,18 @@ extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out,
                      reinterpret_cast<const f32x4*>(pred), reinterpret_cast<const f32x4*>(meas),
                      reinterpret_cast<f32x4*>(out), opt_nis, P);
   KFN_LAUNCH_CHECK("kalman_fuse_kernel");
+  return KFN_OK;
+}
+
+extern "C" int kfn_kalman_fuse2(const float* pred, const float* meas, float* out, long P, void* stream) {
+  KFN_REQUIRE(pred && meas && out && P > 0, "kfn_kalman_fuse2: bad argument");
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(meas) |
+                reinterpret_cast<uintptr_t>(out)) & 15) == 0, "kfn_kalman_fuse2: misaligned buffer");
+  long blocks = (P + 255) / 256;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  hipLaunchKernelGGL(kalman_fuse2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(pred), reinterpret_cast<const f32x4*>(meas),
+                     reinterpret_cast<f32x4*>(out), P);
+  KFN_LAUNCH_CHECK("kalman_fuse2_kernel");
   return KFN_OK;
 }

@@ -938,13 +938,19 @@ class KalmanScanOp(Op):
 class KalmanFuseOp(Op):
     """Stand-alone KFNet.BuildKFCoord (+ optional NIS) on packed [.,.,.,4] tensors."""
 
-    def __init__(self, pred, meas, out, nis=None):
-        self.name = 'kalman_fuse'
+    def __init__(self, pred, meas, out, nis=None, symmetric_variance=False):
+        self.name = 'kalman_fuse2' if symmetric_variance else 'kalman_fuse'
         self.pred, self.meas, self.out, self.nis = pred, meas, out, nis
+        self.symmetric_variance = symmetric_variance     # KFNet.GetKFCoord2's posterior (KFNet/KFNet.py:487-502)
 
     def launch(self, lib, stream):
         for t in (self.pred, self.meas, self.out):
             assert t.ld == 4 and t.C == 4
+        if self.symmetric_variance:
+            assert self.nis is None
+            _lib.check(lib.kfn_kalman_fuse2(self.pred.ptr, self.meas.ptr, self.out.ptr, self.out.pixels, stream),
+                       'kfn_kalman_fuse2')
+            return
         rc = lib.kfn_kalman_fuse(self.pred.ptr, self.meas.ptr, self.out.ptr,
                                  self.nis.ptr if self.nis is not None else None, self.out.pixels, stream)
         _lib.check(rc, 'kfn_kalman_fuse')

@@ -300,6 +300,18 @@ def build_kf_coord(last_coord, last_unc, measure_coord, measure_unc):
     return kf_coord, np.sqrt(kf_var)
 
 
+def get_kf_coord2(temp_coord, temp_unc, measure_coord, measure_unc):
+    """KFNet.GetKFCoord2's fusion step (KFNet/KFNet.py:487-502): the symmetric-form posterior variance
+    (1-K)^2 P^- + K^2 R; the mean as in BuildKFCoord."""
+    dt = temp_coord.dtype
+    meas_var = measure_unc * measure_unc
+    temp_var = temp_unc * temp_unc
+    K = temp_var / (temp_var + meas_var)
+    kf_coord = np.maximum(dt.type(1.0) - K, 0) * temp_coord + K * measure_coord
+    kf_var = (dt.type(1.0) - K) * (dt.type(1.0) - K) * temp_var + (K * K) * meas_var
+    return kf_coord, np.sqrt(kf_var)
+
+
 def get_nis(measure_coord, measure_unc, temp_coord, temp_unc):
     """KFNet.GetNIS (KFNet/KFNet.py:164-184).  Note inno_variance = square(sqrt(.))."""
     inno = measure_coord - temp_coord

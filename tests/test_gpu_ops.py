@@ -273,6 +273,33 @@ def test_kalman_scan_vs_oracle(cfg):
         assert np.allclose(nis.cpu().numpy().reshape(r_nis.shape), r_nis, rtol=1e-4, atol=1e-6)
 
 
+def test_kalman_fuse2_symmetric_variance():
+    """kfn_kalman_fuse2 = KFNet.GetKFCoord2's fusion (KFNet/KFNet.py:487-502): bit exact vs the fp32 numpy oracle;
+    KAT: equal noise -> K = 1/2, mean of the two, sigma / sqrt(2); its sigma equals BuildKFCoord's up to round-off."""
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(18)
+    P = 4099
+    pred = rng.normal(size=(P, 4)).astype(np.float32); pred[:, 3] = np.abs(pred[:, 3]) + 0.01
+    meas = rng.normal(size=(P, 4)).astype(np.float32); meas[:, 3] = np.abs(meas[:, 3]) + 0.01
+    meas[0, 3] = pred[0, 3]
+    out = torch.zeros(P * 4, device='cuda'); out1 = torch.zeros(P * 4, device='cuda')
+    dp, dm = dev(pred), dev(meas)
+    _lib.check(lib.kfn_kalman_fuse2(dp.data_ptr(), dm.data_ptr(), out.data_ptr(), P, stream()), 'fuse2')
+    _lib.check(lib.kfn_kalman_fuse(dp.data_ptr(), dm.data_ptr(), out1.data_ptr(), None, P, stream()), 'fuse')
+    sync()
+    o, o1 = out.cpu().numpy().reshape(P, 4), out1.cpu().numpy().reshape(P, 4)
+    kx, ks = O.get_kf_coord2(pred[:, 0:3], pred[:, 3:4], meas[:, 0:3], meas[:, 3:4])
+    assert np.array_equal(o[:, 0:3], kx) and np.array_equal(o[:, 3:4], ks)
+    assert np.array_equal(o[:, 0:3], o1[:, 0:3])                      # same mean as BuildKFCoord
+    assert np.isclose(o[0, 3], pred[0, 3] / np.sqrt(2), rtol=1e-6)
+    ok = meas[:, 3] > 0.1 * pred[:, 3]            # (1-K)^2 P + K^2 R == (1-K) P in exact arithmetic; BuildKFCoord's form
+    assert np.allclose(o[ok, 3], o1[ok, 3], rtol=1e-4)   # cancels when sigma_z << sigma^-, so compare where 1-K is not tiny
+    assert lib.kfn_kalman_fuse2(dp.data_ptr() + 4, dm.data_ptr(), out.data_ptr(), P, stream()) == -1
+
+
 def test_kalman_fuse_kat():
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib

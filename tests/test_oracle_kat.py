@@ -276,3 +276,18 @@ def test_window_fc_matrix_identity():
     m = pack_window_fc_kernel(wt)[:4 * co].astype(np.float64)            # [(q,o)][(p,c)]
     got = x.reshape(P, 4 * ci) @ m.T + pack_bias_x4(b)[:4 * co]
     assert np.abs(got.reshape(P, 2, 2, co) - ref).max() < 1e-5
+
+
+def test_get_kf_coord2_symmetric_posterior():
+    """KFNet.GetKFCoord2 (KFNet/KFNet.py:487-502): in exact arithmetic (1-K)^2 P + K^2 R == (1-K) P == P R / (P + R);
+    the restatement must agree with that closed form and with build_kf_coord's mean."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1, 5, 7, 3)); z = rng.normal(size=(1, 5, 7, 3))
+    s = np.abs(rng.normal(size=(1, 5, 7, 1))) + 0.1; sz = np.abs(rng.normal(size=(1, 5, 7, 1))) + 0.1
+    c2, u2 = O.get_kf_coord2(x, s, z, sz)
+    c1, u1 = O.build_kf_coord(x, s, z, sz)
+    assert np.allclose(c2, c1, rtol=0, atol=0)
+    assert np.allclose(u2 ** 2, (s ** 2) * (sz ** 2) / (s ** 2 + sz ** 2), rtol=1e-12)
+    assert np.allclose(u2, u1, rtol=1e-12)
+    half = O.get_kf_coord2(x, s, z, s)
+    assert np.allclose(half[0], (x + z) / 2) and np.allclose(half[1], s / np.sqrt(2))
