@@ -95,14 +95,19 @@ __global__ __launch_bounds__(256) void first_conv_kernel(
 // VALU are both at ~17 cycles per pixel and CU, and the layer runs at 3.5 TB/s although it only has to stream its
 // output.  Here a wave owns one 64-pixel row of the 64x4 tile: a lane reads its 27 inputs ONCE (27 conflict-free
 // ds_read_b32 per 64 pixels), the weights are wave-uniform and come from scalar registers, 80 accumulators per lane;
-// the results are transposed through a per-wave LDS staging buffer (36 dwords per pixel: conflict-free
-// ds_write_b128) so that they leave as 16-byte stores in which 8 (fp32 half of 32 channels, or all 64 fp16
-// channels) or 4 (16-channel head) neighbouring lanes cover one pixel's contiguous run.  The halo is filled with
+// the results are transposed through a per-wave LDS staging buffer so that they leave as 16-byte non-temporal
+// stores in which 8 (fp32 half of 32 channels, or all 64 fp16 channels) or 4 (16-channel head) neighbouring lanes
+// cover one pixel's contiguous 128- or 64-byte run.  The buffer holds 32 pixels x 32 dwords (the lanes of one
+// wave half stage, all 64 lanes store) or 64 pixels x 16 dwords: 5 KiB per wave, 25 KiB per workgroup, so six
+// workgroups (24 waves, the 80-VGPR limit) share a CU -- with a 64 x 32-dword buffer there were three, and the
+// store queue drained between their epilogues.  The halo is filled with
 // aligned dword loads of the uint8 rows (4 values per load; the byte-wise form remains for images whose rows are
 // not a multiple of 4 bytes).
 // ------------------------------------------------------------------------------------
-constexpr int PX_SP = 36;                       // dwords per pixel of the staging buffer
-constexpr int PX_STAGE = 64 * PX_SP;            // per wave
+constexpr int PX_SP = 36;                       // staging stride (dwords) of a 32-dword pixel: conflict-free ds_write_b128
+constexpr int PX_SP16 = 20;                     // ... of a 16-dword pixel
+constexpr int PX_STAGE = 64 * PX_SP16;          // per wave: 32 pixels x 32 dwords or 64 pixels x 16 dwords (5 KiB)
+static_assert(PX_STAGE >= 32 * PX_SP, "both pass shapes fit");
 constexpr int PX_LDS_BYTES = ((FT_H + 2) * FT_TW3 + 4 * PX_STAGE) * 4;
 
 __device__ __constant__ float kZeroBias[64] = {0.f};
@@ -132,25 +137,49 @@ __device__ __forceinline__ void px_accumulate(const float* tile_row, const float
 
 // 32 fp32 channels (NQ = 8 quads per pixel) or 16 (NQ = 4) of this wave's 64 pixels: LDS transpose, then
 // 64/NQ pixels per store instruction.  `cstride` = channels per pixel in memory, `c0` = first channel.
+template <class V>
+__device__ __forceinline__ void px_st(V* p, const V& v) {
+  __builtin_nontemporal_store(v, p);          // written once, read by the next layer after 3 GB of other stores
+}
+
 template <int NQ>
 __device__ __forceinline__ void px_store_f32(float* stage, const float* vals, float* __restrict__ y, size_t row_elem0,
                                              int cstride, int c0, int lane, int valid_px) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
-    *reinterpret_cast<f32x4*>(stage + lane * PX_SP + q * 4) = f32x4{vals[q * 4], vals[q * 4 + 1], vals[q * 4 + 2], vals[q * 4 + 3]};
+    *reinterpret_cast<f32x4*>(stage + lane * PX_SP16 + q * 4) = f32x4{vals[q * 4], vals[q * 4 + 1], vals[q * 4 + 2], vals[q * 4 + 3]};
   __builtin_amdgcn_wave_barrier();
+  static_assert(NQ * 4 <= 16, "a pass stages at most 16 dwords per pixel");
   constexpr int PPI = 64 / NQ;                  // pixels per store instruction
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int px = i * PPI + lane / NQ, q = lane % NQ;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * PX_SP + q * 4);
-    if (px < valid_px) *reinterpret_cast<f32x4*>(y + row_elem0 + (size_t)px * cstride + c0 + q * 4) = v;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + px * PX_SP16 + q * 4);
+    if (px < valid_px) px_st(reinterpret_cast<f32x4*>(y + row_elem0 + (size_t)px * cstride + c0 + q * 4), v);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// 32 channels of 32 pixels (half `ph` of the wave): the half's lanes stage, all 64 lanes store 128-byte runs
+__device__ __forceinline__ void px_store_half(float* stage, const float* vals, float* __restrict__ y, size_t row_elem0,
+                                              int cstride, int c0, int lane, int valid_px, int ph) {
+  if ((lane >> 5) == ph) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      *reinterpret_cast<f32x4*>(stage + (lane & 31) * PX_SP + q * 4) = f32x4{vals[q * 4], vals[q * 4 + 1], vals[q * 4 + 2], vals[q * 4 + 3]};
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = i * 8 + lane / 8, q = lane % 8, px = ph * 32 + pl;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + pl * PX_SP + q * 4);
+    if (px < valid_px) px_st(reinterpret_cast<f32x4*>(y + row_elem0 + (size_t)px * cstride + c0 + q * 4), v);
   }
   __builtin_amdgcn_wave_barrier();
 }
 
 template <int C2, bool OUT16_1>
-__global__ __launch_bounds__(256) void first_conv_px_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void first_conv_px_kernel(
     const uint8_t* __restrict__ img, int N, int H, int W, unsigned img_bytes,
     const float* __restrict__ w1, const float* __restrict__ b1, void* __restrict__ y1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y2) {
@@ -195,31 +224,38 @@ __global__ __launch_bounds__(256) void first_conv_px_kernel(
 #pragma unroll
     for (int c = 0; c < C1; ++c) acc[c] = fmaxf(acc[c], 0.f);
     if constexpr (OUT16_1) {
-      // 64 halfs = 32 dwords per pixel: one pass, 8 lanes per pixel
+      // 64 halfs = 32 dwords per pixel, in two passes of 32 channels (16 dwords): 4 lanes per pixel and pass
       typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        u32x4s pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f16x2 h = {(_Float16)acc[q * 8 + 2 * e], (_Float16)acc[q * 8 + 2 * e + 1]};
-          pk[e] = __builtin_bit_cast(unsigned, h);
-        }
-        *reinterpret_cast<u32x4s*>(stage + lane * PX_SP + q * 4) = pk;
-      }
-      __builtin_amdgcn_wave_barrier();
       _Float16* yh = static_cast<_Float16*>(y1);
+      // a pixel's 64 halfs are one 128-byte run: the lanes of half `ph` stage their pixels, all 64 lanes store
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int px = i * 8 + lane / 8, q = lane % 8;
-        const u32x4s v = *reinterpret_cast<const u32x4s*>(stage + px * PX_SP + q * 4);
-        if (px < valid_px) *reinterpret_cast<u32x4s*>(yh + (pix0 + px) * C1 + q * 8) = v;
+      for (int ph = 0; ph < 2; ++ph) {
+        if ((lane >> 5) == ph) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            u32x4s pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f16x2 h = {(_Float16)acc[q * 8 + 2 * e], (_Float16)acc[q * 8 + 2 * e + 1]};
+              pk[e] = __builtin_bit_cast(unsigned, h);
+            }
+            *reinterpret_cast<u32x4s*>(stage + (lane & 31) * PX_SP + q * 4) = pk;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int pl = i * 8 + lane / 8, q = lane % 8, px = ph * 32 + pl;
+          const u32x4s v = *reinterpret_cast<const u32x4s*>(stage + pl * PX_SP + q * 4);
+          if (px < valid_px) px_st(reinterpret_cast<u32x4s*>(yh + (pix0 + px) * C1 + q * 8), v);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     } else {
       float* yf = static_cast<float*>(y1);
-      px_store_f32<8>(stage, acc, yf, pix0 * C1, C1, 0, lane, valid_px);
-      px_store_f32<8>(stage, acc + 32, yf, pix0 * C1, C1, 32, lane, valid_px);
+      // four passes (pixel half x channel half) through a 5 KiB staging buffer: six workgroups per CU stay resident
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) px_store_half(stage, acc + 32 * (cp & 1), yf, pix0 * C1, C1, 32 * (cp & 1), lane, valid_px, cp >> 1);
     }
   }
   if constexpr (C2 > 0) {
