@@ -116,7 +116,7 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_ORDER_M_FAST 1
 #define KFN_WINO_ORDER_N_FAST 2
 #define KFN_WINO_FORM_AUTO 0
-#define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel would run */
+#define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel / wino3_pair_kernel would run */
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1
@@ -176,7 +176,8 @@ int kfn_conv2d_winograd(const kfn_conv_desc* desc, const float* x, const float* 
  * Needs Cin % 16 == 0, (H+1)/2 >= 4, cout_pad % 32 == 0, no fused head epilogue
  * (kfn_winograd_fused_supported() == 1); KFN_ERR_UNSUPPORTED otherwise.  Layers with Cout >= 128 and
  * Cin % 32 == 0 run in the four-wave form (csrc/kfn_wino3.hip: one input transform per 128 output channels,
- * shared through LDS).  operand_dtype KFN_OPERAND_F16 (BASELINE config 5; four-wave form only, Cin % 64 == 0): u2_packed holds
+ * shared through LDS); layers with 33 .. 64 output channels and Cin % 16 == 0 in its two-wave form (one transform
+ * and one read of the input for all their channels; two images of the input below 1 GiB).  operand_dtype KFN_OPERAND_F16 (BASELINE config 5; four-wave form only, Cin % 64 == 0): u2_packed holds
  * IEEE halfs in the same layout, the input transform runs in fp32 on the fp32 activations and is rounded to fp16
  * when it is shared, the products are fp16 MFMAs with fp32 accumulation. */
 int kfn_winograd_fused_supported(const kfn_conv_desc* desc);

@@ -493,6 +493,11 @@ extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x,
     if ((form != 2 || h16) && d->Cout >= 128 && d->Cin % 32 == 0 && 2 * img_b < (1L << 31) &&
         2L * d->H * d->W * d->ldy * 4L < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31))
       return kfn::launch_wino3(d, x, u2_packed, bias, y, (hipStream_t)stream);
+    // 33 .. 64 output channels (conv1b): the two-wave form of the same kernel -- one transform and one read of the
+    // input for all 64 channels, two workgroups per CU
+    if (form != 2 && !h16 && d->cout_pad == 64 && d->Cin % 16 == 0 && 2 * img_b < (1L << 30) &&
+        2L * d->H * d->W * d->ldy * 4L < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31))
+      return kfn::launch_wino3(d, x, u2_packed, bias, y, (hipStream_t)stream);
     if (h16) return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_fused: image or kernel beyond 2 GiB of 32-bit offsets");
   }
   Wino2Args a;

@@ -36,8 +36,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned OOBV = 0x80000000u;
 constexpr int BW = 8, BH = 4;           // tile block: 8 (x) by 4 (y) tiles = 32 MFMA rows
-constexpr int NWAVE = 4;                // waves per workgroup = 32-channel column blocks
-constexpr int NT = 32 * NWAVE;          // output channels per workgroup
+// NW = waves per workgroup = 32-channel column blocks (128 or 64 output channels per workgroup).  NW = 2 is the
+// form for layers with <= 64 output channels (SCoordNet conv1b): the two waves share the transform of an 8 x 4
+// tile block, a super-step is NW chunks, every wave produces TWO tile rows of 16 channels, and two workgroups
+// (72 KiB of V buffers each) share a CU -- still one wave per SIMD.
 // One chunk of V in LDS: [16 positions][2 k-halves][32 tiles][4 floats], padded so that the PRODUCER's stores
 // (8 consecutive lanes = the 8 channel quads of one tile = 4 chunks x 2 halves) fall on 8 different 16-byte bank
 // groups: half stride = 512 + 64, chunk stride = 16 positions + 16 bytes.
@@ -50,7 +52,6 @@ template <bool H16> struct VLayout {
   static constexpr int VBUF = 16 * VPOS + (H16 ? 32 : 16);  // 16 positions + pad
 };
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr int NVBUF = 8;                // two super-steps of 4 chunks
 constexpr int NBR = 16;                 // B ring = one chunk of positions ahead
 constexpr int NVR = 8;                  // V fragment ring (positions ahead inside a super-step)
 // producer schedule inside a super-step of 256 MFMA slots (tools/mb/wino3_prof.hip sweeps these)
@@ -59,6 +60,12 @@ constexpr int NVR = 8;                  // V fragment ring (positions ahead insi
 #define KFN_W3_XSLOT 175    // the transform burst
 #define KFN_W3_SSLOT 192    // first V store
 #define KFN_W3_SSTEP 2      // one V store every SSTEP slots
+#endif
+#ifndef KFN_W3P_GSTEP       // the two-wave form: 128 slots per super-step
+#define KFN_W3P_GSTEP 4
+#define KFN_W3P_XSLOT 96
+#define KFN_W3P_SSLOT 104
+#define KFN_W3P_SSTEP 1
 #endif
 
 struct Wino3Args {
@@ -87,7 +94,7 @@ struct Wino3Args {
 // Every lane stores the same counter value to the same address: an `if (lane == 0)` here is divergent control flow,
 // after which hipcc no longer trusts the gather descriptors to be uniform and wraps each buffer_load in a
 // waterfall loop (4 v_readfirstlane + compare + branch) -- +12 % on the main loop, in the profiled build only.
-#define KFN_STAMP(i) (p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + (i)] = __builtin_readcyclecounter())
+#define KFN_STAMP(i) (p.prof[((size_t)blockIdx.x * NW + wave) * 8 + (i)] = __builtin_readcyclecounter())
 #else
 #define KFN_STAMP(i) do { } while (0)
 #endif
@@ -153,8 +160,12 @@ __device__ __forceinline__ void bt_d_b(f32x2 (&v)[32]) {   // v[2*(4*r + c) + ha
 // H16: BASELINE config 5's fp16-operand convolutions -- V is rounded to fp16 when it is stored to LDS (the input
 // transform itself runs in fp32 on the fp32 activations), U arrives as fp16, one v_mfma_f32_32x32x8_f16 per
 // (position, 8-channel chunk) replaces four v_mfma_f32_32x32x2_f32; accumulation, bias, output transform fp32.
-template <bool H16>
-__global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
+template <bool H16, int NW>
+__device__ __forceinline__ void wino3_body(const Wino3Args& p) {
+  static_assert(NW == 4 || (NW == 2 && !H16), "four waves, or the two-wave fp32 form");
+  constexpr int CPS = NW;           // chunks (of 8 input channels) per super-step
+  constexpr int NVBUF = 2 * CPS;    // chunk buffers: two super-steps
+  constexpr int NT = 32 * NW;       // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem3[];   // [NVBUF][VBUF]
   constexpr int VHALF = VLayout<H16>::VHALF, VPOS = VLayout<H16>::VPOS, VBUF = VLayout<H16>::VBUF, FRAG = VLayout<H16>::FRAG;
   using frag_t = std::conditional_t<H16, f32x2, f32x4>;   // one (position, chunk) fragment of a lane
@@ -163,8 +174,8 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it in an SGPR
   KFN_STAMP(0);
 #ifdef KFN_WINO3_PROF
-  p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-  p.prof[((size_t)blockIdx.x * NWAVE + wave) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+  p.prof[((size_t)blockIdx.x * NW + wave) * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  p.prof[((size_t)blockIdx.x * NW + wave) * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
 #endif
   const int nwg = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap3(blockIdx.x, nwg);
@@ -190,38 +201,68 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
   // lane = (tile column tc, chunk cq, k-half h): 8 CONSECUTIVE lanes read the 128 contiguous bytes of a pixel's 32
   // channels (the texture addresser only merges neighbouring lanes: lanes of one quad on four different pixels
   // are four requests), and a lane's 16 loads are the 4x4 patch of tile (w, tc) for channels 8 cq + 4 h ..+3.
-  const int tc = lane >> 3, ph = lane & 1, cq = (lane >> 1) & 3;
-  // A patch pixel's address splits into a wave-uniform row part (tile row = wave): one descriptor per patch row,
-  // based at the row's first pixel and exactly one image row long (zero long if the row is above/below the image
+  // NW = 2: lane = (tile row of the wave's two rs, tile column tc, chunk cq of 2, k-half h), tc's bit 1 in lane bit 2
+  // so that the 8 lanes of a ds_write_b128 group -- (tc bit 1, cq, h) -- store to 8 different 16-byte bank groups;
+  // 4 neighbouring lanes read the 64 contiguous bytes of a pixel's 16 channels.
+  const int ph = lane & 1;
+  const int cq = NW == 4 ? (lane >> 1) & 3 : (lane >> 1) & 1;
+  const int tc = NW == 4 ? lane >> 3 : ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1) + ((lane >> 4) & 1) * 4;
+  const int ptr = NW == 4 ? wave : 2 * wave + (lane >> 5);   // tile row this lane produces (uniform when NW = 4)
+  // NW = 4: a patch pixel's address splits into a wave-uniform row part (tile row = wave): one descriptor per patch
+  // row, based at the row's first pixel and exactly one image row long (zero long if the row is above/below the image
   // or the tile row does not exist), and a per-lane column part.  Columns left of the image give a negative =
   // huge unsigned vector offset, columns right of it an offset past the row: both fail the range check and
   // read as zero.
-  unsigned gcol[4];                   // byte offset of patch column c at this lane's channel quad
-  __amdgpu_buffer_rsrc_t rs_row[4];   // uniform
+  // NW = 2: the tile row differs between the wave's halves, so ONE descriptor covers the block's (at most two) images
+  // and every lane carries the 16 offsets of its patch, poisoned (>= 1 GiB, beyond any two images the launcher
+  // admits) where the row or the column falls outside the image.
+  unsigned gcol[NW == 4 ? 4 : 1];                   // NW = 4: byte offset of patch column c at this lane's channel quad
+  __amdgpu_buffer_rsrc_t rs_row[NW == 4 ? 4 : 1];   // NW = 4: uniform row descriptors; NW = 2: [0] = the block's images
+  unsigned goff[NW == 4 ? 1 : 16];                  // NW = 2: per-lane offsets of the 4x4 patch
   {
-    const int tr = wave;
+    const int tr = ptr;
     const int img_rel = tr < brk ? 0 : 1;
     const int ty = tr < brk ? ty0 + tr : tr - brk;
     const int tx = cb * BW + tc;
     const bool tile_ok = (vr0 + tr < p.vrows);
     const int row_bytes = ((p.W - 1) * p.ldx + p.Cin) * 4;
+    if constexpr (NW == 4) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int yy = 2 * ty - 1 + r;
-      const bool ok = tile_ok && (unsigned)yy < (unsigned)p.H;
-      const unsigned long long off =
-          ok ? (unsigned long long)((img_rel * p.H + yy) * p.W) * (unsigned long long)(p.ldx * 4) : 0ull;
-      rs_row[r] = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base + off, 0, ok ? row_bytes : 0, 0x00020000);
+      for (int r = 0; r < 4; ++r) {
+        const int yy = 2 * ty - 1 + r;
+        const bool ok = tile_ok && (unsigned)yy < (unsigned)p.H;
+        const unsigned long long off =
+            ok ? (unsigned long long)((img_rel * p.H + yy) * p.W) * (unsigned long long)(p.ldx * 4) : 0ull;
+        rs_row[r] = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base + off, 0, ok ? row_bytes : 0, 0x00020000);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gcol[c] = (unsigned)(((2 * tx - 1 + c) * p.ldx + cq * 8 + ph * 4) * 4);
+    } else {
+      const unsigned long long rest = p.x_bytes - a_base;
+      const unsigned long long two = 2ull * p.H * p.W * p.ldx * 4ull;
+      rs_row[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
+                                                    (int)(rest < two ? rest : two), 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = 2 * ty - 1 + r;
+        const bool rok = tile_ok && (unsigned)yy < (unsigned)p.H;
+        const unsigned roff = rok ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) : 0x80000000u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int xx = 2 * tx - 1 + c;
+          const unsigned coff = (unsigned)xx < (unsigned)p.W ? (unsigned)((xx * p.ldx + cq * 8 + ph * 4) * 4) : 0x40000000u;
+          goff[4 * r + c] = roff + coff;
+        }
+      }
+      (void)row_bytes;
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gcol[c] = (unsigned)(((2 * tx - 1 + c) * p.ldx + cq * 8 + ph * 4) * 4);
   }
   // consumer fragment of position g: g*VPOS + half*VHALF + tile*16; the producer lane stores into chunk cq
   const int v_lane = (lane >> 5) * VHALF + (lane & 31) * FRAG;
-  const int v_st = cq * VBUF + ph * VHALF + wave * (8 * FRAG) + tc * FRAG;
+  const int v_st = cq * VBUF + ph * VHALF + ptr * (8 * FRAG) + tc * FRAG;
   const int n_chunks = p.Cin / 8;
-  const int n_super = n_chunks / 4;
+  const int n_super = n_chunks / CPS;
   const int s_last = n_super - 1;
 
   // ---- this lane as a CONSUMER ---------------------------------------------------------------
@@ -254,7 +295,9 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
     constexpr int i = decltype(ic)::value, pb = decltype(pb_)::value;
     constexpr int r = i >> 2, c = i & 3;
     const int sc = ss < s_last ? ss : s_last;
-    const f32x4 q = bload(rs_row[r], gcol[c], (unsigned)(sc * 128));
+    f32x4 q;
+    if constexpr (NW == 4) q = bload(rs_row[r], gcol[c], (unsigned)(sc * 128));
+    else q = bload(rs_row[0], goff[i], (unsigned)(sc * 64));
     pv[pb][2 * i] = q.xy;
     pv[pb][2 * i + 1] = q.zw;
   };
@@ -263,10 +306,10 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
     if constexpr (H16) {
       const f16x4 q = {(_Float16)pv[pb][2 * g].x, (_Float16)pv[pb][2 * g].y, (_Float16)pv[pb][2 * g + 1].x,
                        (_Float16)pv[pb][2 * g + 1].y};   // RNE
-      *reinterpret_cast<f16x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+      *reinterpret_cast<f16x4*>(smem3 + (ss & 1) * (CPS * VBUF) + v_st + g * VPOS) = q;
     } else {
       const f32x4 q = {pv[pb][2 * g].x, pv[pb][2 * g].y, pv[pb][2 * g + 1].x, pv[pb][2 * g + 1].y};
-      *reinterpret_cast<f32x4*>(smem3 + (ss & 1) * (4 * VBUF) + v_st + g * VPOS) = q;
+      *reinterpret_cast<f32x4*>(smem3 + (ss & 1) * (CPS * VBUF) + v_st + g * VPOS) = q;
     }
   };
   // fragment qidx = chunk*16 + position into ring slot `sl`
@@ -299,24 +342,29 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
   // producer: gather chunk c0+4+wave behind the first MFMAs of chunk c0, transform it as ONE burst in the
   // middle of chunk c0+2, store it behind the MFMAs of chunk c0+3; then the barrier.
 #ifdef KFN_W3_TL
+#ifndef KFN_W3_TL_KS
+#define KFN_W3_TL_KS (-1)   // the super-step whose timeline is kept (-1: the last one)
+#endif
   unsigned long long tl[17];
 #endif
   // MFMA slots per chunk and the producer's schedule inside the 4-chunk super-step.  fp32: gather super-step ks+1
   // early, transform late, store.  fp16: transform + store super-step ks+1 (gathered during ks-1) first, then gather
   // ks+2 into the buffer that just became free.
   constexpr int SPC = H16 ? 16 : 64;
-  constexpr int GSLOT = H16 ? 32 : 0, GSTEP = H16 ? 2 : KFN_W3_GSTEP, XSLOT = H16 ? 8 : KFN_W3_XSLOT;
-  constexpr int SSLOT = H16 ? 12 : KFN_W3_SSLOT, SSTEP = H16 ? 1 : KFN_W3_SSTEP;
+  constexpr int GSLOT = H16 ? 32 : 0, GSTEP = H16 ? 2 : (NW == 4 ? KFN_W3_GSTEP : KFN_W3P_GSTEP);
+  constexpr int XSLOT = H16 ? 8 : (NW == 4 ? KFN_W3_XSLOT : KFN_W3P_XSLOT);
+  constexpr int SSLOT = H16 ? 12 : (NW == 4 ? KFN_W3_SSLOT : KFN_W3P_SSLOT), SSTEP = H16 ? 1 : (NW == 4 ? KFN_W3_SSTEP : KFN_W3P_SSTEP);
+  static_assert(GSLOT + 16 * GSTEP <= CPS * SPC && SSLOT + 16 * SSTEP <= CPS * SPC && XSLOT < SSLOT, "producer schedule inside the super-step");
   auto super_step = [&](int ks, auto par_) __attribute__((always_inline)) {
     constexpr int par = decltype(par_)::value;        // fp16: ks & 1 = the buffer this super-step gathers into
     using GB = std::integral_constant<int, par>;               // gather buffer
     using XB = std::integral_constant<int, H16 ? par ^ 1 : 0>;  // transform / store buffer
-    const int c0 = ks * 4;
+    const int c0 = ks * CPS;
     const int g_ss = H16 ? ks + 2 : ks + 1;   // super-step being gathered
     const int x_ss = ks + 1;                  // super-step being transformed and stored
     // the V fragments of the first NVR positions (nothing of this super-step could be read before the barrier)
     sfor<NVR>([&](auto gc) { v_read(gc, c0); });
-    sfor<4>([&](auto cc_) {
+    sfor<CPS>([&](auto cc_) {
       constexpr int cc = decltype(cc_)::value;
       const int ch = c0 + cc;
       const int qbase = ch * 16;
@@ -326,7 +374,8 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
         constexpr int g = H16 ? j : (j >> 4) * 4 + (j & 3), t = H16 ? 3 : (j >> 2) & 3;
         constexpr int sl = (cc * 16 + g) % NB;     // B ring slot of fragment ch*16 + g (c0 is a multiple of 4)
 #ifdef KFN_W3_TL
-        if constexpr (!H16 && (cc * 64 + j) % 16 == 0) tl[(cc * 64 + j) / 16] = __builtin_readcyclecounter();
+        if constexpr (!H16 && (cc * 64 + j) % 16 == 0)
+          if (KFN_W3_TL_KS < 0 || ks == KFN_W3_TL_KS) tl[(cc * 64 + j) / 16] = __builtin_readcyclecounter();
 #endif
         if constexpr (H16)
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4, vq[g % NVR]), __builtin_bit_cast(f16x4, bq[sl]), acc[g], 0, 0, 0);
@@ -336,7 +385,7 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
           b_load(std::integral_constant<int, sl>{}, qbase + g + NB);
           // V fragment NVR positions ahead: same chunk, or the next chunk of THIS super-step
           if constexpr (g + NVR < 16) v_read(std::integral_constant<int, g + NVR>{}, ch);
-          else if constexpr (cc < 3) v_read(std::integral_constant<int, g + NVR - 16>{}, ch + 1);
+          else if constexpr (cc < CPS - 1) v_read(std::integral_constant<int, g + NVR - 16>{}, ch + 1);
         }
         // producer work, spread thin: the four waves of a CU share one texture addresser and one LDS port, and a
         // wave whose vector-memory instruction cannot issue stalls its MFMAs behind it
@@ -352,6 +401,9 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef KFN_W3_TL
+    if (KFN_W3_TL_KS < 0 || ks == KFN_W3_TL_KS) tl[16] = __builtin_readcyclecounter();
+#endif
   };
   if constexpr (H16) {
     for (int ks = 0; ks < n_super; ks += 2) {   // n_super is even (Cin % 64 == 0): two super-steps per trip, one per buffer
@@ -363,9 +415,8 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
   }
 
 #ifdef KFN_W3_TL
-  tl[16] = __builtin_readcyclecounter();
 #pragma unroll
-  for (int i = 0; i < 17; ++i) p.prof[((size_t)gridDim.x * NWAVE) * 8 + ((size_t)blockIdx.x * NWAVE + wave) * 17 + i] = tl[i];
+  for (int i = 0; i < 17; ++i) p.prof[((size_t)gridDim.x * NW) * 8 + ((size_t)blockIdx.x * NW + wave) * 17 + i] = tl[i];
 #endif
   KFN_STAMP(3);
   // ---- epilogue (per wave, as kfn_wino2.hip) -----------------------------------------------------
@@ -448,6 +499,11 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino3_kernel(Wino3Args p) {
 #endif
 }
 
+// the four-wave form (128 output channels per workgroup) and the two-wave form (33 .. 64 output channels in all)
+template <bool H16>
+__global__ __launch_bounds__(256, 1) void wino3_kernel(Wino3Args p) { wino3_body<H16, 4>(p); }
+__global__ __launch_bounds__(128, 1) void wino3_pair_kernel(Wino3Args p) { wino3_body<false, 2>(p); }
+
 }  // namespace
 
 #ifdef KFN_WINO3_PROF
@@ -456,8 +512,8 @@ unsigned long long* g_wino3_prof = nullptr;
 
 namespace kfn {
 
-// Launch of the 4-wave form for a descriptor kfn_conv2d_winograd_fused has already validated
-// (Cin % 32 == 0, Cout >= 128).  Called from kfn_wino2.hip.
+// Launch of the 4-wave form (Cin % 32 == 0, Cout >= 128) or the two-wave form (cout_pad == 64, Cin % 16 == 0) for
+// a descriptor kfn_conv2d_winograd_fused has already validated.  Called from kfn_wino2.hip.
 int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias, float* y,
                  hipStream_t stream) {
   const bool h16 = d->operand_dtype == KFN_OPERAND_F16;
@@ -474,7 +530,8 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, 
   a.vrows = (int)vrows;
   a.bw = ceil_div(a.Tw, BW);
   const long tiles_m = (long)a.bw * ceil_div(a.vrows, BH);
-  a.tiles_n = ceil_div(d->cout_pad, NT);
+  const bool pair = !h16 && d->cout_pad == 64;          // the two-wave form: all of a layer's 33..64 output channels in one workgroup
+  a.tiles_n = ceil_div(d->cout_pad, pair ? 64 : 128);
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_fused: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
@@ -486,22 +543,29 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, 
 #ifdef KFN_WINO3_PROF
   a.prof = g_wino3_prof;
 #endif
-  static std::atomic<uint64_t> attr_done{0};
-  {
-    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<false>), NVBUF * VLayout<false>::VBUF, attr_done);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  if (pair) {
+    // per-lane patch offsets carry their out-of-image marks in bits 30 and 31: two images must stay below 1 GiB
+    KFN_REQUIRE(2L * d->H * d->W * d->ldx * 4L < (1L << 30), "kfn_conv2d_winograd_fused: image beyond 512 MiB in the two-wave form");
+    constexpr int lds = 4 * VLayout<false>::VBUF;
+    static std::atomic<uint64_t> attr_done2{0};
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_pair_kernel), lds, attr_done2);
     if (rc != KFN_OK) return rc;
-  }
-  if (h16) {
+    hipLaunchKernelGGL(wino3_pair_kernel, grid, dim3(128), lds, stream, a);
+  } else if (h16) {
+    constexpr int lds = 8 * VLayout<true>::VBUF;
     static std::atomic<uint64_t> attr_done16{0};
-    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<true>), NVBUF * VLayout<true>::VBUF, attr_done16);
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<true>), lds, attr_done16);
     if (rc != KFN_OK) return rc;
-    hipLaunchKernelGGL(wino3_kernel<true>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE), NVBUF * VLayout<true>::VBUF,
-                       stream, a);
+    hipLaunchKernelGGL(wino3_kernel<true>, grid, dim3(256), lds, stream, a);
   } else {
-    hipLaunchKernelGGL(wino3_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NWAVE),
-                       NVBUF * VLayout<false>::VBUF, stream, a);
+    constexpr int lds = 8 * VLayout<false>::VBUF;
+    static std::atomic<uint64_t> attr_done{0};
+    int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(wino3_kernel<false>), lds, attr_done);
+    if (rc != KFN_OK) return rc;
+    hipLaunchKernelGGL(wino3_kernel<false>, grid, dim3(256), lds, stream, a);
   }
-  KFN_LAUNCH_CHECK("wino3_kernel");
+  KFN_LAUNCH_CHECK(pair ? "wino3_pair_kernel" : "wino3_kernel");
   return KFN_OK;
 }
 

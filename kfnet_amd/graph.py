@@ -472,7 +472,8 @@ class WinogradFusedConvOp(ConvOp):
     """3x3 stride-1 SAME conv through kfn_conv2d_winograd_fused: all 16 Winograd positions of a tile
     block in registers, input and output transforms in the kernel -- one launch, no workspace.  The library
     picks the form: four waves sharing one input transform through LDS (wino3_kernel, 128 output channels
-    per workgroup) when Cout >= 128 and Cin % 32 == 0, else one wave per 32 output channels (wino2_kernel)."""
+    per workgroup) when Cout >= 128 and Cin % 32 == 0, two waves sharing it (wino3_pair_kernel) for 33 .. 64 output
+    channels with Cin % 16 == 0, else one wave per 32 output channels (wino2_kernel)."""
 
     def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu, operand_dtype=operand_dtype)
@@ -488,9 +489,18 @@ class WinogradFusedConvOp(ConvOp):
         """Mirror of the routing rule in kfn_conv2d_winograd_fused (kfn_wino2.hip)."""
         return self.y.shape[3] >= 128 and self.x.shape[3] % 32 == 0
 
+    def two_wave(self):
+        """The second routing rule of kfn_conv2d_winograd_fused: all of a layer's 33 .. 64 output channels in one
+        workgroup of two waves (two images of the input below 1 GiB: the patch offsets carry their marks above)."""
+        n, h, w, cin = self.x.shape
+        return (not self.four_wave() and self.operand_dtype == _lib.OPERAND_F32 and 32 < self.y.shape[3] <= 64
+                and cin % 16 == 0 and 2 * h * w * self.x.ld * 4 < (1 << 30))
+
     def kernel_name(self, lib):
         if self.operand_dtype == _lib.OPERAND_F16:
             return 'wino3_kernel<true>'
+        if self.two_wave():
+            return 'wino3_pair_kernel'
         return 'wino3_kernel' if self.four_wave() else 'wino2_kernel'
 
     def mfma_flops(self):

@@ -710,7 +710,10 @@ FUSED_CASES = [(1, 8, 8, 128, 128), (2, 7, 9, 128, 160), (1, 60, 80, 256, 128), 
                (4, 14, 33, 32, 40), (1, 64, 96, 64, 64), (17, 10, 12, 16, 8), (2, 16, 30, 1024, 32),
                # >= 128 output channels and Cin % 32 == 0: the four-wave form (kfn_wino3.hip) -- ragged channel
                # tiles (waves past Cout), blocks straddling two images, ragged tile blocks, many super-steps
-               (5, 30, 40, 64, 256), (3, 14, 33, 32, 192), (17, 10, 12, 32, 136), (2, 12, 16, 512, 128)]
+               (5, 30, 40, 64, 256), (3, 14, 33, 32, 192), (17, 10, 12, 32, 136), (2, 12, 16, 512, 128),
+               # 33 .. 64 output channels and Cin % 16 == 0: the two-wave form of kfn_wino3.hip ((3,12,16,64,36),
+               # (2,10,6,48,64), (4,14,33,32,40), (1,64,96,64,64) above take it too) -- one and five super-steps
+               (17, 10, 12, 16, 64), (2, 30, 40, 80, 64)]
 
 
 @pytest.mark.parametrize('relu', [1, 0])
@@ -744,6 +747,40 @@ def test_winograd_fused_vs_oracle(case, relu):
     ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, bool(relu))
     err = np.abs(got[:n * h * w, :co].reshape(ref.shape) - ref).max()
     assert err <= 3 * _conv_tol(x, wt), err
+
+
+@pytest.mark.parametrize('case', [(3, 14, 33, 64, 64, 0), (2, 30, 40, 48, 40, 8), (5, 30, 40, 64, 256, 0)])
+def test_winograd_fused_forms_agree(case):
+    """kfn_conv_desc.wino_form = KFN_WINO_FORM_ONE_WAVE (wino2_kernel) against the default route (two-wave / four-wave
+    wino3_kernel) on the same operands: the same products in the same K order per accumulator, so the two agree to
+    a few ulp of the accumulated magnitude; input read through a strided view (ldx > Cin)."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_fused_kernel
+    lib = _lib.load()
+    n, h, w, ci, co, xpad = case
+    rng = np.random.default_rng(77 + ci + co)
+    ldx = ci + xpad
+    xs = np.full((n, h, w, ldx), 1e3, np.float32)        # the channels beyond Cin must never be read
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    xs[..., :ci] = x
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    dx, du, db = dev(xs), dev(pack_winograd_fused_kernel(wt)), dev(b)
+    outs = []
+    for form in (0, 1):
+        d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=-(-co // 32) * 32, ldy=co, kh=3, kw=3,
+                          stride=1, relu=1, wino_form=form)
+        y = torch.full((n * h * w, co), -5.0, device='cuda')
+        _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                                 stream()), 'fused')
+        sync()
+        outs.append(y.cpu().numpy())
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, True)
+    for o in outs:
+        assert np.abs(o.reshape(ref.shape) - ref).max() <= 3 * _conv_tol(x, wt)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
 # kfn_conv2d_winograd_s2 (3x3 stride 2, even images): blocks straddling images (Th % 4 != 0), odd output sizes

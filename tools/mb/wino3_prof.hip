@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
   hipMemset(x, 0, xb); hipMemset(u, 0, ub); hipMemset(b, 0, d.cout_pad * 4);
   const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
   const long nblk = (long)((Tw + 7) / 8) * ((N * Th + 3) / 4) * ((d.cout_pad + 127) / 128);
+  const int NWV = d.cout_pad == 64 ? 2 : 4;   // waves per workgroup: the two-wave form takes 33..64 output channels
   hipMalloc(&g_wino3_prof, nblk * 4 * 25 * 8);
   hipMemset(g_wino3_prof, 0, nblk * 4 * 25 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -41,22 +42,22 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("launch rc=%d  %.3f ms  (%ld blocks)\n", rc, ms, nblk);
   }
-  std::vector<unsigned long long> h(nblk * 32);
-  hipMemcpy(h.data(), g_wino3_prof, nblk * 32 * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> h(nblk * NWV * 8);
+  hipMemcpy(h.data(), g_wino3_prof, nblk * NWV * 8 * 8, hipMemcpyDeviceToHost);
   // per-phase means over waves
   double ph[5] = {0, 0, 0, 0, 0};
-  for (long i = 0; i < nblk * 4; ++i)
+  for (long i = 0; i < nblk * NWV; ++i)
     for (int k = 0; k < 5; ++k) ph[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]);
   const char* nm[5] = {"setup (geometry, acc init)", "prologue (gather, B ring, transform, barrier)", "main loop",
                        "epilogue issue", "store drain"};
   double tot = 0;
   for (int k = 0; k < 5; ++k) tot += ph[k];
-  for (int k = 0; k < 5; ++k) printf("%-48s %10.0f cycles  %5.1f %%\n", nm[k], ph[k] / (nblk * 4), 100 * ph[k] / tot);
+  for (int k = 0; k < 5; ++k) printf("%-48s %10.0f cycles  %5.1f %%\n", nm[k], ph[k] / (nblk * NWV), 100 * ph[k] / tot);
 #ifdef KFN_W3_EPI
   {
     double a = 0, b = 0;
-    for (long i = 0; i < nblk * 4; ++i) { a += (double)(h[i * 8 + 6] - h[i * 8 + 3]); b += (double)(h[i * 8 + 4] - h[i * 8 + 6]); }
-    printf("epilogue: output transform + LDS writes %.0f cycles, LDS reads + stores %.0f cycles\n", a / (nblk * 4), b / (nblk * 4));
+    for (long i = 0; i < nblk * NWV; ++i) { a += (double)(h[i * 8 + 6] - h[i * 8 + 3]); b += (double)(h[i * 8 + 4] - h[i * 8 + 6]); }
+    printf("epilogue: output transform + LDS writes %.0f cycles, LDS reads + stores %.0f cycles\n", a / (nblk * NWV), b / (nblk * NWV));
   }
 #endif
   const int chunks = Cin / 8;
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
     const long tiles_m = (long)bw * ((N * Th + 3) / 4);
     std::vector<double> by_cb(bw, 0.0); std::vector<long> n_cb(bw, 0);
     for (long bi = 0; bi < nblk; ++bi) {
-      ml[bi] = (double)(h[(bi * 4) * 8 + 3] - h[(bi * 4) * 8 + 2]) / chunks;
+      ml[bi] = (double)(h[(bi * NWV) * 8 + 3] - h[(bi * NWV) * 8 + 2]) / chunks;
       const int nwg = (int)nblk; const int xcd = bi & 7; const int q = nwg >> 3, r = nwg & 7;
       const long base = (xcd < r) ? (long)xcd * (q + 1) : (long)r * (q + 1) + (long)(xcd - r) * q;
       const long tile = base + (bi >> 3);
@@ -81,12 +82,12 @@ int main(int argc, char** argv) {
     for (int c = 0; c < bw; ++c) printf(" %.0f", by_cb[c] / (n_cb[c] ? n_cb[c] : 1));
     printf("\n");
   }
-  printf("main loop per chunk: %.0f cycles (64 MFMAs = 4096 at one per 64)\n", ph[2] / (nblk * 4) / chunks);
+  printf("main loop per chunk: %.0f cycles (64 MFMAs = 4096 at one per 64)\n", ph[2] / (nblk * NWV) / chunks);
   // gaps between consecutive workgroups on the same SIMD (wave 0 of each block keyed by xcc/se/cu/simd)
   std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> per;
   for (long bi = 0; bi < nblk; ++bi)
-    for (int w = 0; w < 4; ++w) {
-      const unsigned long long* r = &h[(bi * 4 + w) * 8];
+    for (int w = 0; w < NWV; ++w) {
+      const unsigned long long* r = &h[(bi * NWV + w) * 8];
       const unsigned hw = (unsigned)r[6], xcc = (unsigned)r[7] & 0xf;
       const unsigned long long key = ((unsigned long long)xcc << 32) | (hw & 0xff30);   // SIMD, CU, SH, SE
       per[key].push_back({r[0], r[5]});
@@ -102,16 +103,17 @@ int main(int argc, char** argv) {
          per.size(), ng ? gap / ng : 0.0);
 #ifdef KFN_W3_TL
   {
-    std::vector<unsigned long long> tl(nblk * 4 * 17);
-    hipMemcpy(tl.data(), g_wino3_prof + nblk * 32, nblk * 4 * 17 * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> tl(nblk * NWV * 17);
+    hipMemcpy(tl.data(), g_wino3_prof + nblk * NWV * 8, nblk * NWV * 17 * 8, hipMemcpyDeviceToHost);
     double seg[16] = {0};
-    for (long i = 0; i < nblk * 4; ++i)
-      for (int k = 0; k < 16; ++k) seg[k] += (double)(tl[i * 17 + k + 1] - tl[i * 17 + k]);
+    const int nseg = NWV * 4;   // a super-step is NWV chunks of 64 slots
+    for (long i = 0; i < nblk * NWV; ++i)
+      for (int k = 0; k < nseg; ++k) seg[k] += (double)(tl[i * 17 + (k + 1 < nseg ? k + 1 : 16)] - tl[i * 17 + k]);
     printf("last super-step, cycles per 16-slot segment (1024 = MFMA bound):");
-    for (int k = 0; k < 16; ++k) printf(" %.0f", seg[k] / (nblk * 4));
+    for (int k = 0; k < nseg; ++k) printf(" %.0f", seg[k] / (nblk * NWV));
     printf("\n");
   }
 #endif
-  printf("per block total %.0f cycles; MFMA-only would be %d\n", tot / (nblk * 4), chunks * 4096);
+  printf("per block total %.0f cycles; MFMA-only would be %d\n", tot / (nblk * NWV), chunks * 4096);
   return 0;
 }

@@ -36,7 +36,7 @@ for (name, H, W, ci, co) in LAYERS:
         if not (co >= 128 and ci % 64 == 0):
             continue
         u = u.half()
-    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1, wino_order=ORDER,
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1, wino_order=ORDER, wino_form=int(os.environ.get('MB_WINO_FORM', '0')),
                       config=int(os.environ.get('KFN_WINO_CFG', '0')), operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32)
     t_fused = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr() + YOFF, st), 'wf'))
     fl = 2.0 * 16 * Mt * ci * co
