@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const_cast<char*>(reinterpret_cast<const char*>(CVOL ? p.x2 : p.x)) + a_base, 0,
       (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
   float* const b_ptr = const_cast<float*>(p.w) + (size_t)grp * p.cout_pad * p.Ktot;
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, p.w_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, p.w_bytes, 0x00020000);
 
   // ---- per-thread im2col row state -------------------------------------------------
   // conv:        a_off = byte offset of input pixel (iy0, ix0) (may be "negative" = wrapped;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr int NDMA = BDMA ? BP : 0;                       // weight-tile transfers global -> LDS per stage
   constexpr int NADMA = ADMA ? AP : 0;                      // activation-tile transfers
   // BDMA: transfer i of this wave covers rows 64 i + 16 wave .. +15 of the B tile, lane L -> byte L*16 of that 1 KiB run
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t [[maybe_unused]];   // (used in the device pass only)
   const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Bs + (unsigned)(wave * 16 * BK * 4));
   auto dma_one = [&](int i, bool live, unsigned bdelta, int bbuf) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b_ptr, 0, live ? (int)p.w_bytes : 0, 0x00020000);

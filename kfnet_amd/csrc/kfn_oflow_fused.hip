@@ -32,7 +32,6 @@ constexpr unsigned OOBV = 0x80000000u;   // voffset that always fails the buffer
 
 constexpr int C0 = 32;            // conv0 / conv1a / conv5 channels
 constexpr int CU = 16;            // upconv0 channels
-constexpr int C1 = CU + C0;       // concat0
 constexpr int C2 = 16;            // conv6 channels
 constexpr int C9 = 9 * C0;        // channels of the T / G maps
 constexpr int LD1 = 56;           // floats per cell: concat0 image
