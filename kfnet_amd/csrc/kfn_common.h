@@ -8,6 +8,12 @@
 #include <cstdint>
 #include "../../include/kfnet_hip.h"
 
+// Cache policy of the wide (16-byte, whole-line) output stores of the convolution kernels: 0 = default, 2 = the
+// non-temporal bit (A/B build: NT_STORE=1 tools/mb/build_hot.sh).
+#ifndef KFN_NT_STORE_AUX
+#define KFN_NT_STORE_AUX 0
+#endif
+
 namespace kfn {
 
 // thread-local error text returned by kfn_last_error()

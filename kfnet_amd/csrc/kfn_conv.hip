@@ -923,7 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const int n = n0 + ch * 8;
       // rows past M fail the range check; chunks past Cout (a partial last column tile) are dropped here
       const unsigned voff = (n < p.Cout) ? (unsigned)row * row_b16 + (unsigned)n * 2u : OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsY16, voff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsY16, voff, 0, KFN_NT_STORE_AUX);
     }
     return;
   }

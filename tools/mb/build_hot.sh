@@ -17,3 +17,13 @@ if [ -n "$W2_DWORD" ]; then
   OBJS=$(ls kfnet_amd/csrc/build/*.o | grep -v kfn_wino2.o)
   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_w2dword.so /tmp/kfn_wino2_nw.o $OBJS || exit 1
 fi
+# A/B of non-temporal wide output stores in the convolution kernels: tools/mb/libkfnet_ntstore.so
+if [ -n "$NT_STORE" ]; then
+  OB=""
+  for f in kfn_wino3 kfn_wino2 kfn_wino_s2 kfn_conv; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DKFN_NT_STORE_AUX=2 -c kfnet_amd/csrc/$f.hip -o /tmp/${f}_nt.o || exit 1
+    OB="$OB /tmp/${f}_nt.o"
+  done
+  OBJS=$(ls kfnet_amd/csrc/build/*.o | grep -v "kfn_wino3.o\|kfn_wino2.o\|kfn_wino_s2.o\|kfn_conv.o")
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_ntstore.so $OB $OBJS || exit 1
+fi

@@ -4,6 +4,8 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kfnet_amd import _lib
+if os.environ.get('MB_LIB'):          # an A/B build (tools/mb/build_hot.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ['MB_LIB'])
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 def timeit(fn, reps=5):
