@@ -202,17 +202,18 @@ def test_epilogue_on_a_winograd_routed_layer_reroutes_to_the_direct_kernel():
     """with winograd_min_channels <= 32, feat7 (3x3, 128 -> 32) would take the Winograd
     path, which has no fused epilogue -- tf.nn.l2_normalize must not be dropped silently."""
     from kfnet_amd import _lib
-    from kfnet_amd.graph import ConvOp, Graph, WinogradConvOp, pack_conv_kernel
+    from kfnet_amd.graph import ConvOp, Graph, WinogradConvOp, WinogradFusedConvOp, pack_conv_kernel
     from kfnet_amd.KFNet.KFNet import KFNet, KFNetDataSpec
     g = Graph()
     g.winograd_min_channels = 32
+    assert g.winograd_fused_min_channels <= 32       # feat7 (128 -> 32) is Winograd-routed before its epilogue is set
     images = g.placeholder((2, 64, 96, 3), 'u8', name='images')
     net = KFNet(images, KFNetDataSpec(batch_size=2, image_size=(64, 96)))
     feat7 = [op for op in net.feat_tower.ops if op.name == 'feat7']
     assert len(feat7) == 1 and type(feat7[0]) is ConvOp and feat7[0].epilogue == _lib.EPI_L2NORM
     assert feat7[0].kernel.pack is pack_conv_kernel and feat7[0] in net.frame_ops and feat7[0] in g.ops
     # the other wide stride-1 layers of the tower did go to Winograd with this setting
-    assert any(isinstance(op, WinogradConvOp) for op in net.feat_tower.ops)
+    assert any(isinstance(op, (WinogradConvOp, WinogradFusedConvOp)) for op in net.feat_tower.ops)
     with pytest.raises(KeyError):
         net.feat_tower.set_epilogue('no_such_layer', _lib.EPI_L2NORM)
 

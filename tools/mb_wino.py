@@ -20,7 +20,8 @@ def timeit(fn, reps=5):
 ORDER = int(os.environ.get('MB_WINO_ORDER', '0'))   # kfn_conv_desc.wino_order: 0 default, 1 tile blocks fastest, 2 channel groups fastest
 N = int(os.environ.get('MB_BATCH', '17'))
 LAYERS = [('conv1b', 480, 640, 64, 64), ('conv2b', 240, 320, 256, 256), ('conv3b', 120, 160, 512, 512),
-          ('conv4b', 60, 80, 1024, 1024), ('conv5', 60, 80, 1024, 512), ('conv6', 60, 80, 512, 256)]
+          ('conv4b', 60, 80, 1024, 1024), ('conv5', 60, 80, 1024, 512), ('conv6', 60, 80, 512, 256),
+          ('feat3', 240, 320, 32, 32), ('feat5', 120, 160, 64, 64)]   # flow-feature tower (KFNet.py:70-76)
 ONLY = os.environ.get('MB_LAYERS', '')
 FUSED_ONLY = os.environ.get('MB_FUSED_ONLY', '') == '1'
 for (name, H, W, ci, co) in LAYERS:
