@@ -78,6 +78,38 @@ def test_graph_matches_reference_architecture():
         sc.feed('conv7').max_pool(2, 2, name='p')
 
 
+def test_default_routes_of_the_3x3_layers():
+    """Which kernel every 3x3 layer of the default (fp32) graph is handed to -- the host mirror of the routing rules
+    in kfn_conv2d_winograd_fused / kfn_conv2d_winograd_s2 (csrc/kfn_wino2.hip, kfn_wino_s2.hip) that bench.py's
+    per-kernel table and roofline rely on."""
+    from kfnet_amd.graph import WinogradFusedConvOp, WinogradS2ConvOp
+    g, net = _build(2)
+    lib = _lib.load()            # kfn_conv2d_plan is host code: no GPU needed
+    four_wave = ('conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6')
+    asked = four_wave + ('conv1b', 'feat5', 'feat3', 'conv2a', 'conv3a', 'conv4a', 'feat6')
+    names = {}
+    for op in g.ops:       # (first op of a name: SCoordNet / the feature tower come before OFlowNet's same-named layers)
+        if op.name in asked and op.name not in names:
+            names[op.name] = op.kernel_name(lib)
+    for n in four_wave:
+        assert names[n] == 'wino3_kernel', (n, names[n])
+    assert names['conv1b'] == 'wino3_pair_kernel'            # 64 -> 64: two waves share one transform
+    assert names['feat5'] == 'wino3_pair_kernel'
+    assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
+    for n in ('conv2a', 'conv3a', 'conv4a', 'feat6'):
+        assert names[n] == 'wino_s2_kernel', (n, names[n])
+    by_name = {}
+    for op in g.ops:
+        by_name.setdefault(op.name, op)
+    assert isinstance(by_name['conv1b'], WinogradFusedConvOp) and by_name['conv1b'].two_wave()
+    assert not by_name['conv2b'].two_wave() and by_name['conv2b'].four_wave()
+    assert isinstance(by_name['conv2a'], WinogradS2ConvOp)
+    # executed MFMA FLOPs of the two-wave form: all 64 channels in one column block (no padding to 128)
+    op = by_name['conv1b']
+    n, ho, wo, co = op.y.shape
+    assert op.mfma_flops() == 2.0 * 16 * (-(-((wo + 1) // 2) // 8) * 8) * (-(-(n * ((ho + 1) // 2)) // 4) * 4) * 64 * 64
+
+
 def test_concat_is_zero_copy_rebinding():
     g, net = _build(1, 64, 96)
     of = net.oflownet
