@@ -143,6 +143,48 @@ def test_weight_packing_layouts():
     assert np.array_equal(pack_dense_kernel(wf)[:64], wf.T)
 
 
+def test_round3_weight_layouts_follow_their_documented_index_formulas():
+    """The device layouts the window-resident OFlowNet kernels and the fp16-activation convolution read, element by
+    element against the index expressions in their docstrings / include/kfnet_hip.h (seeded random kernels)."""
+    from kfnet_amd.graph import (pack_conv_kernel_chunked, pack_oflow_head_kernel, pack_oflow_tail_kernel,
+                                 pack_oflow_upconv_kernel, pack_winograd_fused_kernel)
+    rng = np.random.default_rng(11)
+    # chunk-major conv weights: [K/32][cout_pad][32], K = (kh, kw, ci)
+    w = rng.normal(size=(3, 3, 64, 40)).astype(np.float32)
+    m = pack_conv_kernel_chunked(w)
+    assert m.shape == (9 * 64 // 32, 64, 32)
+    for (ky, kx, ci, co) in [(0, 0, 0, 0), (1, 2, 37, 39), (2, 2, 63, 5), (2, 0, 31, 17)]:
+        k = (ky * 3 + kx) * 64 + ci
+        assert m[k // 32, co, k % 32] == w[ky, kx, ci, co]
+    assert np.all(m[:, 40:, :] == 0)                       # channels 40..63 of the padded column tile
+    # oflow_head: fragment t = (tap*8 + j)*2 + nb of lane (kq, n) = w[tap][kq*8 + j][nb*16 + n]
+    w1 = rng.normal(size=(3, 3, 32, 32)).astype(np.float32)
+    h = pack_oflow_head_kernel(w1)
+    assert h.shape == (144, 64)
+    for (tap, j, nb, kq, n) in [(0, 0, 0, 0, 0), (4, 7, 1, 3, 15), (8, 3, 0, 2, 9)]:
+        assert h[(tap * 8 + j) * 2 + nb, kq * 16 + n] == w1[tap // 3, tap % 3, kq * 8 + j, nb * 16 + n]
+    # oflow_tail2's upconv0: fragment t = tap*8 + j of lane (kq, n) = w[tap][n][kq*8 + j]  (conv2d_transpose: [3,3,Cout,Cin])
+    wu = rng.normal(size=(3, 3, 16, 32)).astype(np.float32)
+    u = pack_oflow_upconv_kernel(wu)
+    assert u.shape == (72, 64)
+    for (tap, j, kq, n) in [(0, 0, 0, 0), (5, 6, 3, 11), (8, 7, 1, 15)]:
+        assert u[tap * 8 + j, kq * 16 + n] == wu[tap // 3, tap % 3, n, kq * 8 + j]
+    # conv6: fragment t = tap*12 + j of lane (kq, n) = w[tap][kq*12 + j][n]
+    w6 = rng.normal(size=(3, 3, 48, 16)).astype(np.float32)
+    t6 = pack_oflow_tail_kernel(w6)
+    assert t6.shape == (108, 64)
+    for (tap, j, kq, n) in [(0, 0, 0, 0), (7, 11, 3, 15), (3, 5, 2, 8)]:
+        assert t6[tap * 12 + j, kq * 16 + n] == w6[tap // 3, tap % 3, kq * 12 + j, n]
+    # single-kernel Winograd: u2[((ci/8)*16 + 4*xi + nu)*cout_pad + co][ci%8] = (G g G^T)[xi][nu]  (include/kfnet_hip.h)
+    ww = rng.normal(size=(3, 3, 16, 24)).astype(np.float32)
+    u2 = pack_winograd_fused_kernel(ww).reshape(2, 16, 32, 8)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    for (ci, co) in [(0, 0), (9, 23), (15, 7)]:
+        U = G @ ww[:, :, ci, co].astype(np.float64) @ G.T
+        assert np.allclose(u2[ci // 8, :, co, ci % 8].reshape(4, 4), U, rtol=1e-6, atol=1e-7)
+    assert np.all(u2[:, :, 24:, :] == 0)
+
+
 def test_variable_scope_names():
     g = Graph()
     with variable_scope('A'):
