@@ -83,6 +83,9 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=16,
                     help='frames of the CPU baseline (BASELINE config 1 is a 16-frame 480x640 sequence)')
     ap.add_argument('--no-kalman-roofline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='c3 on one GPU: skip the config5_960x540 / config2_single_frame blocks')
+    ap.add_argument('--no-eval-png', action='store_true', help='skip the PNG -> coord_<i>.npy end-to-end block')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
@@ -169,12 +172,11 @@ def kalman_roofline(device, S=256, T=64, H=60, W=80):
     from kfnet_amd import _lib
     lib = _lib.load()
     hw = H * W
-    g = torch.Generator(device='cpu').manual_seed(0)
-    flow = (torch.randn(S * T * hw * 2, generator=g) * 1.5).to(device)
-    sig = (torch.rand(S * T * hw, generator=g) * 0.05 + 0.001).to(device)
-    meas = torch.randn(S * T * hw * 4, generator=g)
+    g = torch.Generator(device=device).manual_seed(0)     # generated in HBM: 1.5 G values at T = 256
+    flow = torch.randn(S * T * hw * 2, generator=g, device=device) * 1.5
+    sig = torch.rand(S * T * hw, generator=g, device=device) * 0.05 + 0.001
+    meas = torch.randn(S * T * hw * 4, generator=g, device=device)
     meas[3::4] = meas[3::4].abs() * 0.3 + 0.05
-    meas = meas.to(device)
     state = meas[:S * hw * 4].clone()
     rec = torch.empty(S * T * hw * 4, device=device)
     d = _lib.KalmanDesc(S=S, T=T, H=H, W=W, t0=1, reset_period=500, min_uncertainty=1e-5, nis_gate=0.0,
@@ -253,29 +255,87 @@ def kalman_fuse_roofline(device, P=256 * 64 * 4800):
             'shape': 'P=%d px, 48 B/px (BuildKFCoord only)' % P, 'avg_launch_ms': round(ms, 4)}
 
 
-def host_streamed(eng, host_frames, dev_frames):
-    """PCIe-inclusive rate (never the headline `value`): the same frames start in pinned HOST
-    memory and the records end there; uploads (0.92 MB/frame) and downloads (76.8 KB/frame)
-    run on their own streams beside the compute (kfnet_amd/pipeline.py)."""
+def host_streamed(eng, host_frames, dev_frames, chunk=None):
+    """SURVEY 8(d)'s frames/sec definition (H2D of the uint8 frames and D2H of the records INSIDE the timed
+    region): the same frames start in pinned HOST memory and the records end there; uploads (0.92 MB/frame) and
+    downloads (76.8 KB/frame) run on their own streams beside the compute (kfnet_amd/pipeline.py)."""
     import torch
     from kfnet_amd.pipeline import ChunkLoader, StreamedSequence
     K = int(host_frames.shape[0])
-    chunk = max(eng.B, min(4 * eng.B, eng.max_chunk))
+    chunk = int(chunk) if chunk else max(eng.B, min(4 * eng.B, eng.max_chunk))
     runner = StreamedSequence(eng, chunk)
     pinned = torch.from_numpy(np.ascontiguousarray(host_frames)).pin_memory()
     chunks = [(lo, pinned[lo:lo + chunk]) for lo in range(0, K, chunk)]
     for _ in runner.run(chunks[:2]):       # warm the copy streams
         pass
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    dts = []
     last = None
-    for lo, rec in runner.run(chunks):
-        last = (lo, rec)
-    dt = time.perf_counter() - t0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for lo, rec in runner.run(chunks):
+            last = (lo, rec.copy())
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
     ref = eng.process(dev_frames, t0=0)[last[0]:last[0] + last[1].shape[0]].cpu().numpy()
-    return {'value': round(K / dt, 3), 'unit': 'frames/s', 'chunk': chunk,
+    return {'value': round(K / dt, 3), 'unit': 'frames/s', 'frames': K, 'chunk': chunk, 'passes': len(dts),
+            'ms_per_step': round(dt * 1e3 / K, 4),
             'bit_identical_to_resident_run': bool(np.array_equal(ref, last[1])),
-            'note': 'frames from pinned host memory, records back to host; H2D/D2H overlapped with compute'}
+            'note': 'frames start in pinned host memory, records end in host memory; H2D (0.92 MB/frame) and D2H '
+                    '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
+
+
+def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32):
+    """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
+    (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
+    package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the
+    synthetic sequence's frames written to a temporary directory first (untimed)."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from kfnet_amd.KFNet import eval as KE
+    from kfnet_amd.tools.io import read_lines
+    T = int(host_frames.shape[0])
+    cores = os.cpu_count() or 8
+    workers = max(4, min(32, cores // 2))
+    root = tempfile.mkdtemp(prefix='kfn_png_')
+    try:
+        inp, outd = os.path.join(root, 'in'), os.path.join(root, 'out')
+        os.makedirs(inp)
+        os.makedirs(outd)
+        paths = [os.path.join(inp, 'frame_%05d.png' % i) for i in range(T)]
+        t_w = time.perf_counter()
+        with ThreadPoolExecutor(workers) as pool:     # (untimed set-up: random textures do not compress; level 1)
+            list(pool.map(lambda i: Image.fromarray(host_frames[i]).save(paths[i], compress_level=1), range(T)))
+        t_w = time.perf_counter() - t_w
+        with open(os.path.join(inp, 'image_list.txt'), 'w') as f:
+            f.write('\n'.join(paths) + '\n')
+        np.savetxt(os.path.join(inp, 'transform.txt'), transform_txt)   # what transform.txt holds: get_transform inverts it
+        image_paths = read_lines(os.path.join(inp, 'image_list.txt'))
+        transform = KE.get_transform(os.path.join(inp, 'transform.txt'))
+        png_mb = sum(os.path.getsize(p) for p in paths) / 1e6
+        tele = Telemetry(dev_index)
+        with tele:
+            t0 = time.perf_counter()
+            rec = KE.eval(image_paths, transform, Wt, outd, image_size=(eng.H, eng.W), chunk=chunk, verbose=False,
+                          decode_workers=workers, engine=eng)
+            dt = time.perf_counter() - t0
+        files = sorted(os.listdir(outd))
+        on_disk = np.stack([np.load(os.path.join(outd, 'coord_%d.npy' % i)) for i in (0, T // 2, T - 1)])
+        same = bool(np.array_equal(rec, resident_records)) and bool(np.array_equal(on_disk, resident_records[[0, T // 2, T - 1]]))
+        # (transform.txt went through text: it must come back as the very matrix the resident run used)
+        t_same = bool(np.array_equal(np.asarray(transform, np.float32), np.asarray(T4, np.float32)))
+        return {'value': round(T / dt, 3), 'unit': 'frames/s', 'frames': T, 'chunk': chunk, 'seconds': round(dt, 3),
+                'decode_threads': workers, 'host_cores': cores, 'npy_files_written': len(files),
+                'png_megabytes': round(png_mb, 1), 'png_write_seconds_untimed': round(t_w, 2),
+                'gpu_busy_pct': (tele.summary().get('busy_pct') or {}).get('mean'),
+                'bit_identical_to_resident_run': same, 'transform_roundtrip_exact': t_same,
+                'note': 'image_list.txt -> PIL PNG decode on a thread pool -> pinned staging -> H2D -> towers + scan -> D2H '
+                        '-> coord_<i>.npy (np.save on 2 writer threads); the first chunk\'s decode is exposed, later '
+                        'chunks decode while the GPU computes'}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline(frames, W, T4, steps):
@@ -478,7 +538,7 @@ class Telemetry(object):
                 'busy_pct': agg('busy_pct')}
 
 
-def config3_literal(args, Wt, T4, device, dev_index, frames=256, batch=32):
+def config3_literal(args, Wt, T4, transform_txt, device, dev_index, frames=256, batch=32):
     """BASELINE configs[2] to the letter -- ONE 256-frame 480x640 sequence, tower batch 32 -- for driver
     runs whose --steps is smaller (per-step work is the same; this removes the extrapolation)."""
     import torch
@@ -487,22 +547,33 @@ def config3_literal(args, Wt, T4, device, dev_index, frames=256, batch=32):
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=batch, transform=T4, reset_period=500,
                       max_chunk=frames, device=str(device))
     eng.two_streams = not args.one_stream
-    dev = eng.upload_frames(synthetic_sequence(frames, args.height, args.width, seed=1))
+    host = synthetic_sequence(frames, args.height, args.width, seed=1)
+    dev = eng.upload_frames(host)
     eng.process(dev[:2 * batch], t0=0)
     torch.cuda.synchronize()
     tele = Telemetry(dev_index)
     with tele:
         times = timed_repetitions(lambda: eng.process(dev, t0=0), None, device, None, max(args.min_seconds, 3.0))
     med = float(np.median(times))
+    out = {'value': round(frames / med, 3), 'unit': 'frames/s', 'ms_per_step': round(med * 1e3 / frames, 4),
+           'frames': frames, 'tower_batch': batch, 'repetitions': len(times),
+           'timed_seconds': round(float(np.sum(times)), 3),
+           'ms_per_step_min_max': [round(min(times) * 1e3 / frames, 4), round(max(times) * 1e3 / frames, 4)],
+           'gpu_telemetry': tele.summary(),
+           'note': 'the literal BASELINE configs[2] pass (256-frame sequence, frames resident in HBM -> records in '
+                   'HBM), median of the repetitions; `value` of this line is the same path at --steps frames'}
+    extra = {}
+    if not args.no_host_streamed:
+        # SURVEY 8(d)'s definition of the metric (transfers inside the timed region) on the SAME 256-frame sequence
+        extra['host_streamed'] = host_streamed(eng, host, dev, chunk=128)
+        if not args.no_eval_png:
+            resident = eng.process(dev, t0=0).cpu().numpy()
+            extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index)
+            hs = extra['host_streamed']['value']
+            extra['eval_png_end_to_end']['fraction_of_host_streamed'] = round(extra['eval_png_end_to_end']['value'] / hs, 4)
     del eng, dev
     torch.cuda.empty_cache()
-    return {'value': round(frames / med, 3), 'unit': 'frames/s', 'ms_per_step': round(med * 1e3 / frames, 4),
-            'frames': frames, 'tower_batch': batch, 'repetitions': len(times),
-            'timed_seconds': round(float(np.sum(times)), 3),
-            'ms_per_step_min_max': [round(min(times) * 1e3 / frames, 4), round(max(times) * 1e3 / frames, 4)],
-            'gpu_telemetry': tele.summary(),
-            'note': 'the literal BASELINE configs[2] pass (256-frame sequence, frames resident in HBM -> records in '
-                    'HBM), median of the repetitions; `value` of this line is the same path at --steps frames'}
+    return out, extra
 
 
 def auto_batch(K, lo=15, hi=32, prefer=32):
@@ -549,9 +620,11 @@ def timed_repetitions(run_once, dist, device, backend, min_seconds, max_reps=400
             return times
 
 
-def bench_c2(args, device):
+def measure_c2(args, device, min_seconds=None, min_steps=None):
     """BASELINE configs[1]: SCoordNet alone on ONE 480x640 frame (batch 1, no recurrence) --
     a latency number: ms per frame, eager launches and hipGraph replay."""
+    min_seconds = args.min_seconds if min_seconds is None else min_seconds
+    min_steps = args.steps if min_steps is None else min_steps
     import torch
     from kfnet_amd import _lib
     from kfnet_amd.cnn_wrapper.SCoordNet import SCoordNet
@@ -576,19 +649,19 @@ def bench_c2(args, device):
     def time_loop(fn, min_s):
         lat = []
         t_all = time.perf_counter()
-        while time.perf_counter() - t_all < min_s or len(lat) < args.steps:
+        while time.perf_counter() - t_all < min_s or len(lat) < min_steps:
             t0 = time.perf_counter()
             fn()
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
         return np.array(lat)
-    eager = time_loop(lambda: g.run(stream.cuda_stream), args.min_seconds)
+    eager = time_loop(lambda: g.run(stream.cuda_stream), min_seconds)
     cap = torch.cuda.Stream(device=device)
     cg = torch.cuda.CUDAGraph()
     with torch.cuda.stream(cap):
         with torch.cuda.graph(cg, stream=cap):
             g.run(torch.cuda.current_stream(device).cuda_stream)
-    graph = time_loop(cg.replay, args.min_seconds)
+    graph = time_loop(cg.replay, min_seconds)
     # device-side time of one frame (events; excludes host launch gaps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -615,7 +688,13 @@ def bench_c2(args, device):
                         'traffic': None,
                         'note': 'algorithmic (nominal dense) FLOPs of the 12 layers = %.3f GFLOP / device time; '
                                 'the Winograd layers execute 16/36 of theirs, so this can exceed 1' % (flops / 1e9)}}
-    print(json.dumps(out))
+    del g, cg
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_c2(args, device):
+    print(json.dumps(measure_c2(args, device)))
 
 
 def c5_traffic(kernel, batch):
@@ -629,18 +708,20 @@ def c5_traffic(kernel, batch):
                 this_run_tower_batch=batch)
 
 
-def bench_c5(args, device):
+def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
     """BASELINE configs[4]: 960x540 input (68x120 grid), S independent sequences of T frames,
     fp16 conv operands (fp32 accumulate) + fp32 Kalman scan advancing all sequences in one
     launch.  A step = one 540x960 frame."""
+    min_seconds = args.min_seconds if min_seconds is None else min_seconds
     import torch
     from kfnet_amd.KFNet.eval import get_transform  # noqa: F401  (package's own; no oracle import here)
     from kfnet_amd.engine import KFNetEngine
     from kfnet_amd.synth import synthetic_sequence, synthetic_transform
     from kfnet_amd.weights import synthetic_weights
     H, W = 540, 960
-    S, T = args.sequences, min(args.steps, 64)
-    B = args.batch or auto_batch(T, 8, 16, 16)
+    S = args.sequences
+    T = min(args.steps, 64) if T is None else T
+    B = (args.batch if args.config == 'c5' else 0) or auto_batch(T, 8, 16, 16)
     Wt = synthetic_weights(1234)
     T4 = np.linalg.inv(synthetic_transform())
     eng = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * T,
@@ -651,7 +732,7 @@ def bench_c5(args, device):
     torch.cuda.synchronize()
     tele = Telemetry(device.index if device.index is not None else 0)
     with tele:
-        times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, args.min_seconds)
+        times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, min_seconds)
     med = float(np.median(times))
     PF = min(T, 16)     # frames per sequence of the parity sample
     rec16 = eng.process_sequences(dev)[:, :PF].cpu().numpy().copy()
@@ -699,7 +780,7 @@ def bench_c5(args, device):
            'tolerance': 'own tolerance (tests/test_gpu_e2e.py::test_config5_tolerance_at_bench_scale): coord max-abs <= 2e-2, '
                         'confidence max-rel <= 5e-2 on every pixel away from the steps of the reference sampler; see '
                         'parity_vs_fp32_path'}
-    if not args.no_cpu_baseline:
+    if with_parity:
         # parity of the fp16 path against the fp32 HIP path on the same frames (the fp32 path is
         # itself checked against the oracle in tests/)
         del eng
@@ -722,7 +803,79 @@ def bench_c5(args, device):
                       'pixel-frames, kfnet_amd/tools/parity.py); `outside_tolerance_fraction` of all pixel-frames actually '
                       'deviate by more' % (PF, C5_DELTA_PX))
         out['parity_vs_fp32_path'] = mp
-    print(json.dumps(out))
+        del eng32
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_c5(args, device):
+    print(json.dumps(measure_c5(args, device, with_parity=not args.no_cpu_baseline)))
+
+
+def chain_timing(run_with_timer, dist, device, world):
+    """One extra, instrumented sharded pass (NOT a timed repetition): every rank stamps heavy-end / recv-end /
+    scan-end / send-end with HIP events relative to an origin taken right behind a barrier + synchronize, so the
+    stamps of different ranks sit on the node's monotonic clock.  Collective: every rank calls it.
+      scan_chain_ms  = last rank's scan end - rank 0's scan start: the serial part of the sharded configuration
+                       (world scans + world-1 hand-offs; it hides behind the heavy phase only on rank 0 .. world-2);
+      handoff_us     = per rank: recv (time from its own heavy-phase end until the state has arrived -- includes
+                       waiting for the predecessor's scan) and send (issue -> complete on the stream);
+      handoff_us_net = (scan_chain_ms - sum of the ranks' scan times) / (world - 1): what one hand-off adds."""
+    import torch
+    from kfnet_amd.dist import ChunkTimer
+    timer = ChunkTimer(torch, device)
+    torch.cuda.synchronize()
+    dist.barrier()
+    timer.origin()
+    run_with_timer(timer)
+    torch.cuda.synchronize()
+    mine = timer.summary()
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    t_abs = lambda r, name: allr[r]['t_origin_monotonic_s'] * 1e3 + allr[r]['ms_since_origin'][name]
+    chain = t_abs(world - 1, 'scan_end') - t_abs(0, 'recv_end')
+    scans = [a['scan_ms'] for a in allr]
+    return {'scan_chain_ms': round(chain, 4),
+            'scan_ms_per_rank': [round(x, 4) for x in scans],
+            'heavy_ms_per_rank': [round(a['heavy_ms'], 3) for a in allr],
+            'handoff_us': [{'recv_wait_us': None if a['recv_wait_us'] is None else round(a['recv_wait_us'], 1),
+                            'send_us': None if a['send_us'] is None else round(a['send_us'], 1)} for a in allr],
+            'handoff_us_net': round((chain - sum(scans)) * 1e3 / max(world - 1, 1), 1),
+            'note': 'one instrumented pass after the timed repetitions; HIP events on each rank\'s stream, origins '
+                    'aligned through a barrier and time.monotonic()'}
+
+
+def config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index, frames_per_rank=256, batch=32):
+    """BASELINE configs[3] to the letter when the driver runs 8 ranks with fewer steps: ONE 2048-frame sequence,
+    rank r owns frames [256 r, 256 r + 256), Kalman state handed rank -> rank (resets at 500/1000/1500/2000 fall
+    inside chunks).  Collective: every rank calls it; returns the block (the same on every rank)."""
+    import torch
+    from kfnet_amd.dist import needs_state, run_chunk
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    K = frames_per_rank
+    lo = rank * K
+    need_prev = 1 if needs_state(lo, 500) else 0
+    host = synthetic_sequence(K + need_prev, args.height, args.width, seed=2, start=lo - need_prev)
+    eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=batch, transform=T4, reset_period=500,
+                      max_chunk=K, device=str(device))
+    eng.two_streams = not args.one_stream
+    dev_all = eng.upload_frames(host)
+    prev = dev_all[0] if need_prev else None
+    dev = dev_all[need_prev:]
+    run = lambda timer=None: run_chunk(eng, dev, lo, rank, world, link, prev, timer=timer)
+    run()
+    torch.cuda.synchronize()
+    times = timed_repetitions(run, dist, device, backend, max(args.min_seconds, 3.0))
+    med = float(np.median(times))
+    chain = chain_timing(run, dist, device, world)
+    del eng, dev_all
+    torch.cuda.empty_cache()
+    return {'value': round(K * world / med, 3), 'unit': 'frames/s', 'frames_total': K * world, 'frames_per_rank': K,
+            'tower_batch': batch, 'ms_per_step': round(med * 1e3 / K, 4), 'repetitions': len(times),
+            'timed_seconds': round(float(np.sum(times)), 3), 'handoff': chain,
+            'note': 'the literal BASELINE configs[3]: one %d-frame sequence over %d ranks, median repetition, '
+                    'MAX over ranks' % (K * world, world)}
 
 
 def main():
@@ -840,6 +993,13 @@ def main():
         'self_launched': bool(os.environ.get('KFN_BENCH_SELF_LAUNCHED')),
         'gpu_telemetry_rank0': tele.summary(),
     }
+    # ---- collective extras of a multi-rank run (every rank takes part; rank 0 reports) -------------------
+    if dist is not None:
+        out['handoff'] = chain_timing(lambda timer: run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev, timer=timer),
+                                      dist, device, world)
+        if world == 8 and K < 256 and not args.no_config3 and (args.height, args.width) == (480, 640) \
+                and args.conv_operands == 'f32':
+            out['config4_2048_frames'] = config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index)
     if rank == 0:
         rows = per_kernel_profile(eng, dev_frames)
         heavy_ms = sum(r[3] for r in rows)
@@ -863,27 +1023,27 @@ def main():
                 'command': 'bench.py --steps 64 --batch 32', 'tower_batch': 32}), this_run_tower_batch=B)
         out['roofline'] = {
             'kernel': dom, 'bound': 'mfma',
-            # FLOPs the fp32 MFMA pipe actually executes in this kernel / its time.  For the direct
-            # implicit GEMM (<...,0>) that IS the algorithmic (nominal dense) FLOP count of SURVEY
-            # App. C; the Winograd GEMMs (<...,2>) execute 16/36 of it, so the hardware-utilisation
-            # number is reported here and the algorithmic rate beside it.
+            # FLOPs the fp32 MFMA pipe actually executes in this kernel / its time.  For the direct implicit GEMM
+            # that IS the algorithmic (nominal dense) FLOP count of SURVEY App. C; the Winograd kernels execute
+            # 16/36 (F(2x2,3x3)) or 9/36 (F(4x4,3x3)) of it, so the hardware-utilisation number is reported here and
+            # the algorithmic rate beside it.
             'achieved': round(tf_exec, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'traffic': traffic,
             'algorithmic_tflops': round(tf, 2), 'algorithmic_frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': ('wino3_kernel / wino2_kernel = single-kernel Winograd F(2x2,3x3) (kfn_conv2d_winograd_fused, fp32; four waves '
-                     'sharing one input transform through LDS / one wave per 32 output channels): achieved = FLOPs the '
-                     'MFMAs execute (16/36 of the nominal direct-convolution FLOPs + tile-block padding) / time, algorithmic_* '
-                     'counts the nominal FLOPs of SURVEY App. C and may exceed the MFMA peak; traffic = PMC HBM-side bytes per '
-                     'launch, averaged over the launches of a batch like avg_launch_ms. conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,'
-                     'PREC>: MODE 0 direct implicit GEMM, 1 transposed, 2 the 16 GEMMs of the two-kernel Winograd form, 3 conv0 '
-                     'with the cost volume in the loader'),
+            'note': ('wino3_kernel / wino2_kernel = single-kernel Winograd F(2x2,3x3), wino4_kernel = F(4x4,3x3) '
+                     '(kfn_conv2d_winograd_fused, fp32; the waves of a workgroup share one input transform through LDS): '
+                     'achieved = FLOPs the MFMAs execute (16/36 resp. 9/36 of the nominal direct-convolution FLOPs + tile-block '
+                     'padding) / time, algorithmic_* counts the nominal FLOPs of SURVEY App. C and may exceed the MFMA peak; '
+                     'traffic = PMC HBM-side bytes per launch, averaged over the launches of a batch like avg_launch_ms. '
+                     'conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,PREC>: MODE 0 direct implicit GEMM, 1 transposed, 2 the 16 GEMMs of the '
+                     'two-kernel Winograd form, 3 conv0 with the cost volume in the loader'),
             'launches_per_batch': n_dom,
             'algorithmic_gflop_per_launch_avg': round(fl_dom / n_dom / 1e9, 3),
             'executed_gflop_per_launch_avg': round(ex_dom / n_dom / 1e9, 3),
             'avg_launch_ms': round(ms_dom / n_dom, 4),
             'share_of_step_time': round(ms_dom / heavy_ms, 4),
-            'all_conv_mfma_algorithmic_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+            'all_conv_mfma_algorithmic_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
             'all_conv_mfma_share_of_step_time': round(conv_ms / heavy_ms, 4),
         }
         out['kernels_ms_per_batch'] = {k: {'launches': v[0], 'ms': round(v[2], 4),
@@ -903,19 +1063,27 @@ def main():
         out['top_layers'] = [{'op': r[0], 'ms': round(r[3], 3),
                               'tflops': round(r[2] / (r[3] * 1e-3) / 1e12, 1) if r[2] else None} for r in top]
         if not args.no_kalman_roofline:
-            out['roofline_kalman'] = kalman_roofline(device)
+            out['roofline_kalman'] = kalman_roofline(device)                        # S = 256 x T = 64
+            out['roofline_kalman_T256'] = kalman_roofline(device, S=256, T=256)     # SURVEY 8(d)'s default shape
             out['roofline_kalman_fuse'] = kalman_fuse_roofline(device)
-        if world == 1 and K < 256 and not args.no_config3 and (args.height, args.width) == (480, 640) \
-                and args.conv_operands == 'f32':
-            out['config3_256_frames'] = config3_literal(args, Wt, T4, device, dev_index)
-        if world == 1 and not args.no_host_streamed:
+        single_480 = world == 1 and (args.height, args.width) == (480, 640) and args.conv_operands == 'f32'
+        if single_480 and not args.no_config3:
+            # the literal 256-frame pass of BASELINE configs[2], and on the same engine / sequence the two
+            # transfer-inclusive forms: frames from pinned host memory, and PNG files -> coord_<i>.npy files
+            c3, extra = config3_literal(args, Wt, T4, synthetic_transform(), device, dev_index)
+            if K < 256:
+                out['config3_256_frames'] = c3
+            out.update(extra)
+        elif world == 1 and not args.no_host_streamed:
             out['host_streamed'] = host_streamed(eng, frames_all[need_prev:], dev_frames)
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames_all[need_prev:need_prev + max(args.cpu_steps, 2)]
+            if host_frames.shape[0] < max(args.cpu_steps, 2):     # --steps below config 1's 16 frames
+                host_frames = synthetic_sequence(max(args.cpu_steps, 2), args.height, args.width, seed=1)
             cb, cpu_recs = cpu_baseline(host_frames, Wt, T4, args.cpu_steps)
             cb['sample_is_config1'] = bool(args.cpu_steps == 16)
             out['cpu_baseline'] = cb
-            gpu_recs = eng.process(dev_frames[:args.cpu_steps], t0=0).cpu().numpy()
+            gpu_recs = eng.process(eng.upload_frames(host_frames[:args.cpu_steps]), t0=0).cpu().numpy()
             out['parity_vs_cpu_restatement'] = {
                 'frames': int(args.cpu_steps),
                 'coord_max_abs': float(np.abs(gpu_recs[..., :3] - cpu_recs[..., :3]).max()),
@@ -925,23 +1093,63 @@ def main():
             if not args.no_alt_modes and args.conv_operands == 'f32':
                 # NOT the headline: same workload with every wide forward conv evaluated as
                 # hi*hi + hi*lo + lo*hi of fp16-split operands on the fp16 MFMA (fp32 accumulate)
-                del eng
-                torch.cuda.empty_cache()
                 eng2 = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
-                                   max_chunk=max(K, Wm, B), device=str(device), conv_operands='f16x3')
+                                   max_chunk=max(K, Wm, B, args.cpu_steps), device=str(device), conv_operands='f16x3')
                 eng2.process(dev_frames[:min(Wm, K)], t0=0)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                rec2 = eng2.process(dev_frames, t0=0)
+                eng2.process(dev_frames, t0=0)
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t0
-                g2 = rec2[:args.cpu_steps].cpu().numpy()
+                g2 = eng2.process(eng2.upload_frames(host_frames[:args.cpu_steps]), t0=0).cpu().numpy()
+                del eng2
                 out['alt_mode_f16x3'] = {
                     'value': round(K / dt2, 3), 'unit': 'frames/s',
                     'dtype': 'f32 emulated: operands split into fp16 hi+lo, 3 fp16-MFMA products, f32 accumulate',
                     'coord_max_abs_vs_cpu': float(np.abs(g2[..., :3] - cpu_recs[..., :3]).max()),
                     'conf_max_rel_vs_cpu': float((np.abs(g2[..., 3] - cpu_recs[..., 3]) / np.abs(cpu_recs[..., 3])).max()),
                     'note': 'opt-in (KFNetEngine(conv_operands="f16x3")); reported beside, never as, the fp32 headline value'}
+        if single_480 and not args.no_extra_configs:
+            # BASELINE configs[4] and configs[1] inside the driver's one line (VERDICT r3 Next #1)
+            del eng
+            torch.cuda.empty_cache()
+            c5 = measure_c5(args, device, T=64, min_seconds=2.0, with_parity=True)
+            out['config5_960x540'] = {k: c5[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'steps', 'repetitions', 'config',
+                                                          'roofline', 'gpu_telemetry', 'kernels_ms_per_batch', 'tolerance',
+                                                          'parity_vs_fp32_path') if k in c5}
+            c2 = measure_c2(args, device, min_seconds=1.0, min_steps=50)
+            out['config2_single_frame'] = {k: c2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'latency_ms',
+                                                               'roofline')}
+        # ---- the numbers a reader wants first, LAST in the line (a log tail shows them) ------------------
+        hs, c5b, c2b = out.get('host_streamed'), out.get('config5_960x540'), out.get('config2_single_frame')
+        if hs is not None:
+            out['value_streamed'] = hs['value']
+        pick = lambda d, *ks: None if d is None else {k: d.get(k) for k in ks}
+        summ = {
+            'value_hbm_resident_frames_per_s': out['value'],
+            'value_streamed_h2d_d2h_inclusive_frames_per_s': out.get('value_streamed'),
+            'value_streamed_is': None if hs is None else '%d frames, chunk %d, from pinned host memory' % (hs['frames'], hs['chunk']),
+            'config3_256_frames': pick(out.get('config3_256_frames'), 'value', 'ms_per_step'),
+            'eval_png_end_to_end': pick(out.get('eval_png_end_to_end'), 'value', 'fraction_of_host_streamed', 'decode_threads',
+                                        'gpu_busy_pct', 'bit_identical_to_resident_run'),
+            'roofline_frac_dominant_kernel': [out['roofline']['kernel'], out['roofline']['frac']],
+            'roofline_kalman_frac': None if 'roofline_kalman' not in out else {
+                'S256xT64': [out['roofline_kalman']['frac'], out['roofline_kalman']['frac_on_actual_hbm_bytes']],
+                'S256xT256': [out['roofline_kalman_T256']['frac'], out['roofline_kalman_T256']['frac_on_actual_hbm_bytes']],
+                'is': '[76 B/px definition, bytes that really cross HBM] / 8 TB/s'},
+            'cpu_baseline_frames_per_s': None if 'cpu_baseline' not in out else [out['cpu_baseline']['value'], out['cpu_baseline']['cores']],
+            'parity_vs_cpu': pick(out.get('parity_vs_cpu_restatement'), 'coord_max_abs', 'conf_max_rel'),
+            'config5_960x540': None if c5b is None else {
+                'value': c5b['value'], 'ms_per_step': c5b['ms_per_step'],
+                'roofline': pick(c5b['roofline'], 'kernel', 'achieved', 'frac'),
+                'sclk_mhz_mean': ((c5b.get('gpu_telemetry') or {}).get('sclk_mhz') or {}).get('mean'),
+                'parity_vs_fp32_path': pick(c5b.get('parity_vs_fp32_path'), 'unmasked_outside_tolerance', 'masked_fraction',
+                                            'outside_tolerance_fraction', 'frames', 'sequences', 'crossings')},
+            'config2_single_frame_ms': None if c2b is None else c2b['latency_ms'],
+            'handoff': pick(out.get('handoff'), 'scan_chain_ms', 'handoff_us_net'),
+            'config4_2048_frames': pick(out.get('config4_2048_frames'), 'value', 'ms_per_step'),
+        }
+        out['summary'] = {k: v for k, v in summ.items() if v is not None}
         print(json.dumps(out))
     if link is not None:
         link.close()

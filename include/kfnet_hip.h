@@ -35,7 +35,10 @@ extern "C" {
 #define KFN_ERR_HIP (-2)
 #define KFN_ERR_UNSUPPORTED (-3)
 
-#define KFN_ABI_VERSION 4
+/* 5 (round 4): kfn_conv_desc starts with `struct_size` (the struct had grown at its end -- weights_path -- without a
+ * version bump); kfn_comm_rank asks RCCL; kfn_kalman_scan_ex no longer allocates.  A host checks
+ * kfn_abi_version() == KFN_ABI_VERSION once after loading the library. */
+#define KFN_ABI_VERSION 5
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -71,6 +74,11 @@ int kfn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
  * rounded up to a multiple of 32 with zero rows.  Padding is TF 'SAME'.
  */
 typedef struct kfn_conv_desc {
+  int32_t struct_size;  /* = sizeof(kfn_conv_desc) AS THE CALLER COMPILED IT (use KFN_CONV_DESC_INIT).  The struct only
+                         * ever grows at its end: the library copies struct_size bytes and reads every field beyond them
+                         * as 0 (= AUTO / fp32), so a host built against an older header keeps working and the library
+                         * never reads past the caller's object.  Smaller than the first-round struct (through `config`),
+                         * not a multiple of 4, or larger than the library's own struct: KFN_ERR_ARG. */
   int32_t N, H, W, Cin; /* logical input shape */
   int32_t ldx;          /* input pixel stride (floats), >= Cin, multiple of 4 */
   int32_t Cout;         /* logical output channels */
@@ -98,6 +106,8 @@ typedef struct kfn_conv_desc {
                           * ds_write) / _LDS_DMA (global -> LDS directly, `buffer_load ... lds`, three weight buffers) /
                           * KFN_OPERANDS_LDS_DMA (the activation tile too) */
 } kfn_conv_desc;
+/* kfn_conv_desc d = KFN_CONV_DESC_INIT;  -- zero everything, set struct_size */
+#define KFN_CONV_DESC_INIT {(int32_t)sizeof(kfn_conv_desc)}
 
 #define KFN_WEIGHTS_AUTO 0
 #define KFN_WEIGHTS_VIA_REGISTERS 1
@@ -143,6 +153,9 @@ typedef struct kfn_conv_desc {
 #define KFN_CFG_256x16 10  /* 16-column tiles on v_mfma_f32_16x16x4_f32 for the 16-channel layers */
 #define KFN_CFG_128x16 11  /* (fp32 operands, no fused head epilogue)                               */
 #define KFN_CFG_256x64 12  /* 4 waves side by side in M, wave tile 64x64: the fp16-activation kernels on 64-channel layers */
+#define KFN_CFG_256x256 13    /* fp16 activations only: 4 waves, wave tile 128x128 (16 accumulators = 256 registers, one wave
+                               * per SIMD): half the LDS fragment reads and half the operand staging per MFMA of 128x256 */
+#define KFN_CFG_256x256_W8 14 /* fp16 activations only: 8 waves (2 x 4), wave tile 128x64, two waves per SIMD */
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);

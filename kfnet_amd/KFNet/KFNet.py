@@ -173,6 +173,10 @@ class KFNet():
         net_ops = self.oflownet.ops
         if not g.fuse_oflow_window:
             return
+        # kfn_oflow_tail2 needs 4 x 34 000 B of dynamic LDS per workgroup: gfx950's 160 KiB.  On a part with less the
+        # round-2 launches (gather + conv1a, upconv0 + kfn_oflow_tail) stay in place.
+        if getattr(g, 'lds_bytes_per_cu', 160 * 1024) < 136000:
+            return
         y0 = conv0.y
         tails = [op for op in net_ops if isinstance(op, OFlowTailOp)]
         if len(tails) != 1 or tails[0].logits is not None:
@@ -371,6 +375,15 @@ class KFNet():
                 g.storages.remove(vol.storage)
             self._fuse_oflow_window(tt, gp, conv0, new_ops[3], c)
             return
+        # the loader-generated volume feeds the DIRECT kernel: conv0 may have been built as a Winograd layer (3x3
+        # stride 1, 32 channels, 8x8 grid), whose kernel variable is packed [Cin/8][16][Cout][8] -- reset the packers
+        # to the [cout_pad][9 Cin] layout kfn_cost_volume_conv reads (silently wrong flow otherwise)
+        from ..graph import pack_bias, pack_conv_kernel
+        if conv0.kernel.storage is not None:
+            return   # already uploaded in another layout: keep the unfused pair of launches
+        conv0.kernel.pack = pack_conv_kernel
+        if conv0.bias is not None:
+            conv0.bias.pack = pack_bias
         fused = CostVolumeConvOp(feat_map1, feat_map2, conv0.y, conv0.kernel, conv0.bias, conv0.relu, window_size)
         g.ops[g.ops.index(conv0)] = fused
         g.ops.remove(cv[0])

@@ -94,11 +94,13 @@ def eval_sharded(image_paths, transform, weights, output_folder, rank, world, li
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=RESET_PERIOD, chunk=256, verbose=True, label_paths=None, labels=None,
-         decode_workers=8, device=None, metrics_sequence_length=1000):
+         decode_workers=8, device=None, metrics_sequence_length=1000, engine=None, save_workers=2):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
-    returns (records, metrics) in that case."""
+    returns (records, metrics) in that case.  `engine`: a ready KFNetEngine to run on (its batch / max_chunk / transform
+    are used; bench.py times the path without the one-off graph build); `save_workers`: threads that write the
+    coord_<i>.npy files behind the consumer loop (np.save releases the GIL in the file write)."""
     from ..engine import KFNetEngine
     from . import metrics as M
     from ..pipeline import ChunkLoader, StreamedSequence
@@ -107,16 +109,29 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     if device is None:   # --gpu N: everything (buffers, streams, launches) lives on the CURRENT device
         import torch
         device = 'cuda:%d' % torch.cuda.current_device()
-    eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform,
-                      reset_period=sequence_length, nis_gate=7.815 if nis else 0.0, max_chunk=chunk,
-                      emit_metrics=want_metrics, device=device)
+    eng = engine if engine is not None else KFNetEngine(
+        weights, image_size=image_size, batch=batch, transform=transform, reset_period=sequence_length,
+        nis_gate=7.815 if nis else 0.0, max_chunk=chunk, emit_metrics=want_metrics, device=device)
+    if engine is not None:
+        chunk = min(chunk, eng.max_chunk)
+        if want_metrics and not eng.emit_metrics:
+            raise ValueError('labels given, but the engine was built without emit_metrics')
     records, all_metrics = [], []
+    # coord_<i>.npy (KFNet/eval.py:121-126) written off the consumer thread: the next chunk's records can be
+    # fetched while the previous chunk's 76.8 KB files are still going to disk
+    from concurrent.futures import ThreadPoolExecutor
+    saver = ThreadPoolExecutor(max(1, int(save_workers))) if (output_folder and os.path.isdir(output_folder)) else None
+    pending_saves = []
+
+    def save_chunk(lo, rec):
+        for k in range(rec.shape[0]):
+            np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k])
 
     def emit(lo, rec):
+        rec = np.ascontiguousarray(rec, dtype=np.float32)
         records.append(rec)
-        if output_folder and os.path.isdir(output_folder):
-            for k in range(rec.shape[0]):
-                np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), rec[k].astype(np.float32))
+        if saver is not None:
+            pending_saves.append(saver.submit(save_chunk, lo, rec))
 
     # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239);
     # uploads / compute / downloads overlapped on three streams -- with or without labels
@@ -151,6 +166,10 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         elif verbose:
             print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
         k += 1
+    for f in pending_saves:
+        f.result()          # re-raise write errors; every file is on disk when eval() returns
+    if saver is not None:
+        saver.shutdown()
     records = np.concatenate(records) if records else np.zeros((0, eng.h, eng.w, 4), np.float32)
     if not want_metrics:
         return records

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
@@ -25,10 +25,18 @@ class KfnError(RuntimeError):
 
 
 class ConvDesc(C.Structure):
+    """kfn_conv_desc (include/kfnet_hip.h).  `struct_size` is filled in here: the library copies that many bytes and
+    reads every later field as 0, so the struct can grow at its end without breaking older hosts
+    (tests/test_host_logic.py::test_conv_desc_matches_header_and_integration_doc keeps the three field lists equal)."""
     _fields_ = [(n, C.c_int32) for n in (
-        'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
+        'struct_size', 'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
         'transposed', 'relu', 'epilogue', 'config', 'operand_dtype', 'wino_order', 'wino_form',
         'x_dtype', 'y_dtype', 'k_step', 'weights_path')]
+
+    def __init__(self, *args, **kw):
+        super(ConvDesc, self).__init__(*args, **kw)
+        if not self.struct_size:
+            self.struct_size = C.sizeof(ConvDesc)
 
 
 class KalmanDesc(C.Structure):

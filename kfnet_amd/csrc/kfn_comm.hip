@@ -27,6 +27,9 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -54,6 +57,9 @@ void load_rccl() {
   g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
   g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+  g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(sym("ncclCommUserRank"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(sym("ncclCommCount"));
+  g_rccl.CommCuDevice = reinterpret_cast<decltype(g_rccl.CommCuDevice)>(sym("ncclCommCuDevice"));
   g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
   g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
@@ -121,10 +127,28 @@ extern "C" int kfn_comm_destroy(kfn_comm* comm) {
   return rc;
 }
 
+// RCCL's OWN view of the communicator (ncclCommUserRank / ncclCommCount / ncclCommCuDevice), not an echo of what
+// kfn_comm_init was told: bench.py's `rccl_ranks` is this.  A communicator whose answers differ from the arguments
+// it was created with is reported as an error.
 extern "C" int kfn_comm_rank(const kfn_comm* comm, int* rank, int* nranks) {
   KFN_REQUIRE(comm != nullptr, "kfn_comm_rank: null communicator");
-  if (rank) *rank = comm->rank;
-  if (nranks) *nranks = comm->nranks;
+  KFN_REQUIRE(comm->comm != nullptr && g_rccl.CommUserRank && g_rccl.CommCount, "kfn_comm_rank: no RCCL communicator");
+  int r = -1, n = -1, dev = -1;
+  int rc = check_nccl(g_rccl.CommUserRank(comm->comm, &r), "ncclCommUserRank");
+  if (rc != KFN_OK) return rc;
+  rc = check_nccl(g_rccl.CommCount(comm->comm, &n), "ncclCommCount");
+  if (rc != KFN_OK) return rc;
+  if (g_rccl.CommCuDevice) {
+    rc = check_nccl(g_rccl.CommCuDevice(comm->comm, &dev), "ncclCommCuDevice");
+    if (rc != KFN_OK) return rc;
+    if (dev != comm->device)
+      return kfn::fail(KFN_ERR_HIP, "kfn_comm_rank: RCCL reports device %d, the communicator was created on %d", dev, comm->device);
+  }
+  if (r != comm->rank || n != comm->nranks)
+    return kfn::fail(KFN_ERR_HIP, "kfn_comm_rank: RCCL reports rank %d of %d, the communicator was created as %d of %d", r, n,
+                     comm->rank, comm->nranks);
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
   return KFN_OK;
 }
 

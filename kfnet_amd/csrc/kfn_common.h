@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <cstddef>
 #include <atomic>
 #include <cstdint>
 #include "../../include/kfnet_hip.h"
@@ -57,6 +58,32 @@ inline int set_max_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// kfn_conv_desc crosses the ABI by pointer and grows at its end; `struct_size` (first member) says how many bytes the
+// CALLER's object has.  Every entry point works on a full-size copy whose missing tail is zero (= AUTO / fp32
+// defaults) and never touches the caller's memory beyond struct_size.
+inline int conv_desc_in(const kfn_conv_desc* in, kfn_conv_desc* out, const char* who) {
+  if (in == nullptr) return fail(KFN_ERR_ARG, "%s: null descriptor", who);
+  const int32_t sz = in->struct_size;
+  const int32_t min_sz = (int32_t)(offsetof(kfn_conv_desc, config) + sizeof(int32_t));   // the first-round struct
+  if (sz < min_sz || sz > (int32_t)sizeof(kfn_conv_desc) || (sz & 3) != 0)
+    return fail(KFN_ERR_ARG,
+                "%s: kfn_conv_desc.struct_size = %d (this library: %d bytes, minimum %d) -- set it to sizeof(kfn_conv_desc) "
+                "(KFN_CONV_DESC_INIT); hosts built for ABI <= 4 (no struct_size member) must be rebuilt against ABI %d",
+                who, (int)sz, (int)sizeof(kfn_conv_desc), (int)min_sz, KFN_ABI_VERSION);
+  std::memset(out, 0, sizeof(*out));
+  std::memcpy(out, in, (size_t)sz);
+  out->struct_size = (int32_t)sizeof(kfn_conv_desc);
+  return KFN_OK;
+}
+// (the declaration shadows the caller's pointer with the normalised copy)
+#define KFN_CONV_DESC_IN(d, who)                                   \
+  kfn_conv_desc d##_full;                                          \
+  {                                                                \
+    int _rc = ::kfn::conv_desc_in(d, &d##_full, who);              \
+    if (_rc != KFN_OK) return _rc;                                 \
+  }                                                                \
+  d = &d##_full
 
 // Wave-wide (64 lanes) sum / max on the VALU: four DPP butterfly steps leave every lane of a 16-lane row with the
 // row's total (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- each step adds a lane's

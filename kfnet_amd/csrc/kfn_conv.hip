@@ -161,7 +161,8 @@ constexpr int PREC_F16_XY_BDMA = 7;
 constexpr int PREC_F16_XY_DMA = 8;
 
 template <int TM, int TN, int WM, int WN, int BK, int MODE, int PREC = PREC_F32>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
+  // (a 128x128 wave tile = 16 accumulators = 256 registers: one wave per SIMD, the full 512-register budget)
   constexpr bool ADMA = (PREC == PREC_F16_XY_DMA);                      // activations through LDS-DMA too
   constexpr bool BDMA = (PREC == PREC_F16_XY_BDMA) || ADMA;
   constexpr bool X16 = (PREC == PREC_F16_X || PREC == PREC_F16_XY || BDMA);   // activations read as halfs
@@ -950,7 +951,8 @@ const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x1
                          {KFN_CFG_64x64, 64, 64, 0.60, 0.60},     {KFN_CFG_160x256, 160, 256, 0.0, 0.0},
                          {KFN_CFG_128x256, 128, 256, 0.0, 0.82},
                          {KFN_CFG_256x16, 256, 16, 0.50, 0.0},    {KFN_CFG_128x16, 128, 16, 0.45, 0.0},
-                         {KFN_CFG_256x64, 256, 64, 0.0, 0.0}};
+                         {KFN_CFG_256x64, 256, 64, 0.0, 0.0},     {KFN_CFG_256x256, 256, 256, 0.0, 0.0},
+                         {KFN_CFG_256x256_W8, 256, 256, 0.0, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -1016,6 +1018,8 @@ int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_192x64: return launch_cfg<3, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, BK, MODE_CONV, PREC>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-activation instantiation", cfg);
   }
 }
@@ -1128,10 +1132,20 @@ int pick_config(const kfn_conv_desc* d, int M) {
   return cfg;
 }
 
+// fp16 activations in, fp32 out (the heads under an fp16 scope): four tiles are instantiated; any other choice of
+// the heuristic maps to the nearest of them instead of failing at launch.
+int x16_config(int cfg, int Cout) {
+  switch (cfg) {
+    case KFN_CFG_256x32: case KFN_CFG_128x32: case KFN_CFG_128x64: case KFN_CFG_128x128: return cfg;
+    default: return Cout > 64 ? KFN_CFG_128x128 : (Cout > 32 ? KFN_CFG_128x64 : KFN_CFG_128x32);
+  }
+}
+
 }  // namespace
 
 extern "C" int kfn_conv2d_out_shape(const kfn_conv_desc* d, int* Ho, int* Wo) {
   KFN_REQUIRE(d && Ho && Wo, "kfn_conv2d_out_shape: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_out_shape");
   int pt, pl;
   out_shape(d, Ho, Wo, &pt, &pl);
   return KFN_OK;
@@ -1139,6 +1153,7 @@ extern "C" int kfn_conv2d_out_shape(const kfn_conv_desc* d, int* Ho, int* Wo) {
 
 extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int* tiles) {
   KFN_REQUIRE(d && config && bk && tiles, "kfn_conv2d_plan: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_plan");
   int rc = validate(d);
   if (rc != KFN_OK) return rc;
   int Ho, Wo, pt, pl;
@@ -1146,6 +1161,7 @@ extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int
   const int M = d->N * Ho * Wo;
   const bool y16 = d->y_dtype == KFN_ACT_F16;
   *config = y16 ? f16io_config(d, M) : pick_config(d, M);
+  if (!y16 && d->x_dtype == KFN_ACT_F16 && d->config == KFN_CFG_AUTO) *config = x16_config(*config, d->Cout);
   const TileCfg* c = find_cfg(*config);
   KFN_REQUIRE(c, "kfn_conv2d_plan: unknown config %d", *config);
   *bk = y16 ? f16io_bk(d) : pick_bk(d->Cin, d->transposed ? MODE_DECONV : MODE_CONV);
@@ -1156,6 +1172,7 @@ extern "C" int kfn_conv2d_plan(const kfn_conv_desc* d, int* config, int* bk, int
 extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const float* w_packed,
                                const float* bias, float* y, void* stream) {
   KFN_REQUIRE(d && x && w_packed && y, "kfn_conv2d_nhwc: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_nhwc");
   int rc = validate(d);
   if (rc != KFN_OK) return rc;
   KFN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_packed) & 15) == 0,
@@ -1221,12 +1238,15 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
       // weights global -> LDS directly: +6-8 % on the 128x256 tile (966-1026 -> 1032-1089 TFLOP/s, profiles/
       // r03_c5_layer_microbench.log), neutral on 128x128; AUTO takes it where it pays
       const bool dma = d->weights_path == KFN_WEIGHTS_LDS_DMA ||
-                       (d->weights_path == KFN_WEIGHTS_AUTO && c16 == KFN_CFG_128x256);
+                       (d->weights_path == KFN_WEIGHTS_AUTO &&
+                        (c16 == KFN_CFG_128x256 || c16 == KFN_CFG_256x256 || c16 == KFN_CFG_256x256_W8));
       if (x16 && f16io_bk(d) == 16 && d->weights_path == KFN_OPERANDS_LDS_DMA) {
         switch (c16) {
           case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
         }
       }
@@ -1234,6 +1254,8 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
         switch (c16) {
           case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
           case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
+          case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
+          case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
           default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
         }
       }
@@ -1242,7 +1264,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
       return x16 ? dispatch_f16io<16, PREC_F16_XY>(c16, a, s) : dispatch_f16io<16, PREC_F16_Y>(c16, a, s);
     }
     // fp16 in, fp32 out (the heads: 'prediction' with its exp epilogue): the narrow tiles
-    switch (cfg) {
+    switch (d->config == KFN_CFG_AUTO ? x16_config(cfg, d->Cout) : cfg) {
       case KFN_CFG_256x32: return launch_cfg<2, 1, 4, 1, 16, MODE_CONV, PREC_F16_X>(a, s);
       case KFN_CFG_128x32: return launch_cfg<1, 1, 4, 1, 16, MODE_CONV, PREC_F16_X>(a, s);
       case KFN_CFG_128x64: return launch_cfg<2, 1, 2, 2, 16, MODE_CONV, PREC_F16_X>(a, s);
@@ -1318,6 +1340,8 @@ int wino_validate(const kfn_conv_desc* d) {
               "kfn_conv2d_winograd: only 3x3 stride-1 SAME convolutions");
   KFN_REQUIRE(d->Cout % 4 == 0 && d->ldy % 4 == 0, "kfn_conv2d_winograd: Cout and ldy must be multiples of 4");
   KFN_REQUIRE(d->epilogue == KFN_EPI_NONE, "kfn_conv2d_winograd: fused head epilogues are not supported");
+  KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32 && d->operand_dtype == KFN_OPERAND_F32,
+              "kfn_conv2d_winograd: fp32 operands and fp32 activations in memory only");
   return KFN_OK;
 }
 
@@ -1325,6 +1349,7 @@ int wino_validate(const kfn_conv_desc* d) {
 
 extern "C" int kfn_winograd_workspace_bytes(const kfn_conv_desc* d, size_t* bytes) {
   KFN_REQUIRE(d && bytes, "kfn_winograd_workspace_bytes: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_winograd_workspace_bytes");
   int rc = wino_validate(d);
   if (rc != KFN_OK) return rc;
   const size_t Mt = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
@@ -1334,6 +1359,7 @@ extern "C" int kfn_winograd_workspace_bytes(const kfn_conv_desc* d, size_t* byte
 
 extern "C" int kfn_winograd_plan(const kfn_conv_desc* d, int* config, int* bk, int* tiles) {
   KFN_REQUIRE(d && config && bk && tiles, "kfn_winograd_plan: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_winograd_plan");
   int rc = wino_validate(d);
   if (rc != KFN_OK) return rc;
   const int Mt = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
@@ -1349,6 +1375,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
                                    const float* bias, float* y, float* workspace, int phases,
                                    void* stream) {
   KFN_REQUIRE(d && x && u_packed && y && workspace, "kfn_conv2d_winograd: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd");
   int rc = wino_validate(d);
   if (rc != KFN_OK) return rc;
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u_packed) |

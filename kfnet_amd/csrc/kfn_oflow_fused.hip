@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const f
   const int wv = threadIdx.x >> 6;
   char* const tA = smem_of + wv * HEAD_WAVE_BYTES;
   for (int i = lane; i < HEAD_WAVE_BYTES / 16; i += 64) reinterpret_cast<f32x4*>(tA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_wave_barrier();   // the zero fill is ordered before the first interior stores (same wave; pins the compiler)
 
   // conv1a weights: fragment t = (tap*8 + j)*2 + nb of lane (n = l%16, kq = l/16) = w[tap][kq*8 + j][nb*16 + n]
   float wreg[144];
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
   char* const t2 = t1 + T1_BYTES;
   char* const t3 = t2 + T2_BYTES;
   for (int i = lane; i < TAIL_WAVE_BYTES / 16; i += 64) reinterpret_cast<f32x4*>(t1)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_wave_barrier();   // the zero fill is ordered before the first interior stores (same wave; pins the compiler)
 
   // conv6: fragment t = tap*12 + j of lane (n, kq) = w6[tap][kq*12 + j][n]   (graph.pack_oflow_tail_kernel)
   float w6r[108];

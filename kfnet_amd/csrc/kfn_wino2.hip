@@ -453,7 +453,10 @@ int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, 
 
 // Can the single-kernel path take this layer?  (host-side routing; no device access)
 extern "C" int kfn_winograd_fused_supported(const kfn_conv_desc* d) {
-  if (!d) return 0;
+  kfn_conv_desc d_full;
+  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_fused_supported") != KFN_OK) return 0;
+  d = &d_full;
+  if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32) return 0;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->transposed) return 0;
   if (d->Cin <= 0 || d->Cin % KS != 0) return 0;
   if ((d->H + 1) / 2 < BH) return 0;   // a 4-row tile block may straddle at most two images
@@ -468,6 +471,9 @@ extern "C" int kfn_winograd_fused_supported(const kfn_conv_desc* d) {
 extern "C" int kfn_conv2d_winograd_fused(const kfn_conv_desc* d, const float* x, const void* u2_packed,
                                          const float* bias, float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_fused: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_fused");
+  KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32,
+              "kfn_conv2d_winograd_fused: fp32 activations in memory only (x_dtype / y_dtype = KFN_ACT_F16 is implemented by kfn_conv2d_nhwc)");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed,
               "kfn_conv2d_winograd_fused: only 3x3 stride-1 SAME convolutions");
   KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "kfn_conv2d_winograd_fused: bad shape %dx%dx%d", d->N, d->H, d->W);

@@ -427,7 +427,10 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
 
 // Can the polyphase kernel take this layer?  (host-side routing; no device access)
 extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
-  if (!d) return 0;
+  kfn_conv_desc d_full;
+  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_s2_supported") != KFN_OK) return 0;
+  d = &d_full;
+  if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32) return 0;
   if (d->kh != 3 || d->kw != 3 || d->stride != 2 || d->transposed) return 0;
   if (d->H <= 0 || d->W <= 0 || (d->H & 1) || (d->W & 1)) return 0;     // 'same' pads after the image only
   if (d->Cin <= 0 || d->Cin % SS_CH != 0) return 0;
@@ -440,6 +443,9 @@ extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
 extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias,
                                       float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2");
+  KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32,
+              "kfn_conv2d_winograd_s2: fp32 activations in memory only (x_dtype / y_dtype = KFN_ACT_F16 is implemented by kfn_conv2d_nhwc)");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 2 && !d->transposed,
               "kfn_conv2d_winograd_s2: only 3x3 stride-2 SAME convolutions");
   KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "kfn_conv2d_winograd_s2: bad shape %dx%dx%d", d->N, d->H, d->W);

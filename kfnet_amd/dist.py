@@ -192,9 +192,42 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
     return TorchLink(dist)
 
 
-def run_chunk(eng, dev_frames, first_frame, rank, world, link=None, dev_prev_frame=None):
+class ChunkTimer(object):
+    """HIP-event stamps of one `run_chunk` pass on the engine's stream, for the serial chain of the sharded
+    configuration: heavy phase | recv (waits for the predecessor's scan) | scan | send.  `origin()` is called right
+    after a barrier + synchronize, so event times relative to it can be placed on the node's monotonic clock and
+    compared ACROSS ranks (bench.py: scan_chain_ms = last rank's scan end - rank 0's scan start)."""
+    NAMES = ('origin', 'heavy_end', 'recv_end', 'scan_end', 'send_end')
+
+    def __init__(self, torch, device):
+        self.torch, self.device = torch, device
+        self.ev = {n: torch.cuda.Event(enable_timing=True) for n in self.NAMES}
+        self.t_origin = None
+        self.did = {'recv': False, 'send': False}
+
+    def origin(self):
+        import time
+        self.torch.cuda.synchronize(self.device)
+        self.t_origin = time.monotonic()
+        self.stamp('origin')
+
+    def stamp(self, name):
+        self.ev[name].record(self.torch.cuda.current_stream(self.device))
+
+    def summary(self):
+        """ms since origin of every stamp + absolute monotonic seconds; call after a synchronize."""
+        rel = {n: float(self.ev['origin'].elapsed_time(self.ev[n])) for n in self.NAMES[1:]}
+        return {'t_origin_monotonic_s': self.t_origin, 'ms_since_origin': rel,
+                'heavy_ms': rel['heavy_end'],
+                'recv_wait_us': (rel['recv_end'] - rel['heavy_end']) * 1e3 if self.did['recv'] else None,
+                'scan_ms': rel['scan_end'] - rel['recv_end'],
+                'send_us': (rel['send_end'] - rel['scan_end']) * 1e3 if self.did['send'] else None}
+
+
+def run_chunk(eng, dev_frames, first_frame, rank, world, link=None, dev_prev_frame=None, timer=None):
     """Process this rank's chunk [first_frame, first_frame + T).  `link` is a StateLink (or an
-    initialised torch.distributed module, wrapped on the fly; None for a single process)."""
+    initialised torch.distributed module, wrapped on the fly; None for a single process).  `timer`: a ChunkTimer
+    whose origin() has been called; stamps the phase boundaries on the stream (no host synchronisation)."""
     if link is not None and hasattr(link, 'get_backend'):   # the torch.distributed module itself
         link = TorchLink(link)
     T = int(dev_frames.shape[0])
@@ -205,12 +238,22 @@ def run_chunk(eng, dev_frames, first_frame, rank, world, link=None, dev_prev_fra
                 raise ValueError('chunk starting at frame %d needs the preceding frame' % first_frame)
             eng.prime(dev_prev_frame)      # flow features of frame first_frame-1, recomputed locally
         eng.heavy(dev_frames, T)           # state-independent: no waiting on other ranks
+    if timer is not None:
+        timer.stamp('heavy_end')
     if recv:
         link.recv(eng.get_state(), rank - 1, eng)      # the 76.8 KB hand-off, into the live state
+    if timer is not None:
+        timer.did['recv'] = bool(recv)
+        timer.stamp('recv_end')
     if T > 0:
         eng.scan(T, first_frame)
+    if timer is not None:
+        timer.stamp('scan_end')
     if send:                               # an empty chunk just forwards what it received
         link.send(eng.get_state(), rank + 1, eng)
+    if timer is not None:
+        timer.did['send'] = bool(send)
+        timer.stamp('send_end')
     return eng.records(T)
 
 

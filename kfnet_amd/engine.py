@@ -31,7 +31,7 @@ def grid_size(image_hw):
 class KFNetEngine(object):
     def __init__(self, weights, image_size=(480, 640), batch=4, transform=None, reset_period=500,
                  nis_gate=0.0, max_chunk=256, device='cuda:0', emit_debug=False, autotune=False,
-                 conv_operands='f32', use_graph=False, emit_metrics=False):
+                 conv_operands='f32', use_graph=False, emit_metrics=False, graph_options=None):
         import torch
         self.torch = torch
         self.B = int(batch)
@@ -47,6 +47,18 @@ class KFNetEngine(object):
 
         g = self.graph = Graph()
         g.conv_operands = conv_operands
+        if torch.cuda.is_available():
+            import ctypes as C
+            lds = C.c_int(0)
+            dev_index = torch.device(device).index
+            _lib.check(_lib.load().kfn_device_info(torch.cuda.current_device() if dev_index is None else dev_index,
+                                                   None, C.byref(lds), None, 0), 'kfn_device_info')
+            if lds.value > 0:
+                g.lds_bytes_per_cu = int(lds.value)
+        for key, val in (graph_options or {}).items():     # routing switches of kfnet_amd.graph.Graph (tests, A/B runs)
+            if not hasattr(g, key):
+                raise ValueError('unknown Graph option %r' % key)
+            setattr(g, key, val)
         spec = KFNetDataSpec(batch_size=self.B, image_size=image_size)
         self.images = g.placeholder((self.B, self.H, self.W, 3), 'u8', name='images')
         self.state = g.placeholder((1, self.h, self.w, 4), name='last_state')

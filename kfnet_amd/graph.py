@@ -982,6 +982,8 @@ class Graph(object):
         # conv6 + prediction + soft-argmax): conv0's [P,8,8,32] output, concat0 and the gather launch disappear.
         # Needs the factored cost volume and the fused tail.
         self.fuse_oflow_window = True
+        self.lds_bytes_per_cu = 160 * 1024   # gfx950; KFNetEngine overwrites it with kfn_device_info's answer before the
+                                             # graph is built (the window-resident OFlowNet tail needs 136 000 B per workgroup)
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
         # (0 disables).  Below ~128 channels the [tiles][16][Cout] workspace traffic outweighs
         # the 2.25x MFMA saving.

@@ -62,6 +62,36 @@ def test_small_sequence_vs_fp64_oracle(batch):
     _check(rec, ref)
 
 
+@pytest.mark.parametrize('options', [dict(factor_cost_volume=False), dict(fuse_oflow_window=False),
+                                     dict(fuse_cost_volume=False), dict(fuse_oflow_window=False, fuse_oflow_tail=False)])
+def test_unfused_oflow_routes_vs_fp64_oracle(options):
+    """The routes the default graph does not take (conv0 had become a Winograd layer whose re-packed kernel the
+    loader-generated cost-volume route read as a direct-conv matrix -- silently wrong flow, no test): the cost volume
+    generated in conv0's loader (factor_cost_volume=False), the round-2 launches instead of the window-resident ends
+    (fuse_oflow_window=False), the materialised volume (fuse_cost_volume=False)."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(1234)
+    imgs = synthetic_sequence(4, 64, 96, seed=1)
+    T4 = O.get_transform(synthetic_transform())
+    ref, dbg = O.eval_sequence(imgs, W, T4, reset_period=500, dtype=np.float64, return_debug=True)
+    eng = KFNetEngine(W, image_size=(64, 96), batch=2, transform=T4, reset_period=500, max_chunk=8, emit_debug=True,
+                      graph_options=options)
+    names = [type(op).__name__ for op in eng.net.pair_ops]
+    if options.get('factor_cost_volume') is False:
+        assert 'CostVolumeConvOp' in names and 'OFlowHeadOp' not in names
+    if options.get('fuse_oflow_window') is False:
+        assert 'OFlowHeadOp' not in names and 'OFlowTail2Op' not in names
+    if options.get('fuse_cost_volume') is False:
+        assert 'CostVolumeOp' in names
+    rec = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    d = eng.debug(4)
+    for t in (1, 2, 3):
+        assert np.abs(d['flow'][t] - dbg[t]['flow'][0]).max() < 5e-5, (options, t)
+    _check(rec, ref)
+
+
 def test_nis_gate_and_odd_grid():
     """540x960-style odd intermediate sizes (SAME pad (1,1) on odd rows) at reduced scale:
     68x120 image -> 34x60 -> 17x30 -> 9x15 grid; plus the --NIS output gate."""

@@ -217,11 +217,20 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     src = tmp_path / 'host.c'
     src.write_text('#include "kfnet_hip.h"\n#include <stdio.h>\n'
                    'int main(void) {\n'
-                   '  kfn_conv_desc d = {0};\n'
+                   '  kfn_conv_desc d = KFN_CONV_DESC_INIT;\n'
                    '  int ho = 0, wo = 0;\n'
                    '  d.N = 1; d.H = 480; d.W = 640; d.Cin = 64; d.ldx = 64; d.Cout = 256; d.cout_pad = 256; d.ldy = 256;\n'
                    '  d.kh = 3; d.kw = 3; d.stride = 2;\n'
                    '  if (kfn_conv2d_out_shape(&d, &ho, &wo) != KFN_OK) return 1;\n'
+                   '  /* a host compiled against an OLDER, shorter struct: fields beyond its size read as 0 */\n'
+                   '  d.struct_size = (int)offsetof(kfn_conv_desc, x_dtype);\n'
+                   '  d.weights_path = 77; d.k_step = 5;   /* beyond the declared size: must be ignored */\n'
+                   '  if (kfn_conv2d_out_shape(&d, &ho, &wo) != KFN_OK) return 2;\n'
+                   '  /* no struct_size (an ABI <= 4 host): a clean argument error, never an out-of-bounds read */\n'
+                   '  d.struct_size = 0;\n'
+                   '  if (kfn_conv2d_out_shape(&d, &ho, &wo) != KFN_ERR_ARG) return 3;\n'
+                   '  d.struct_size = (int)sizeof(kfn_conv_desc) + 4;\n'
+                   '  if (kfn_conv2d_out_shape(&d, &ho, &wo) != KFN_ERR_ARG) return 4;\n'
                    '  printf("%d %d %d\\n", kfn_abi_version(), ho, wo);\n'
                    '  return 0;\n}\n')
     exe = tmp_path / 'host'
@@ -230,6 +239,88 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     out = subprocess.check_output([str(exe)]).decode().split()
     from kfnet_amd._lib import ABI_VERSION
     assert out == [str(ABI_VERSION), '240', '320']          # ABI version, TF-SAME output size of conv2a
+
+
+def _header_struct_fields(text, name):
+    """Member names of `typedef struct <name> { ... } <name>;` in declaration order (comments stripped;
+    `int32_t a, b;` and `float t[12];` forms)."""
+    import re
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), text, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    out = []
+    for stmt in body.split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        typ, names = stmt.split(None, 1)
+        for n in names.split(','):
+            m = re.match(r'\s*(\w+)\s*(\[(\d+)\])?\s*$', n)
+            out.append((m.group(1), typ, int(m.group(3)) if m.group(3) else 1))
+    return out
+
+
+def test_conv_desc_matches_header_and_integration_doc():
+    """VERDICT r3 Weak #6: kfn_conv_desc grew (weights_path) while _lib.py, the header and INTEGRATION.md drifted apart.
+    The three field lists -- include/kfnet_hip.h, kfnet_amd._lib.ConvDesc, the reference-side stub in INTEGRATION.md --
+    must name the same members in the same order, the struct must start with struct_size, and the ABI numbers agree."""
+    import ctypes as C
+    import re
+    from kfnet_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'kfnet_hip.h')).read()
+    fields = _header_struct_fields(hdr, 'kfn_conv_desc')
+    assert all(t == 'int32_t' and n == 1 for _, t, n in fields)
+    names = [f[0] for f in fields]
+    assert names[0] == 'struct_size'
+    assert names == [f[0] for f in _lib.ConvDesc._fields_]
+    assert C.sizeof(_lib.ConvDesc) == 4 * len(names)
+    assert _lib.ConvDesc(N=1).struct_size == C.sizeof(_lib.ConvDesc)
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    snippet = re.search(r'class ConvDesc\(C\.Structure\):.*?_fields_ = \[\(n, C\.c_int32\) for n in \((.*?)\)\]', doc, re.S).group(1)
+    assert re.findall(r"'(\w+)'", snippet) == names
+    abi = int(re.search(r'#define KFN_ABI_VERSION (\d+)', hdr).group(1))
+    assert abi == _lib.ABI_VERSION
+    assert 'kfn_abi_version() == %d' % abi in doc
+    # the scan descriptor too
+    kf = _header_struct_fields(hdr, 'kfn_kalman_desc')
+    assert [f[0] for f in kf] == [f[0] for f in _lib.KalmanDesc._fields_]
+    assert sum(f[2] for f in kf) * 4 == C.sizeof(_lib.KalmanDesc)
+
+
+def test_every_header_function_is_bound_and_exported():
+    """Every `int kfn_*(` / `const char* kfn_*(` prototype of the header has a ctypes signature in _lib.SYMBOLS with the
+    same number of parameters, and nothing is bound that the header does not declare."""
+    import re
+    from kfnet_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'kfnet_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    protos = dict()
+    for m in re.finditer(r'(?:int|const char\*)\s+(kfn_\w+)\s*\(([^;{]*?)\)\s*;', hdr, re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ('', 'void') else len(args.split(','))
+    assert set(protos) == set(_lib.SYMBOLS)
+    for name, n in protos.items():
+        assert len(_lib.SYMBOLS[name][1]) == n, name
+
+
+def test_loader_generated_cost_volume_route_packs_conv0_for_the_direct_kernel():
+    """with Graph.factor_cost_volume = False conv0's kernel variable goes to kfn_cost_volume_conv,
+    which reads the [cout_pad][9 Cin] direct-convolution layout -- whatever route Network.conv had picked for the layer
+    (3x3 stride 1 on an 8x8 grid with 32 channels qualifies for the Winograd kernels since round 3)."""
+    from kfnet_amd.graph import Graph, pack_bias, pack_conv_kernel
+    from kfnet_amd.KFNet.KFNet import KFNet, KFNetDataSpec
+    g = Graph()
+    g.factor_cost_volume = False
+    images = g.placeholder((2, 64, 96, 3), 'u8', name='images')
+    state = g.placeholder((1, 8, 12, 4), name='last_state')
+    net = KFNet(images, KFNetDataSpec(batch_size=2, image_size=(64, 96)))
+    net.GetKFCoordRecursive(state.channels(0, 3), state.channels(3, 1), transform=None, reset_period=500, nis_gate=0.0,
+                            emit_temp=False, emit_nis=False)
+    fused = [op for op in net.pair_ops if type(op).__name__ == 'CostVolumeConvOp']
+    assert len(fused) == 1
+    assert fused[0].kernel.pack is pack_conv_kernel and fused[0].bias.pack is pack_bias
+    assert not any(type(op).__name__ in ('CostVolumeOp', 'OFlowHeadOp') for op in net.pair_ops)
 
 
 def test_comm_entry_points_validate_arguments_without_a_gpu():

@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   const int xpad = argc > 6 ? atoi(argv[6]) : 0, ypad = argc > 7 ? atoi(argv[7]) : 0;   // extra floats of pixel pitch
   kfn_conv_desc d;
   memset(&d, 0, sizeof d);
+  d.struct_size = (int)sizeof d;
   d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.ldx = Cin + xpad; d.Cout = Cout; d.cout_pad = (Cout + 31) / 32 * 32; d.ldy = Cout + ypad;
   d.kh = d.kw = 3; d.stride = 1; d.relu = 1;
   const size_t xb = (size_t)N * H * W * d.ldx * 4, yb = (size_t)N * H * W * d.ldy * 4, ub = (size_t)16 * d.cout_pad * Cin * 4;
