@@ -285,11 +285,14 @@ def host_streamed(eng, host_frames, dev_frames, chunk=None):
                     '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
 
 
-def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32):
+def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4):
     """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
     (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
     package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the
-    synthetic sequence's frames written to a temporary directory first (untimed)."""
+    synthetic sequence's frames written to a temporary directory first (untimed); image_list.txt walks them `repeat`
+    times (a 1024-entry list: the one-off costs of a run -- page-locking the staging buffers, the first chunk's
+    decode, the last chunk's download and file writes, ~0.1 s -- are a quarter of a 256-frame run but not of a real
+    sequence of 1000-4000 frames); the first pass's records are compared with the resident run."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -310,7 +313,7 @@ def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_record
             list(pool.map(lambda i: Image.fromarray(host_frames[i]).save(paths[i], compress_level=1), range(T)))
         t_w = time.perf_counter() - t_w
         with open(os.path.join(inp, 'image_list.txt'), 'w') as f:
-            f.write('\n'.join(paths) + '\n')
+            f.write('\n'.join(paths * repeat) + '\n')
         np.savetxt(os.path.join(inp, 'transform.txt'), transform_txt)   # what transform.txt holds: get_transform inverts it
         image_paths = read_lines(os.path.join(inp, 'image_list.txt'))
         transform = KE.get_transform(os.path.join(inp, 'transform.txt'))
@@ -323,10 +326,11 @@ def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_record
             dt = time.perf_counter() - t0
         files = sorted(os.listdir(outd))
         on_disk = np.stack([np.load(os.path.join(outd, 'coord_%d.npy' % i)) for i in (0, T // 2, T - 1)])
-        same = bool(np.array_equal(rec, resident_records)) and bool(np.array_equal(on_disk, resident_records[[0, T // 2, T - 1]]))
+        same = bool(np.array_equal(rec[:T], resident_records)) and bool(np.array_equal(on_disk, resident_records[[0, T // 2, T - 1]]))
+        NT = T * repeat
         # (transform.txt went through text: it must come back as the very matrix the resident run used)
         t_same = bool(np.array_equal(np.asarray(transform, np.float32), np.asarray(T4, np.float32)))
-        return {'value': round(T / dt, 3), 'unit': 'frames/s', 'frames': T, 'chunk': chunk, 'seconds': round(dt, 3),
+        return {'value': round(NT / dt, 3), 'unit': 'frames/s', 'frames': NT, 'distinct_png_files': T, 'chunk': chunk, 'seconds': round(dt, 3),
                 'decode_threads': workers, 'host_cores': cores, 'npy_files_written': len(files),
                 'png_megabytes': round(png_mb, 1), 'png_write_seconds_untimed': round(t_w, 2),
                 'gpu_busy_pct': (tele.summary().get('busy_pct') or {}).get('mean'),

@@ -17,6 +17,7 @@ OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
 ACT_F32, ACT_F16 = 0, 1
 WINO_ORDER_AUTO, WINO_ORDER_M_FAST, WINO_ORDER_N_FAST = 0, 1, 2
 CFG_128x256 = 9
+CFG_256x64, CFG_256x256, CFG_256x256_W8 = 12, 13, 14
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 
 

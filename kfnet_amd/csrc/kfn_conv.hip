@@ -21,6 +21,21 @@
 #include <type_traits>
 #include <cstdlib>
 
+// fp16-activation kernels: pin the issue order of the main loop (one sched_barrier per MFMA slot).  Without it hipcc
+// re-clusters the stage -- 8 MFMAs, then ALL fragment reads of the next chunk in one burst with the LDS stores and
+// global loads behind them, then a wait for those reads in front of the next MFMA -- which exposes one LDS round trip
+// per chunk (tools/mb/build_hot.sh builds the A/B library with -DKFN_F16_PIN=0).
+#ifndef KFN_F16_PIN
+#define KFN_F16_PIN 1
+#endif
+// position of the stage barrier inside the last k-chunk of a stage: after J / KFN_F16_BAR_DIV of its J MFMAs (fp16-activation
+// kernels; everything else keeps J / 2).  The fragment reads of the next stage follow the barrier and are covered by the rest.
+// Same-box A/B on the eight-wave 256x256 tile (profiles/r04_c5_layer_microbench.log, conv2b / 3b / 4b / 5, TFLOP/s):
+// J/2 with both operands on LDS-DMA 1090 / 1153 / 1188 / 1201, J/4: 1123 / 1180 / 1197 / 1215.
+#ifndef KFN_F16_BAR_DIV
+#define KFN_F16_BAR_DIV 4
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,6 +76,7 @@ struct ConvArgs {
   int N, H, W, Cin, ldx;
   int Ho, Wo, Cout, cout_pad, ldy;
   int kh, kw, stride, pad_t, pad_l;
+  unsigned kw_inv;   // ceil(65536 / kw): tap / kw == (tap * kw_inv) >> 16 for tap < 32 (a scalar integer divide is ~20 SALU instructions per stage)
   int relu, epilogue;
   int M, Ktot;
   int tiles_m, tiles_n;
@@ -655,7 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma
   if (n_stages > 0) {
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers ----------------------
     {
-      const int ky = ld_tap / p.kw, kx = ld_tap - ky * p.kw;
+      const int ky = (int)(((unsigned)ld_tap * p.kw_inv) >> 16), kx = ld_tap - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = TAP_INNER ? (unsigned)((ld_tap * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
                                         : (unsigned)(ld_tap * p.Cin + ld_c0) * 4u;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma
     {
       const bool live = ld_tap < 32;
       const int tp = live ? ld_tap : 0;
-      const int ky = tp / p.kw, kx = tp - ky * p.kw;
+      const int ky = (int)(((unsigned)tp * p.kw_inv) >> 16), kx = tp - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = TAP_INNER ? (unsigned)((tp * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
                                         : (unsigned)(tp * p.Cin + ld_c0) * 4u;
@@ -702,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma
       const int buf = s & 1;
       const bool live = ld_tap < 32;
       const int tp = live ? ld_tap : 0;
-      const int ky = tp / p.kw, kx = tp - ky * p.kw;
+      const int ky = (int)(((unsigned)tp * p.kw_inv) >> 16), kx = tp - ky * p.kw;
       const unsigned adelta = (unsigned)((ky * p.W + kx) * p.ldx + ld_c0) * XB;
       const unsigned bdelta = TAP_INNER ? (unsigned)((tp * (p.Cin >> 5) + (ld_c0 >> 5)) * p.cout_pad) * 128u
                                         : (unsigned)(tp * p.Cin + ld_c0) * 4u;
@@ -719,11 +735,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma
         constexpr int n_dma = (c == 0 && !ADMA) ? NDMA : 0;     // behind the A stores of the same chunk (see PREC_F16_XY_BDMA)
         constexpr int n_ld = (c == LOADC) ? NLD : 0;
         constexpr int n_side = n_rd + n_st + n_dma + n_ld;
-        constexpr int jspan = last ? (J / 2 > 0 ? J / 2 : 1) : J;  // in the last chunk side ops ride the first half
+        constexpr int JB = (TAP_INNER ? J / KFN_F16_BAR_DIV : J / 2) > 0 ? (TAP_INNER ? J / KFN_F16_BAR_DIV : J / 2) : 1;   // MFMAs of the last chunk in front of the barrier
+        constexpr int jspan = last ? JB : J;  // in the last chunk side ops ride in front of the barrier
         static_for<J>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int t = j / (TM * TN), rem = j % (TM * TN), mi = rem / TN, ni = rem % TN;
-          if constexpr (last && j == J / 2) {
+          if constexpr (last && j == (J > 1 ? JB : 0)) {
             if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers for stage s+1 have landed
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -758,6 +775,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 8 ? 1 : 2)) void conv_mfma
             else if constexpr (k < n_rd + n_st + n_dma) dma_one(k - n_rd - n_st, live, bdelta, bcur == 0 ? 2 : bcur - 1);
             else load_one(k - n_rd - n_st - n_dma, live, adelta, bdelta, ky, kx, tp);
           });
+          if constexpr (KFN_F16_PIN != 0 && TAP_INNER) __builtin_amdgcn_sched_barrier(0);
         });
       });
       advance();
@@ -1030,7 +1048,10 @@ int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
 // (576 vs 524 TFLOP/s on 128x64).  desc->config / desc->k_step override either.
 void f16io_plan(const kfn_conv_desc* d, int* cfg, int* bk) {
   int c = d->config, k = d->k_step;
-  if (c == KFN_CFG_AUTO) c = d->Cout >= 256 ? KFN_CFG_128x256 : (d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_256x64);
+  // (round 4: the eight-wave 256x256 tile -- half the weight transfers per MFMA, one workgroup of two waves per SIMD --
+  //  beats 128x256 on every >= 256-channel layer of config 5: conv4b 1144 vs 1085, conv3b 1112 vs 1069, conv5 1141 vs
+  //  1077, conv6 1104 vs 1049, conv2b 1032 vs 1024, conv3a 1000 vs 986 TFLOP/s; profiles/r04_c5_layer_microbench.log)
+  if (c == KFN_CFG_AUTO) c = d->Cout >= 256 ? KFN_CFG_256x256_W8 : (d->Cout >= 128 ? KFN_CFG_128x128 : KFN_CFG_256x64);
   if (k == 0 || d->Cin % 64 != 0) k = 16;
   *cfg = c;
   *bk = k;
@@ -1183,6 +1204,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
+  a.kw_inv = (65536u + (unsigned)d->kw - 1u) / (unsigned)d->kw;
   a.relu = d->relu; a.epilogue = d->epilogue;
   out_shape(d, &a.Ho, &a.Wo, &a.pad_t, &a.pad_l);
   const long M = (long)d->N * a.Ho * a.Wo;
@@ -1240,7 +1262,10 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
       const bool dma = d->weights_path == KFN_WEIGHTS_LDS_DMA ||
                        (d->weights_path == KFN_WEIGHTS_AUTO &&
                         (c16 == KFN_CFG_128x256 || c16 == KFN_CFG_256x256 || c16 == KFN_CFG_256x256_W8));
-      if (x16 && f16io_bk(d) == 16 && d->weights_path == KFN_OPERANDS_LDS_DMA) {
+      // AUTO on the eight-wave tile: both operand tiles global -> LDS directly (+1-3 % over weights only; on the four-wave
+      // tiles the activation tile through registers stays ahead)
+      if (x16 && f16io_bk(d) == 16 &&
+          (d->weights_path == KFN_OPERANDS_LDS_DMA || (d->weights_path == KFN_WEIGHTS_AUTO && c16 == KFN_CFG_256x256_W8))) {
         switch (c16) {
           case KFN_CFG_128x256: return launch_cfg<2, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
@@ -1388,6 +1413,7 @@ extern "C" int kfn_conv2d_winograd(const kfn_conv_desc* d, const float* x, const
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
   a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->Cout;
   a.kh = 1; a.kw = 1; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
+  a.kw_inv = 65536u;
   a.relu = 0; a.epilogue = KFN_EPI_NONE;
   a.Ho = Th; a.Wo = Tw;  // row index space of the GEMMs = 2x2 output tiles
   a.Ktot = d->Cin;
@@ -1444,6 +1470,7 @@ extern "C" int kfn_cost_volume_conv(const float* f1, const float* f2, const floa
   a.N = N; a.H = H; a.W = W; a.Cin = C; a.ldx = C;
   a.Cout = Cout; a.cout_pad = cout_pad; a.ldy = ldy;
   a.kh = 3; a.kw = 3; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
+  a.kw_inv = 21846u;
   a.relu = relu; a.epilogue = KFN_EPI_NONE;
   a.Ho = 8; a.Wo = 8;
   const long M = (long)N * H * W * 64;

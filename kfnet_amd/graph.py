@@ -375,7 +375,8 @@ class ConvOp(Op):
 
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
                 6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2),
-                10: (2, 1, 4, 1), 11: (1, 1, 4, 1), 12: (2, 2, 4, 1)}   # 10/11: 16-column variants (PREC tag 3)
+                10: (2, 1, 4, 1), 11: (1, 1, 4, 1), 12: (2, 2, 4, 1),   # 10/11: 16-column variants (PREC tag 3)
+                13: (4, 4, 2, 2), 14: (4, 2, 2, 4)}                     # 256x256: four / eight waves (fp16 activations)
     # template tag PREC of conv_mfma_kernel for fp16 activations: (x is f16, y is f16) -> 4 / 5 / 6
     PREC_F16_IO = {(True, False): 4, (False, True): 5, (True, True): 6}
 
@@ -388,8 +389,10 @@ class ConvOp(Op):
         io = (self.x.dtype == 'f16', self.y.dtype == 'f16')
         if self.operand_dtype == _lib.OPERAND_F16 and io != (False, False):
             prec = self.PREC_F16_IO[io]
-            if io == (True, True) and bk.value == 16 and cfg.value == _lib.CFG_128x256:
+            if io == (True, True) and bk.value == 16 and cfg.value in (_lib.CFG_128x256, _lib.CFG_256x256):
                 prec = 7      # weights global -> LDS directly (mirror of the AUTO rule in kfn_conv2d_nhwc)
+            if io == (True, True) and bk.value == 16 and cfg.value == _lib.CFG_256x256_W8:
+                prec = 8      # ... and the activation tile too (the eight-wave tile's AUTO rule)
             return 'conv_mfma_kernel<%d, %d, %d, %d, %d, 0, %d>' % (t + (bk.value if io[1] else 16, prec))
         if self.operand_dtype == _lib.OPERAND_F16:
             return 'conv_mfma_kernel<%d, %d, %d, %d, 16, %d, 1>' % (t + (1 if self.transposed else 0,))

@@ -71,6 +71,7 @@ class ChunkLoader(object):
         self.ready = queue.Queue()
         self.thread = None
         self._held = []
+        self._pool = None
 
     def __len__(self):
         return (self.T + self.chunk - 1) // self.chunk
@@ -80,16 +81,16 @@ class ChunkLoader(object):
         if isinstance(self.source, np.ndarray):
             dst[:hi - lo] = self.source[lo:hi]
             return
-        from concurrent.futures import ThreadPoolExecutor
-
         def one(i):
             dst[i - lo] = self.decode(self.source[i], self.image_size)
         if self.workers == 1:
             for i in range(lo, hi):
                 one(i)
         else:
-            with ThreadPoolExecutor(self.workers) as pool:
-                list(pool.map(one, range(lo, hi)))   # list(): re-raise decode errors here
+            if self._pool is None:      # one pool for the whole sequence (not one per chunk)
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.workers, thread_name_prefix='kfnet-decode')
+            list(self._pool.map(one, range(lo, hi)))   # list(): re-raise decode errors here
 
     def _produce(self):
         try:
@@ -103,6 +104,10 @@ class ChunkLoader(object):
             self.ready.put((None, 0, None, None))
         except BaseException as e:   # hand decode errors to the consumer thread
             self.ready.put((None, 0, None, e))
+        finally:
+            if self._pool is not None:
+                self._pool.shutdown(wait=False)
+                self._pool = None
 
     def __iter__(self):
         if self.thread is not None:
