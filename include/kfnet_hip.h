@@ -211,6 +211,20 @@ int kfn_winograd_s2_supported(const kfn_conv_desc* desc);
 int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void* u2_packed, const float* bias,
                            float* y, void* stream);
 
+/* Winograd F(4x4,3x3) for the same 3x3 stride-1 'same' convolutions (csrc/kfn_wino4.hip, round 4): 36 products per
+ * 4x4 outputs -- 2.25 multiplies per output instead of 4 (F(2x2,3x3)) or 9 (direct) -- interpolation points
+ * {0, +-1, +-2}, fp32 throughout, one launch, no workspace.  Meant for the layers with Cin >= 512 (SCoordNet conv3b /
+ * conv4b / conv5, cnn_wrapper/SCoordNet.py:26-30), where the K loop amortises the larger transforms; the result differs
+ * from kfn_conv2d_nhwc by ~3x the F(2x2,3x3) round-off (1.4e-6 on the network's coordinates, tools/experiments/
+ * f43_error_budget.py).  u4_packed = [Cin/8][36][cout_pad][8]: U[6 xi + nu] = (G g G^T)[xi][nu] in fp64, rounded once,
+ * u4[((ci/8)*36 + 6*xi+nu)*cout_pad + co][ci%8] (kfnet_amd.graph.pack_winograd_f43_kernel).
+ * Needs Cin % 16 == 0, H >= 29, Cout % 4 == 0, ldy % 4 == 0, ldx % 2 == 0, y 16-byte aligned, two images of the input
+ * below 1 GiB, fp32 operands and activations, no fused head epilogue (kfn_winograd_f43_supported() == 1);
+ * KFN_ERR_UNSUPPORTED otherwise. */
+int kfn_winograd_f43_supported(const kfn_conv_desc* desc);
+int kfn_conv2d_winograd_f43(const kfn_conv_desc* desc, const float* x, const float* u4_packed, const float* bias,
+                            float* y, void* stream);
+
 /* ---- first layers: uint8 image -> (x-128)*0.00625 -> 3x3 conv, Cin = 3 --------------
  * Replaces SCoordNet.preprocess + conv1a (SCoordNet.py:20-21,34-37) and the feature
  * tower's preprocess + feat1 (KFNet/KFNet.py:317-320) in ONE pass over the image.

@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _lib
 from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
-                     WinogradS2ConvOp, WindowFcConvOp, as_f16,
+                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
                      pack_winograd_s2_kernel, current_scope, pack_conv_kernel_chunked)
@@ -257,6 +257,14 @@ class Network(object):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_window_fc_kernel)
             bias.pack = pack_bias_x4
             self._emit(WindowFcConvOp(name, input, y, kern, bias, relu))
+            return y
+        f43 = g.winograd_f43_min_channels
+        # (measured at batch 32, F(2x2,3x3) -> F(4x4,3x3): conv3b 9.67 -> 6.46 ms, conv4b 9.25 -> 6.32, conv5 4.61 -> 3.28;
+        #  conv6 -- 512 -> 256 channels, 1200 workgroups = 4.7 rounds of the 256 CUs -- ties at 1.27 and stays)
+        if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43
+                and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld)):
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel)
+            self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu))
             return y
         fmin = g.winograd_fused_min_channels
         # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs

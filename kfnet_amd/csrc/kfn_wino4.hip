@@ -1,0 +1,515 @@
+// kfn_wino4.hip -- single-kernel Winograd F(4x4,3x3) for the 3x3 stride-1 SAME layers with Cin >= 512
+// (tf.layers.conv2d behind Network.conv, cnn_wrapper/network.py:116-135; SCoordNet conv3b / conv4b / conv5,
+// cnn_wrapper/SCoordNet.py:26-30): 36 products per 4x4 outputs instead of 16 per 2x2 -- 2.25 multiplies per output
+// instead of 4 (F(2x2,3x3), kfn_wino3.hip) or 9 (direct).  fp32 throughout; interpolation points {0, +-1, +-2}:
+//
+//   B^T = [ 4  0 -5  0  1  0 ]   G = [ 1/4    0     0  ]   A^T = [ 1  1  1  1  1  0 ]
+//         [ 0 -4 -4  1  1  0 ]       [-1/6  -1/6  -1/6 ]         [ 0  1 -1  2 -2  0 ]
+//         [ 0  4 -4 -1  1  0 ]       [-1/6   1/6  -1/6 ]         [ 0  1  1  4  4  0 ]
+//         [ 0 -2 -1  2  1  0 ]       [ 1/24  1/12  1/6 ]         [ 0  1 -1  8 -8  1 ]
+//         [ 0  2 -1 -2  1  0 ]       [ 1/24 -1/12  1/6 ]
+//         [ 0  4  0 -5  0  1 ]       [ 0     0     1   ]
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A.  U = G g G^T is prepared on the host in fp64 (graph.pack_winograd_f43_kernel).
+//   Error budget on the full 12-layer SCoordNet (tools/experiments/f43_error_budget.py): coordinates 1.4e-6 max-abs
+//   against the fp64 convolution (F(2x2,3x3): 5e-7; the parity target is 1e-4).
+//
+// Structure = kfn_wino3.hip's, re-cut for 36 positions:
+//   * a workgroup of FOUR waves (one per SIMD) owns a block of 4 x 8 tiles (16 x 32 output pixels = the 32 rows of a
+//     32x32 MFMA) x 64 output channels.  Wave (wx, wc) accumulates the 18 positions (xi, nu), xi in {3 wx .. 3 wx + 2},
+//     for the 32 channels of column block wc: 18 accumulators of 32x32 = 288 registers.
+//   * V = B^T d B of a SUPER-STEP (16 input channels = 2 chunks of 8) is produced once per workgroup and shared through
+//     LDS: lane = (tile row of the wave's two, tile column, channel pair) gathers its tile's 6x6 patch for 2 channels
+//     (36 loads of 8 bytes; 8 neighbouring lanes read 64 contiguous bytes of a pixel; zero padding = out-of-range
+//     offsets), transforms it in registers (144 packed FMAs as one burst) and stores 36 x 8 bytes.  4 chunk buffers of
+//     [36 positions][2 k-halves][32 tiles][4 floats] (padded: the producer's stores and the consumer's fragment reads are
+//     bank-conflict free) = 153 KiB; the buffers written during super-step k are read during k+1: one barrier per
+//     super-step (144 MFMAs = 9.2 K cycles).
+//   * B fragments as in kfn_wino3.hip: U re-packed [Cin/8][36][cout_pad][8] (one 1 KiB run per (chunk, position, 32
+//     channels)), L2 -> registers through a ring one chunk deep.
+//   * Output transform: the nu pass is local to a wave (all six nu of its three xi); the xi pass splits into the wave's
+//     half and its partner's, so every wave evaluates its PARTIAL 4x4 outputs in registers and adds them into an LDS
+//     image [32 tiles][16 pixels][64 channels] (zero-filled; ds_add_f32 -- two addends per element, so the sum does not
+//     depend on their order); the image leaves as 16-byte stores, 16 lanes per 256 contiguous bytes of a pixel.
+#include "kfn_common.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned ROW_POISON = 0x80000000u;   // a row offset that fails the range check (two images stay below 2 GiB)
+constexpr int BW4 = 4, BH4 = 8;            // tile block: 4 (x) by 8 (y) tiles of 4x4 output pixels
+constexpr int NPOS = 36, WPOS = 18;        // positions in all / per wave
+constexpr int CPS = 2;                     // chunks of 8 input channels per super-step
+constexpr int VHALF = 32 * 16 + 32;        // one k-half of a position: [32 tiles][4 floats] + pad (8 dwords: see below)
+constexpr int VPOS = 2 * VHALF;
+constexpr int VBUF = NPOS * VPOS + 16;     // one chunk; the pad puts the two chunks of a super-step 4 dwords apart mod 32
+constexpr int LDS_V = 2 * CPS * VBUF;      // 156 928 B
+constexpr int LDS_OUT = 32 * 16 * 64 * 4;  // 131 072 B: the output image of the epilogue (overlays the V buffers)
+#ifndef KFN_W4_NB
+#define KFN_W4_NB 9
+#endif
+constexpr int NB = KFN_W4_NB;              // B ring: positions ahead (must divide 36; 9 = half a chunk = 2.3 K cycles)
+constexpr int NVR = 6;                     // V fragment ring (must divide 36)
+constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions x 4 k-steps
+// producer schedule inside the 144 slots of a super-step
+#ifndef KFN_W4_GSTEP
+#define KFN_W4_GSTEP 2      // one patch load every GSTEP slots, from slot 0
+#define KFN_W4_XSLOT 100    // the transform burst
+#define KFN_W4_SSLOT 106    // first V store, then one per slot
+#endif
+// timing experiments only (wrong results on purpose; tools/mb/build_w4.sh): bit 0 no transform, 1 no patch loads,
+// 2 no V stores, 3 no B loads in the main loop
+#ifndef KFN_W4_DBG
+#define KFN_W4_DBG 0
+#endif
+static_assert(36 * KFN_W4_GSTEP <= KFN_W4_XSLOT && KFN_W4_XSLOT < KFN_W4_SSLOT && KFN_W4_SSLOT + 36 <= CPS * SPC, "producer schedule");
+static_assert(36 % NB == 0 && 36 % NVR == 0 && LDS_OUT <= LDS_V, "ring slots are compile-time constants per super-step");
+
+struct Wino4Args {
+  const float* x;
+  const float* u4;    // [Cin/8][36][cout_pad][8]
+  const float* bias;
+  float* y;
+  int N, H, W, Cin, ldx;
+  int Cout, cout_pad, ldy;
+  int Th, Tw;         // tiles per image (4x4 output pixels each)
+  int vrows;          // N * Th: tile rows of the whole batch, image after image
+  int bw;             // ceil(Tw / 4) column blocks
+  int tiles_m, tiles_n;
+  int relu;
+  int n_fast;
+  unsigned long long x_bytes;
+  unsigned long long y_bytes;
+  unsigned u_bytes;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor4_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor4_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor4(F&& f) {
+  sfor4_impl<0, N>(f);
+}
+
+__device__ __forceinline__ int xcd_remap4(int b, int nwg) {
+  int xcd = b & 7;
+  int q = nwg >> 3, r = nwg & 7;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+// packed fp32 helpers (two channels per register pair).  Constants ride in SGPR pairs.
+__device__ __forceinline__ f32x2 pk_add4(const f32x2& a, const f32x2& b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub4(const f32x2& a, const f32x2& b) {   // a - b
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_fma4(const f32x2& a, const f32x2& k, const f32x2& c) {   // a * k + c, k wave-uniform
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_mul4(const f32x2& a, const f32x2& k) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k));
+  return r;
+}
+
+struct BtConst {
+  f32x2 p4, m4, m5, p2, m2;
+};
+// one 1-D pass of B^T on six register pairs, in place:
+//   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   t3 = (d4 - d2) + 2 (d3 - d1)   t4 = (d4 - d2) - 2 (d3 - d1)       t5 = 4 d1 - 5 d3 + d5
+__device__ __forceinline__ void bt6(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5, const BtConst& k) {
+  const f32x2 a = pk_fma4(d2, k.m4, d4);
+  const f32x2 b = pk_fma4(d1, k.m4, d3);
+  const f32x2 c = pk_sub4(d4, d2);
+  const f32x2 e = pk_sub4(d3, d1);
+  const f32x2 u = pk_fma4(d2, k.m5, d4);
+  const f32x2 v = pk_fma4(d3, k.m5, d5);
+  d0 = pk_fma4(d0, k.p4, u);
+  d5 = pk_fma4(d1, k.p4, v);
+  d1 = pk_add4(a, b);
+  d2 = pk_sub4(a, b);
+  d3 = pk_fma4(e, k.p2, c);
+  d4 = pk_fma4(e, k.m2, c);
+}
+__device__ __forceinline__ void bt_d_b6(f32x2 (&v)[36], const BtConst& k) {   // v[6 r + c] -> v[6 xi + nu]
+#pragma unroll
+  for (int r = 0; r < 6; ++r) bt6(v[6 * r + 0], v[6 * r + 1], v[6 * r + 2], v[6 * r + 3], v[6 * r + 4], v[6 * r + 5], k);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) bt6(v[c], v[6 + c], v[12 + c], v[18 + c], v[24 + c], v[30 + c], k);
+}
+
+__global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];   // [4][VBUF], later the output image
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wx = wave & 1, wc = wave >> 1;      // xi half, 32-channel column block
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap4(blockIdx.x, nwg);
+  const int tm = p.n_fast ? tile / p.tiles_n : tile % p.tiles_m;
+  const int tn = p.n_fast ? tile % p.tiles_n : tile / p.tiles_m;
+  const int cb = tm % p.bw, rb = tm / p.bw;
+  const int nbase = tn * 64;                    // the workgroup's 64 output channels
+  const int n0 = nbase + wc * 32;               // this wave's 32
+
+  // ---- block geometry (uniform) ----------------------------------------------------------
+  const int vr0 = rb * BH4;
+  const int img0 = vr0 / p.Th;
+  const int ty0 = vr0 - img0 * p.Th;
+  const int brk = (p.Th - ty0 < BH4) ? (p.Th - ty0) : BH4;   // tile rows >= brk belong to image img0 + 1 (Th >= 8)
+
+  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_rest = p.x_bytes - a_base;
+  const unsigned long long two_img = 2ull * p.H * p.W * p.ldx * 4ull;
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u4), 0, p.u_bytes, 0x00020000);
+
+  // ---- this lane as a PRODUCER: tile (tr = lane >> 3, tc = wave), channels 2 cp, 2 cp + 1 of the super-step's 16 ------
+  // The wave owns tile COLUMN `wave` of the block: the six patch columns are wave-uniform (scalar offsets; a column left or
+  // right of the image reads through a descriptor with num_records = 0), the rows are per lane (offset, or a mark that
+  // fails the range check).  No vector ALU work per load: every VALU instruction is paid in MFMA time here.
+  const int cp = lane & 7, ptr = lane >> 3;
+  unsigned roff[6];                     // per lane: byte offset of patch row r at this lane's channel pair, or ROW_POISON
+  unsigned coff[6];                     // uniform: byte offset of patch column c
+  bool cok[6];                          // uniform: column inside the image (and the tile column exists)
+  {
+    const int img_rel = ptr < brk ? 0 : 1;
+    const int ty = ptr < brk ? ty0 + ptr : ptr - brk;
+    const int tx = cb * BW4 + wave;
+    const bool row_tile_ok = (vr0 + ptr < p.vrows);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = 4 * ty - 1 + r;
+      roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
+                    ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(cp * 8) : ROW_POISON;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = 4 * tx - 1 + c;
+      cok[c] = (tx < p.Tw) && ((unsigned)xx < (unsigned)p.W);
+      coff[c] = cok[c] ? (unsigned)(xx * p.ldx * 4) : 0u;
+    }
+  }
+  const int x_records = (int)(a_rest < two_img ? a_rest : two_img);
+  // V store address of this lane inside a chunk buffer: chunk cp >> 2, k-half (cp >> 1) & 1, pair cp & 1, tile 4 ptr + wave
+  // (a ds_write_b64 group of 16 lanes = 8 channel pairs x 2 tile rows: dwords {0,2} + {0,8} + {0,4} + {0,16}: 32 banks once)
+  const int v_st = (cp >> 2) * VBUF + ((cp >> 1) & 1) * VHALF + (ptr * 4 + wave) * 16 + (cp & 1) * 8;
+  const int n_chunks = p.Cin / 8;
+  const int n_super = n_chunks / CPS;
+  const int s_last = n_super - 1;
+
+  // ---- this lane as a CONSUMER ---------------------------------------------------------------
+  const int li = lane & 31, lh = lane >> 5;
+  const int v_lane = (WPOS * wx) * VPOS + lh * VHALF + li * 16;          // position 18 wx + l: + l * VPOS
+  const unsigned voff_b = (unsigned)(((n0 + li) * 8 + lh * 4) * 4);
+  const unsigned b_step = (unsigned)p.cout_pad * 32u;                    // bytes between consecutive (chunk, position) fragments
+  const int q_last = n_chunks * NPOS - 1;
+
+  f32x16 acc[WPOS];
+#pragma unroll
+  for (int l = 0; l < WPOS; ++l)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[l][e] = 0.f;
+
+  f32x2 pv[36];        // producer: raw 6x6 patch -> V, two channels
+  f32x4 bq[NB];        // B ring
+  f32x4 vq[NVR];       // V fragment ring
+  BtConst kc;
+  kc.p4 = f32x2{4.f, 4.f}; kc.m4 = f32x2{-4.f, -4.f}; kc.m5 = f32x2{-5.f, -5.f}; kc.p2 = f32x2{2.f, 2.f}; kc.m2 = f32x2{-2.f, -2.f};
+
+  auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i / 6, c = i % 6;
+    const int sc = ss < s_last ? ss : s_last;     // past the end: re-read the last super-step (nobody consumes it)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
+    pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)(sc * 64), 0));
+  };
+  auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    *reinterpret_cast<f32x2*>(smem4 + (ss & 1) * (CPS * VBUF) + v_st + g * VPOS) = pv[g];
+  };
+  // this wave's fragment (chunk ch, local position l) = global fragment ch * 36 + 18 wx + l, into ring slot `sl`
+  auto b_load = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_)::value;
+    const int q = ch * NPOS + WPOS * wx + l;
+    const int qc = q < q_last ? q : q_last;
+    bq[sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)qc * b_step, 0));
+  };
+  auto v_read = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_)::value;
+    vq[sl] = *reinterpret_cast<const f32x4*>(smem4 + (ch & (2 * CPS - 1)) * VBUF + l * VPOS + v_lane);
+  };
+
+  // ---- prologue: the workgroup produces super-step 0; every wave fills its B ring --------------------------
+  sfor4<36>([&](auto ic) { p_gather(ic, 0); });
+  sfor4<NB>([&](auto sc) { b_load(sc, 0, decltype(sc)::value); });
+  bt_d_b6(pv, kc);
+  sfor4<36>([&](auto gc) { p_store(gc, 0); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- main loop: one super-step = 2 chunks x 72 MFMA slots ------------------------------------------------
+  // slot j of a chunk -> (position l, k-step t): four positions interleaved (groups 0..3), then the last two
+  for (int ks = 0; ks < n_super; ++ks) {
+    const int c0 = ks * CPS;
+    sfor4<NVR>([&](auto gc) { v_read(gc, c0, decltype(gc)::value); });
+    sfor4<CPS>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      const int ch = c0 + cc;
+      sfor4<SPC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int l = j < 64 ? (j >> 4) * 4 + (j & 3) : 16 + ((j - 64) & 1);
+        constexpr int t = j < 64 ? (j >> 2) & 3 : (j - 64) >> 1;
+        constexpr int qs = cc * WPOS + l;            // fragment index inside the super-step (36 per wave)
+        constexpr int sb = qs % NB, sv = qs % NVR;
+        // 18 accumulators are 288 registers, the accumulation file holds 256: hipcc gives every MFMA of a function the
+        // AGPR form, and accumulators 16 / 17 would be copied in and out around each of their MFMAs (496 v_accvgpr
+        // moves per super-step).  Their MFMAs are therefore written with VGPR destinations by hand; between two
+        // MFMAs on the same accumulator there is always at least one other MFMA (64 cycles), so the hardware's
+        // accumulator forwarding rules are met without software wait states.
+        if constexpr (l < 16) {
+          acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[sv][t], bq[sb][t], acc[l], 0, 0, 0);
+        } else {
+          const float av = vq[sv][t], bvv = bq[sb][t];
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[l]) : "v"(av), "v"(bvv));
+        }
+        if constexpr (t == 3) {
+          // the slots this position held are free: the B fragment one ring ahead, the V fragment NVR positions ahead
+          // (same chunk, or the next chunk of THIS super-step -- the next super-step's V is behind the barrier)
+          if constexpr (!(KFN_W4_DBG & 8)) {
+            if constexpr (l + NB < WPOS) b_load(std::integral_constant<int, sb>{}, ch, l + NB);
+            else b_load(std::integral_constant<int, sb>{}, ch + 1, l + NB - WPOS);
+          }
+          if constexpr (l + NVR < WPOS) v_read(std::integral_constant<int, sv>{}, ch, l + NVR);
+          else if constexpr (cc < CPS - 1) v_read(std::integral_constant<int, sv>{}, ch + 1, l + NVR - WPOS);
+        }
+        constexpr int sj = cc * SPC + j;
+        if constexpr (!(KFN_W4_DBG & 2) && sj < 36 * KFN_W4_GSTEP && sj % KFN_W4_GSTEP == 0)
+          p_gather(std::integral_constant<int, sj / KFN_W4_GSTEP>{}, ks + 1);
+        if constexpr (!(KFN_W4_DBG & 1) && sj == KFN_W4_XSLOT) bt_d_b6(pv, kc);
+        if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_SSLOT && sj < KFN_W4_SSLOT + 36)
+          p_store(std::integral_constant<int, sj - KFN_W4_SSLOT>{}, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------
+  // Partial output transform of this wave's 18 positions, reduced with the partner wave (same column block, other xi half)
+  // through the output image [32 tiles][16 px][64 ch] in LDS (every wave is behind the loop's last barrier: V is dead).
+  //   pass 1: the rows i of the 4x4 outputs that the PARTNER finishes (wave wx = 0 finishes i in {0,1}, wx = 1 i in {2,3})
+  //           are written to the image;  barrier;
+  //   pass 2: the rows this wave finishes: own partial + the partner's from the image -> back to the same addresses.
+  // (LDS atomics -- ds_add_f32 of both partials into a zeroed image -- were the first version: 220 K cycles per
+  //  workgroup, they serialise per lane.)  tile m = (e & 3) + 8 (e >> 2) + 4 lh, channel 32 wc + li:
+  //  float index (m * 16 + 4 i + j) * 64 + 32 wc + li
+  {
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+    float* const img = reinterpret_cast<float*>(smem4) + (lh * 4 * 1024 + wc * 32 + li);
+    // rows i0, i0 + 1 of the partial outputs of e-pair e0 for this wave's xi half (LOWER: xi in {0,1,2})
+    auto rows = [&](auto lower_half, auto e0c, auto i0c, f32x2 (&P)[2][4]) __attribute__((always_inline)) {
+      constexpr bool LOWER = decltype(lower_half)::value;
+      constexpr int e0 = decltype(e0c)::value, i0 = decltype(i0c)::value;
+      f32x2 R[3][4];     // nu pass: R[a][j] = sum_nu M[a][nu] A^T[j][nu]
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        f32x2 M[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) M[nu] = f32x2{acc[6 * a + nu][e0], acc[6 * a + nu][e0 + 1]};
+        const f32x2 s1 = pk_add4(M[1], M[2]), d1 = pk_sub4(M[1], M[2]);
+        const f32x2 s2 = pk_add4(M[3], M[4]), d2 = pk_sub4(M[3], M[4]);
+        R[a][0] = pk_add4(pk_add4(M[0], s1), s2);
+        R[a][1] = pk_fma4(d2, k2, d1);
+        R[a][2] = pk_fma4(s2, k4, s1);
+        R[a][3] = pk_add4(pk_fma4(d2, k8, d1), M[5]);
+      }
+      // xi pass over this wave's half: P[i][j] = sum_a A^T[i][xi_a] R[a][j]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (LOWER) {   // A^T columns 0..2: (1,0,0,0), (1,1,1,1), (1,-1,1,-1)
+          if constexpr (i0 == 0) {
+            P[0][j] = pk_add4(R[0][j], pk_add4(R[1][j], R[2][j]));
+            P[1][j] = pk_sub4(R[1][j], R[2][j]);
+          } else {
+            P[0][j] = pk_add4(R[1][j], R[2][j]);
+            P[1][j] = pk_sub4(R[1][j], R[2][j]);
+          }
+        } else {                 // A^T columns 3..5: (1,2,4,8), (1,-2,4,-8), (0,0,0,1)
+          if constexpr (i0 == 0) {
+            P[0][j] = pk_add4(R[0][j], R[1][j]);
+            P[1][j] = pk_mul4(pk_sub4(R[0][j], R[1][j]), k2);
+          } else {
+            P[0][j] = pk_mul4(pk_add4(R[0][j], R[1][j]), k4);
+            P[1][j] = pk_fma4(pk_sub4(R[0][j], R[1][j]), k8, R[2][j]);
+          }
+        }
+      }
+    };
+    auto reduce = [&](auto lower_half) __attribute__((always_inline)) {
+      constexpr bool LOWER = decltype(lower_half)::value;
+      constexpr int I_MINE = LOWER ? 0 : 2, I_THEIRS = LOWER ? 2 : 0;
+      sfor4<8>([&](auto epc) {
+        constexpr int e0 = 2 * decltype(epc)::value;
+        f32x2 P[2][4];
+        rows(lower_half, std::integral_constant<int, e0>{}, std::integral_constant<int, I_THEIRS>{}, P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m16 = (((e0 + h) & 3) + 8 * ((e0 + h) >> 2)) * 16;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) img[(m16 + (I_THEIRS + i) * 4 + j) * 64] = h == 0 ? P[i][j].x : P[i][j].y;
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sfor4<8>([&](auto epc) {
+        constexpr int e0 = 2 * decltype(epc)::value;
+        f32x2 P[2][4];
+        rows(lower_half, std::integral_constant<int, e0>{}, std::integral_constant<int, I_MINE>{}, P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m16 = (((e0 + h) & 3) + 8 * ((e0 + h) >> 2)) * 16;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float* const q = img + (m16 + (I_MINE + i) * 4 + j) * 64;
+              *q = *q + (h == 0 ? P[i][j].x : P[i][j].y);
+            }
+        }
+      });
+    };
+    if (wx == 0) reduce(std::true_type{});
+    else reduce(std::false_type{});
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // (3) the image leaves: iteration `it` = tile it, pixel row i = wave, column j = lane >> 4, channel quad lane & 15
+  {
+    const bool relu = p.relu != 0;
+    const unsigned long long y_base = (unsigned long long)img0 * p.H * p.W * p.ldy * 4ull;
+    const unsigned long long y_rest = p.y_bytes - y_base;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+    const int j = lane >> 4, nq = nbase + 4 * (lane & 15);
+    const bool q_ok = nq < p.Cout;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && q_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + nq);
+    const unsigned voff = (unsigned)((j * p.ldy + nq) * 4);
+    const int pix_bytes = p.ldy * 4;
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem4 + it * 4096 + wave * 1024 + lane * 16);
+      v += bv;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int tr = it >> 2, tcc = it & 3;
+      const int img_rel = tr < brk ? 0 : 1;
+      const int ty = tr < brk ? ty0 + tr : tr - brk;
+      const int tx = cb * BW4 + tcc;
+      const int oy = 4 * ty + wave;
+      const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
+      const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
+      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
+    }
+  }
+}
+
+}  // namespace
+
+// Can the F(4x4,3x3) kernel take this layer?  (host-side routing; no device access)
+extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
+  kfn_conv_desc d_full;
+  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_f43_supported") != KFN_OK) return 0;
+  d = &d_full;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->transposed) return 0;
+  if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32 || d->operand_dtype != KFN_OPERAND_F32) return 0;
+  if (d->Cin <= 0 || d->Cin % 16 != 0) return 0;
+  if ((d->H + 3) / 4 < BH4) return 0;               // an 8-row tile block may straddle at most two images
+  if (d->epilogue != KFN_EPI_NONE) return 0;
+  if (d->cout_pad % 32 != 0 || d->Cout % 4 != 0 || d->ldy % 4 != 0 || d->ldx % 2 != 0) return 0;
+  if (2L * d->H * d->W * d->ldx * 4L >= (1L << 30)) return 0;
+  return 1;
+}
+
+extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, const float* u4_packed, const float* bias,
+                                       float* y, void* stream) {
+  KFN_REQUIRE(d && x && u4_packed && y, "kfn_conv2d_winograd_f43: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_f43");
+  KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed,
+              "kfn_conv2d_winograd_f43: only 3x3 stride-1 SAME convolutions");
+  KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "kfn_conv2d_winograd_f43: bad shape %dx%dx%d", d->N, d->H, d->W);
+  KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32 && d->operand_dtype == KFN_OPERAND_F32 &&
+                  d->epilogue == KFN_EPI_NONE,
+              "kfn_conv2d_winograd_f43: fp32 operands and activations, no fused head epilogue");
+  if (d->Cin <= 0 || d->Cin % 16 != 0)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: Cin=%d must be a multiple of 16", d->Cin);
+  if ((d->H + 3) / 4 < BH4)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: H=%d is below %d rows", d->H, 4 * BH4 - 3);
+  KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 2 == 0 && d->Cout > 0 && d->ldy >= d->Cout && d->cout_pad >= d->Cout &&
+                  d->cout_pad % 32 == 0,
+              "kfn_conv2d_winograd_f43: bad strides / channel counts");
+  if (d->Cout % 4 != 0 || d->ldy % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: Cout and ldy must be multiples of 4 and y 16-byte aligned");
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) & 7) | (reinterpret_cast<uintptr_t>(u4_packed) & 15) |
+               (bias ? (reinterpret_cast<uintptr_t>(bias) & 15) : 0)) == 0,
+              "kfn_conv2d_winograd_f43: x must be 8-byte, u4_packed and bias 16-byte aligned");
+  const long img_b = (long)d->H * d->W * d->ldx * 4L;
+  const long out_b = (long)d->H * d->W * d->ldy * 4L;
+  if (2 * img_b >= (1L << 30) || 2 * out_b >= (1L << 31) || 36L * d->cout_pad * d->Cin * 4L >= (1L << 31))
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: image or kernel beyond the 32-bit offsets of this form");
+  Wino4Args a;
+  a.x = x; a.u4 = u4_packed; a.bias = bias; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
+  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
+  a.Th = (d->H + 3) / 4; a.Tw = (d->W + 3) / 4;
+  const long vrows = (long)d->N * a.Th;
+  KFN_REQUIRE(vrows < (1L << 30), "kfn_conv2d_winograd_f43: N*ceil(H/4) = %ld tile rows exceed 32-bit addressing", vrows);
+  a.vrows = (int)vrows;
+  a.bw = kfn::ceil_div(a.Tw, BW4);
+  const long tiles_m = (long)a.bw * kfn::ceil_div(a.vrows, BH4);
+  a.tiles_n = kfn::ceil_div(d->cout_pad, 64);
+  KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_f43: grid too large");
+  a.tiles_m = (int)tiles_m;
+  a.relu = d->relu;
+  a.n_fast = d->wino_order == KFN_WINO_ORDER_N_FAST ? 1 : 0;
+  const long in_pix = (long)d->N * d->H * d->W;
+  a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
+  a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
+  // the B ring prefetches whole 1 KiB fragments of 32 output channels: the last column block of a 32-but-not-64-multiple
+  // cout_pad reads 32 channels past the matrix -- the range check returns zeros for them (their accumulators are never stored)
+  a.u_bytes = (unsigned)(36L * d->cout_pad * d->Cin * 4L);
+  static std::atomic<uint64_t> attr_done{0};
+  int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);
+  if (rc != KFN_OK) return rc;
+  hipLaunchKernelGGL(wino4_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), LDS_V, (hipStream_t)stream, a);
+  KFN_LAUNCH_CHECK("wino4_kernel");
+  return KFN_OK;
+}

@@ -275,6 +275,27 @@ def pack_winograd_fused_kernel(w):
     return np.ascontiguousarray(u.reshape(g, cp, ci // 8, 8).transpose(2, 0, 1, 3))
 
 
+# Winograd F(4x4,3x3), interpolation points {0, +-1, +-2} (csrc/kfn_wino4.hip carries the same three matrices)
+_WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                     [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+_WINO4_BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                      [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+_WINO4_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+
+
+def pack_winograd_f43_kernel(w):
+    """TF HWIO [3,3,Cin,Cout] -> U4 [Cin/8][36][cout_pad][8] for kfn_conv2d_winograd_f43: U[6*xi+nu] = (G g G^T)[xi][nu]
+    of Winograd F(4x4,3x3), evaluated in fp64 and rounded once to fp32, laid out so that the 32-channel fragment of one
+    (8-channel k-chunk, position) is one contiguous 1 KiB run."""
+    kh, kw, ci, co = w.shape
+    assert kh == 3 and kw == 3 and ci % 8 == 0
+    cp = -(-co // 32) * 32
+    U = np.einsum('ai,ijco,bj->abco', _WINO4_G, np.asarray(w, np.float64), _WINO4_G)   # [6,6,ci,co]
+    u = np.zeros((36, cp, ci), dtype=np.float32)
+    u[:, :co, :] = np.transpose(U.reshape(36, ci, co), (0, 2, 1)).astype(np.float32)
+    return np.ascontiguousarray(u.reshape(36, cp, ci // 8, 8).transpose(2, 0, 1, 3))
+
+
 def pack_winograd_s2_kernel(w):
     """TF HWIO [3,3,Cin,Cout] -> the 16 weight fragments [Cin/8][16][cout_pad][8] of kfn_conv2d_winograd_s2
     (3x3 stride-2 conv as four stride-1 polyphase filters under F(2,2), csrc/kfn_wino_s2.hip): with
@@ -523,6 +544,39 @@ class WinogradFusedConvOp(ConvOp):
         rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
                                            self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_winograd_fused[%s]' % self.name)
+
+
+class WinogradF43ConvOp(ConvOp):
+    """3x3 stride-1 SAME conv through kfn_conv2d_winograd_f43 (csrc/kfn_wino4.hip): F(4x4,3x3), 36 positions split over
+    the four waves of a workgroup (18 accumulators each), one launch, no workspace -- for the Cin >= 512 layers."""
+
+    def __init__(self, name, x, y, kernel, bias, relu):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+
+    @staticmethod
+    def supported(x_shape, cin, cout, ldx=None):
+        n, h, w, _ = x_shape
+        ldx = cin if ldx is None else ldx
+        return cin % 16 == 0 and (h + 3) // 4 >= 8 and cout % 4 == 0 and 2 * h * w * ldx * 4 < (1 << 30)
+
+    def kernel_name(self, lib):
+        return 'wino4_kernel'
+
+    def mfma_flops(self):
+        """FLOPs the MFMAs execute: 36 positions x (tile blocks padded to 4x8 tiles of 4x4 pixels, batch rows packed) x
+        output channels padded to the workgroup's 64."""
+        n, ho, wo, cout = self.y.shape
+        n = _scaled(n, self.x.graph)
+        th, tw = (ho + 3) // 4, (wo + 3) // 4
+        tiles = (-(-tw // 4) * 4) * (-(-(n * th) // 8) * 8)
+        cpad = -(-cout // 64) * 64
+        return 2.0 * 36 * tiles * cpad * self.x.shape[3]
+
+    def launch(self, lib, stream, phases=3):
+        d = self.desc()
+        rc = lib.kfn_conv2d_winograd_f43(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                         self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        _lib.check(rc, 'kfn_conv2d_winograd_f43[%s]' % self.name)
 
 
 class WinogradS2ConvOp(ConvOp):
@@ -997,6 +1051,9 @@ class Graph(object):
         # cannot take (Cin % 16, fewer than 4 tile rows) fall back to the two-kernel form above
         self.winograd_fused = True
         self.winograd_fused_min_channels = 32   # (32: the flow-feature tower's feat3, 0.49 -> 0.35 ms at batch 32)
+        # F(4x4,3x3) (kfn_conv2d_winograd_f43) for 3x3 stride-1 layers with at least this many INPUT channels (0 = off):
+        # the K loop must amortise the 36-position transforms and the cross-wave output reduction
+        self.winograd_f43_min_channels = 512
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

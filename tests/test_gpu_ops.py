@@ -749,6 +749,57 @@ def test_winograd_fused_vs_oracle(case, relu):
     assert err <= 3 * _conv_tol(x, wt), err
 
 
+# (N, H, W, Cin, Cout): whole blocks, blocks straddling two images (Th % 8 != 0), ragged tile columns / rows (H, W not
+# multiples of 4 or 16), channel counts that leave waves past Cout (Cout % 64 != 0), one and many super-steps
+F43_CASES = [(2, 32, 16, 16, 64), (3, 60, 80, 32, 64), (2, 30, 40, 64, 128), (5, 36, 20, 16, 96), (1, 68, 120, 48, 72),
+             (3, 29, 35, 32, 100), (2, 120, 160, 16, 64), (9, 32, 16, 512, 64), (2, 60, 80, 1024, 128)]
+
+
+@pytest.mark.parametrize('relu', [1, 0])
+@pytest.mark.parametrize('case', F43_CASES)
+def test_winograd_f43_vs_oracle(case, relu):
+    """kfn_conv2d_winograd_f43 (F(4x4,3x3): 36 positions over the four waves of a workgroup, the xi half of the output
+    transform reduced across waves through LDS) == oracle up to fp32 round-off; strided input and output windows, guard
+    rows behind the tensor untouched.  Tolerance 8x the direct kernel's: the transforms carry factors up to 8."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_f43_kernel
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 43)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldx, ldy = ci + 8, co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=1, relu=relu)
+    assert lib.kfn_winograd_f43_supported(C.byref(d)) == 1
+    GUARD = 64
+    xb = np.full((n * h * w, ldx), 9.0, dtype=np.float32)      # the columns behind Cin must never be read into the sum
+    xb[:, :ci] = x.reshape(-1, ci)
+    y = torch.full((n * h * w + GUARD, ldy), -5.0, device='cuda')
+    dx, du, db = dev(xb), dev(pack_winograd_f43_kernel(wt)), dev(np.concatenate([b, np.zeros((-co) % 4, np.float32)]))
+    _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                           stream()), 'wino4')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, co:] == -5.0) and np.all(got[n * h * w:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 1, bool(relu))
+    err = np.abs(got[:n * h * w, :co].reshape(ref.shape) - ref).max()
+    assert err <= 8 * _conv_tol(x, wt), err
+
+
+def test_winograd_f43_rejects_what_it_cannot_do():
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    ok = dict(N=1, H=32, W=32, Cin=32, ldx=32, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1)
+    assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**ok))) == 1
+    for bad in (dict(H=28), dict(Cin=24, ldx=24), dict(stride=2), dict(Cout=62, ldy=62), dict(ldy=66), dict(x_dtype=1),
+                dict(operand_dtype=1), dict(epilogue=2), dict(kh=1, kw=1)):
+        assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**dict(ok, **bad)))) == 0, bad
+
+
 @pytest.mark.parametrize('case', [(3, 14, 33, 64, 64, 0), (2, 30, 40, 48, 40, 8), (5, 30, 40, 64, 256, 0)])
 def test_winograd_fused_forms_agree(case):
     """kfn_conv_desc.wino_form = KFN_WINO_FORM_ONE_WAVE (wino2_kernel) against the default route (two-wave / four-wave

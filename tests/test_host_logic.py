@@ -16,8 +16,11 @@ from kfnet_amd.weights import num_params, synthetic_weights, variable_specs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(B=2, H=480, W=640):
+def _build(B=2, H=480, W=640, **graph_options):
     g = Graph()
+    for k, v in graph_options.items():
+        assert hasattr(g, k)
+        setattr(g, k, v)
     img = g.placeholder((B, H, W, 3), 'u8')
     h, w = -(-H // 8), -(-W // 8)
     st = g.placeholder((1, h, w, 4))
@@ -85,14 +88,17 @@ def test_default_routes_of_the_3x3_layers():
     from kfnet_amd.graph import WinogradFusedConvOp, WinogradS2ConvOp
     g, net = _build(2)
     lib = _lib.load()            # kfn_conv2d_plan is host code: no GPU needed
-    four_wave = ('conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6')
-    asked = four_wave + ('conv1b', 'feat5', 'feat3', 'conv2a', 'conv3a', 'conv4a', 'feat6')
+    four_wave = ('conv2b', 'conv6')
+    f43 = ('conv3b', 'conv4b', 'conv5')          # Cin >= 512 and Cout >= 512: F(4x4,3x3), csrc/kfn_wino4.hip (round 4)
+    asked = four_wave + f43 + ('conv1b', 'feat5', 'feat3', 'conv2a', 'conv3a', 'conv4a', 'feat6')
     names = {}
     for op in g.ops:       # (first op of a name: SCoordNet / the feature tower come before OFlowNet's same-named layers)
         if op.name in asked and op.name not in names:
             names[op.name] = op.kernel_name(lib)
     for n in four_wave:
         assert names[n] == 'wino3_kernel', (n, names[n])
+    for n in f43:
+        assert names[n] == 'wino4_kernel', (n, names[n])
     assert names['conv1b'] == 'wino3_pair_kernel'            # 64 -> 64: two waves share one transform
     assert names['feat5'] == 'wino3_pair_kernel'
     assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
@@ -104,6 +110,14 @@ def test_default_routes_of_the_3x3_layers():
     assert isinstance(by_name['conv1b'], WinogradFusedConvOp) and by_name['conv1b'].two_wave()
     assert not by_name['conv2b'].two_wave() and by_name['conv2b'].four_wave()
     assert isinstance(by_name['conv2a'], WinogradS2ConvOp)
+    from kfnet_amd.graph import WinogradF43ConvOp
+    op4 = by_name['conv4b']
+    assert isinstance(op4, WinogradF43ConvOp)
+    n4, h4, w4, c4 = op4.y.shape            # 60x80: 15 x 20 tiles of 4x4 pixels, 5 column blocks, rows packed over the batch
+    assert op4.mfma_flops() == 2.0 * 36 * 20 * (-(-(n4 * 15) // 8) * 8) * 1024 * 1024
+    assert op4.flops() / op4.mfma_flops() == pytest.approx(4.0 * (n4 * 15) / (-(-(n4 * 15) // 8) * 8))   # 36 products per 16 outputs instead of 144
+    g0, net0 = _build(2, winograd_f43_min_channels=0)
+    assert all(type(op).__name__ != 'WinogradF43ConvOp' for op in g0.ops)
     # executed MFMA FLOPs of the two-wave form: all 64 channels in one column block (no padding to 128)
     op = by_name['conv1b']
     n, ho, wo, co = op.y.shape

@@ -291,3 +291,36 @@ def test_get_kf_coord2_symmetric_posterior():
     assert np.allclose(u2, u1, rtol=1e-12)
     half = O.get_kf_coord2(x, s, z, s)
     assert np.allclose(half[0], (x + z) / 2) and np.allclose(half[1], s / np.sqrt(2))
+
+
+def test_winograd_f43_matrices_and_partial_output_transform():
+    """The F(4x4,3x3) triple of kfnet_amd.graph (== csrc/kfn_wino4.hip) reproduces the oracle's 3x3 SAME convolution, the
+    packer's layout is the documented one, and the kernel's split of the output transform -- a full nu pass, then the xi
+    pass in two halves {0,1,2} / {3,4,5} whose partial 4x4 outputs are added -- equals A^T M A."""
+    from kfnet_amd.graph import _WINO4_AT as AT, _WINO4_BT as BT, _WINO4_G as G, pack_winograd_f43_kernel
+    rng = np.random.default_rng(43)
+    x = rng.normal(size=(1, 8, 12, 8))
+    w = rng.normal(size=(3, 3, 8, 5))
+    ref = O.conv2d_same(x, w, None, 1, False)
+    xp = np.zeros((1, 8 + 2, 12 + 2, 8))
+    xp[:, 1:9, 1:13] = x
+    U = np.einsum('ai,ijco,bj->abco', G, w, G)
+    got = np.zeros_like(ref)
+    for ty in range(2):
+        for tx in range(3):
+            d = xp[0, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6, :]                      # [6,6,ci]
+            V = np.einsum('ar,rcx,bc->abx', BT, d, BT)
+            M = np.einsum('abx,abxo->abo', V, U)                                        # [6,6,co]
+            # the kernel's order: nu pass for every xi, then the two xi halves
+            R = np.einsum('jn,ano->ajo', AT, M)                                         # [xi][j][co]
+            P0 = np.einsum('ia,ajo->ijo', AT[:, 0:3], R[0:3])
+            P1 = np.einsum('ia,ajo->ijo', AT[:, 3:6], R[3:6])
+            got[0, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4, :] = P0 + P1
+    assert np.abs(got - ref).max() < 1e-10
+    wf = rng.normal(size=(3, 3, 16, 40)).astype(np.float32)
+    u4 = pack_winograd_f43_kernel(wf)
+    assert u4.shape == (2, 36, 64, 8) and u4.dtype == np.float32
+    Uf = np.einsum('ai,ijco,bj->abco', G, wf.astype(np.float64), G)
+    for (ci, co, xi, nu) in ((0, 0, 0, 0), (9, 39, 3, 5), (15, 17, 5, 1)):
+        assert u4[ci // 8, 6 * xi + nu, co, ci % 8] == np.float32(Uf[xi, nu, ci, co])
+    assert np.all(u4[:, :, 40:, :] == 0)

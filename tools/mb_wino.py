@@ -53,6 +53,13 @@ for (name, H, W, ci, co) in LAYERS:
     if F16:
         w9 = w9.half()
     t_dir = float('nan') if (FUSED_ONLY and not F16) else timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(dd), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
+    f43 = ''
+    if os.environ.get('MB_F43', '1') == '1' and not F16 and lib.kfn_winograd_f43_supported(C.byref(dd)) == 1:
+        u4 = torch.randn(36 * co * ci, device='cuda') * 0.02
+        t4 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(dd), x.data_ptr(), u4.data_ptr(), None, y.data_ptr(), st), 'w4'))
+        M4 = N * (-(-H // 4)) * (-(-W // 4))
+        f43 = ' | F(4x4,3x3) %.3f ms (%.1f TF exec, %.2fx the F(2x2,3x3) kernel)' % (t4, 2.0 * 36 * M4 * ci * co / t4 / 1e9, t_fused / t4)
+        del u4
     print('%-7s %3dx%3d C%4d->%4d: FUSED %.3f ms (%.1f TF exec) | two-kernel %.3f ms = gemm %.3f (%.1f TF exec) + out %.3f | direct %.3f ms (%.1f TF)'
-          % (name, H, W, ci, co, t_fused, fl / t_fused / 1e9, t_gemm + t_out, t_gemm, fl / t_gemm / 1e9, t_out, t_dir, fl * 2.25 / t_dir / 1e9), flush=True)
+          % (name, H, W, ci, co, t_fused, fl / t_fused / 1e9, t_gemm + t_out, t_gemm, fl / t_gemm / 1e9, t_out, t_dir, fl * 2.25 / t_dir / 1e9) + f43, flush=True)
     del x, u, y, w9
