@@ -187,7 +187,7 @@ def kalman_roofline(device, S=256, T=64, H=60, W=80):
 
     def launch():
         _lib.check(lib.kfn_kalman_scan(C.byref(d), flow.data_ptr(), sig.data_ptr(), meas.data_ptr(),
-                                       state.data_ptr(), rec.data_ptr(), None, None, stream), 'scan')
+                                       state.data_ptr(), rec.data_ptr(), None, None, None, stream), 'scan')
     launch()
     torch.cuda.synchronize()
     reps = 5
@@ -747,7 +747,7 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
         k = by_kernel.setdefault(r[1], [0, 0.0, 0.0, 0.0])
         k[0] += 1; k[1] += r[2]; k[2] += r[3]; k[3] += r[4]
     heavy_ms = sum(r[3] for r in rows)
-    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7'))
+    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7', '8'))
     k16 = {k: v for k, v in by_kernel.items() if is16(k)}
     dom = max(k16, key=lambda k: k16[k][2])
     n_dom, fl_dom, ms_dom, ex_dom = k16[dom]
@@ -774,7 +774,8 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
                         'note': 'conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,PREC>: PREC 6 = direct implicit GEMM on '
                                 'v_mfma_f32_32x32x16_f16 with fp16 activations in AND out of HBM (tap-innermost K order, '
                                 'chunk-major weights, LDS-transposed 16-byte output runs), PREC 7 = the same with the weight '
-                                'tile going global -> LDS directly (buffer_load ... lds), PREC 4 = fp16 in / fp32 out, PREC 1 = '
+                                'tile going global -> LDS directly (buffer_load ... lds), PREC 8 = both operand tiles that way (the '
+                                'eight-wave 256x256 tile <4,2,2,4,...>), PREC 4 = fp16 in / fp32 out, PREC 1 = '
                                 'fp16 operands rounded while staging fp32 activations (OFlowNet, feature tower); '
                                 'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
                                 'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},

@@ -15,7 +15,10 @@
  *     host threads may call with distinct streams, on any device: launches go to the
  *     calling thread's current device, kernel attributes are set per device).
  *   - `stream` is a hipStream_t (NULL = the default stream).  All work is asynchronous
- *     on that stream and is hipGraph-capturable (no allocation / sync inside a launch).
+ *     on that stream and hipGraph-capturable: no entry point allocates, frees or synchronises
+ *     (kfn_malloc / kfn_free / kfn_stream_sync / kfn_event_elapsed_ms / kfn_comm_init are the
+ *     plumbing exceptions and say so).  Scratch memory, where a launch needs it, is the caller's
+ *     (kfn_winograd_workspace_bytes, kfn_kalman_scan_scratch_bytes).
  *   - A "pixel stride" (ldx / ldy) is the distance in floats between consecutive
  *     pixels; it lets a layer read or write a channel slice of a wider buffer, which is
  *     how `Network.concat` (cnn_wrapper/network.py:316-318) is realised without copies.
@@ -166,7 +169,18 @@ int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
  * measured launch times to kernel names. */
 int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles);
 
-/* Winograd F(2x2,3x3) variant for 3x3 stride-1 SAME convolutions (same arguments and
+/* Which entry points the default graph (kfnet_amd.KFNet / KFNetEngine) launches, and which it does not
+ *   ON the default route: kfn_first_conv_u8[_ex], kfn_conv2d_nhwc, kfn_conv2d_winograd_fused, kfn_conv2d_winograd_f43,
+ *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head, kfn_oflow_tail2, kfn_kalman_scan[_ex], kfn_eval_metrics,
+ *     kfn_send_state / kfn_recv_state (multi-GPU), kfn_copy_channels (concat fallback).
+ *   LEGACY -- earlier forms of the same operators, superseded on the default route, kept as tested stand-alone
+ *     operators (and reachable through the Graph switches named in DESIGN.md): kfn_conv2d_winograd (+
+ *     kfn_winograd_workspace_bytes / kfn_winograd_plan: the two-kernel Winograd form), kfn_cost_volume (materialising),
+ *     kfn_cost_volume_conv (volume generated in conv0's loader), kfn_cost_volume_gather, kfn_flow_softargmax,
+ *     kfn_flow_head, kfn_oflow_tail.  A maintainer wiring the reference to this library needs none of them.
+ *   Reference API beside eval.py's path: kfn_kalman_fuse, kfn_kalman_fuse2 (KFNet.BuildKFCoord / GetKFCoord2 alone). */
+
+/* [LEGACY: two-kernel form]  Winograd F(2x2,3x3) variant for 3x3 stride-1 SAME convolutions (same arguments and
  * result as kfn_conv2d_nhwc up to fp32 round-off, 2.25x fewer MFMA FLOPs): 16 GEMMs on the
  * MFMA kernel with the B^T d B input transform evaluated in its loader, then A^T M A +
  * bias + ReLU.  u_packed = [16][cout_pad][Cin], group g = 4*xi+nu holding (G g G^T)[xi][nu]
@@ -239,13 +253,13 @@ int kfn_first_conv_u8_ex(const uint8_t* img, int N, int H, int W,
                          const float* w1, const float* b1, void* y1, int C1, int y1_dtype,
                          const float* w2, const float* b2, float* y2, int C2, void* stream);
 
-/* ---- KFNet.BuildCoordVolume + reshape (KFNet/KFNet.py:343-359, :372) -----------------
+/* ---- [LEGACY: materialising]  KFNet.BuildCoordVolume + reshape (KFNet/KFNet.py:343-359, :372) ----
  * vol[n, y, x, i, j, c] = f2[n,y,x,c] - f1[n, y+i-w/2, x+j-w/2, c]  (0 outside).
  * f1, f2: [N,H,W,C] (C % 4 == 0); vol: [N*H*W, window, window, C]. */
 int kfn_cost_volume(const float* f1, const float* f2, float* vol, int N, int H, int W, int C,
                     int window, void* stream);
 
-/* BuildCoordVolume fused into OFlowNet's first conv (cnn_wrapper/OFlowNet.py:19, 3x3 SAME on
+/* [LEGACY: Graph.factor_cost_volume = False]  BuildCoordVolume fused into OFlowNet's first conv (cnn_wrapper/OFlowNet.py:19, 3x3 SAME on
  * the 8x8 window grid): y[p, i, j, :] = act(conv0(vol)[p, i, j, :]) with vol generated inside
  * the MFMA kernel's loader (window fixed at 8, kernel 3x3); the 39 MB/frame volume never
  * exists in HBM.  f1, f2 [N,H,W,C] (C % 16 == 0); w_packed [cout_pad][9*C] as for
@@ -263,17 +277,18 @@ int kfn_cost_volume_conv(const float* f1, const float* f2, const float* w_packed
  * (kfn_pad_nhwc pads f1 by 2); this launch gathers, subtracts and applies the ReLU into the
  * [(N*H*W),8,8,C] tensor conv0 used to produce (pixel stride ldy). */
 int kfn_pad_nhwc(const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+/* [LEGACY: Graph.fuse_oflow_window = False -- kfn_oflow_head / kfn_oflow_tail2 evaluate T - G where they need it] */
 int kfn_cost_volume_gather(const float* T, const float* Gp, float* y, int N, int H, int W, int C,
                            int ldy, int relu, void* stream);
 
-/* ---- softmax over the window cells + soft-argmax flow ---------------------------------
+/* ---- [LEGACY: debug_prob path]  softmax over the window cells + soft-argmax flow ---------
  * OFlowNet.GetOutput softmax (OFlowNet.py:45-47) + KFNet.BuildOFlowNet flow
  * (KFNet/KFNet.py:381-385): flow[p] = sum_k softmax(logits[p])_k * (j-w/2, i-w/2).
  * logits [P, window*window] (row-major i,j); flow_xy [P,2]; prob [P,window^2] or NULL. */
 int kfn_flow_softargmax(const float* logits, float* flow_xy, float* prob, int P, int window,
                         void* stream);
 
-/* ---- fused flow head: OFlowNet 'prediction' conv + softmax + soft-argmax ----------------
+/* ---- [LEGACY: Graph.fuse_oflow_tail = False]  fused flow head: 'prediction' conv + softmax + soft-argmax ----
  * cnn_wrapper/OFlowNet.py:41 (3x3 conv C->1, SAME, no ReLU on the 8x8 window grid) +
  * OFlowNet.py:45-47 + KFNet/KFNet.py:381-385 in one kernel; the 64 logits stay on chip.
  * x [P,8,8,C] (C % 4 == 0, C <= 32); w [3,3,C] = the TF kernel [3,3,C,1] flattened;
@@ -281,7 +296,7 @@ int kfn_flow_softargmax(const float* logits, float* flow_xy, float* prob, int P,
 int kfn_flow_head(const float* x, const float* w, const float* bias, float* flow_xy,
                   float* opt_logits, int P, int C, void* stream);
 
-/* OFlowNet's tail for every window in ONE launch: conv6 (3x3, 48 -> 16, ReLU; cnn_wrapper/OFlowNet.py:36-40) on
+/* [LEGACY: Graph.fuse_oflow_window = False]  OFlowNet's tail for every window in ONE launch: conv6 (3x3, 48 -> 16, ReLU; cnn_wrapper/OFlowNet.py:36-40) on
  * x = concat0 [P,8,8,48], the 'prediction' conv (3x3, 16 -> 1, linear; OFlowNet.py:41), the softmax over the 64
  * cells (OFlowNet.py:45-47) and the soft-argmax flow (KFNet/KFNet.py:381-385) -> flow_xy [P,2] (and the 64 logits
  * per window into opt_logits when given).  One wave per window, the patch resident in LDS, conv6's weights in
@@ -319,8 +334,10 @@ int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int re
  *     optional NIS gate on the OUTPUT only, record = (T.x, 1/sigma) via ApplyTransform
  *     (KFNet/util.py:12-40).
  * Grids above 10 240 pixels (state > 160 KB) run one launch per frame with the state
- * ping-ponging between `state` and a stream-ordered scratch copy (hipMallocAsync); results
- * are the same function of the inputs.
+ * ping-ponging between `state` and `scratch`, a second copy of the state the CALLER provides
+ * (kfn_kalman_scan_scratch_bytes; 0 bytes -- scratch may be NULL -- for every grid that fits
+ * the LDS, which includes BASELINE's 60x80 and 68x120); results are the same function of the
+ * inputs.
  */
 typedef struct kfn_kalman_desc {
   int32_t S, T, H, W;
@@ -332,6 +349,7 @@ typedef struct kfn_kalman_desc {
   float transform[12];   /* first 3 rows of inv(transform.txt), row-major */
 } kfn_kalman_desc;
 
+int kfn_kalman_scan_scratch_bytes(const kfn_kalman_desc* desc, size_t* bytes);
 int kfn_kalman_scan(const kfn_kalman_desc* desc,
                     const float* flow_xy,     /* [S,T,H*W,2] */
                     const float* sigma_trans, /* [S,T,H*W]   */
@@ -340,6 +358,7 @@ int kfn_kalman_scan(const kfn_kalman_desc* desc,
                     float* records,           /* [S,T,H*W,4] = (T.x, 1/sigma) */
                     float* opt_temp,          /* [S,T,H*W,4] = (x^-, sigma^-) or NULL */
                     float* opt_nis,           /* [S,T,H*W,3] or NULL */
+                    void* scratch,            /* kfn_kalman_scan_scratch_bytes() bytes, 16-byte aligned, or NULL when 0 */
                     void* stream);
 
 /* The same scan with the extra debug outputs eval.py's log line is computed from:
@@ -351,7 +370,7 @@ int kfn_kalman_scan(const kfn_kalman_desc* desc,
  * State, records and the NIS gate are unaffected.  kfn_kalman_scan == kfn_kalman_scan_ex(.., NULL, 0, ..). */
 int kfn_kalman_scan_ex(const kfn_kalman_desc* desc, const float* flow_xy, const float* sigma_trans,
                        const float* meas, float* state, float* records, float* opt_temp, float* opt_nis,
-                       float* opt_kf, int raw_on_reset, void* stream);
+                       float* opt_kf, int raw_on_reset, void* scratch, void* stream);
 
 /* ---- evaluation numbers of eval.py, reduced on the device --------------------------------
  * KFNet.CoordLossWithUncertainty(downsample=True) x3 (KFNet/KFNet.py:192-232 via KFNet/train.py:252-257),

@@ -259,8 +259,9 @@ class Network(object):
             self._emit(WindowFcConvOp(name, input, y, kern, bias, relu))
             return y
         f43 = g.winograd_f43_min_channels
-        # (measured at batch 32, F(2x2,3x3) -> F(4x4,3x3): conv3b 9.67 -> 6.46 ms, conv4b 9.25 -> 6.32, conv5 4.61 -> 3.28;
-        #  conv6 -- 512 -> 256 channels, 1200 workgroups = 4.7 rounds of the 256 CUs -- ties at 1.27 and stays)
+        # (measured at batch 32, F(2x2,3x3) -> F(4x4,3x3), profiles/r04_wino4_microbench.log: conv2b 10.02 -> 6.99 ms,
+        #  conv3b 9.30 -> 6.41, conv4b 9.18 -> 6.26, conv5 4.61 -> 3.28, conv6 1.24 -> 0.85, conv1b 3.66 -> 2.77, feat5 0.23 -> 0.18;
+        #  with 32 output channels -- feat3 -- half of the workgroup idles: 0.31 -> 0.47, stays on wino2_kernel)
         if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43
                 and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel)

@@ -309,10 +309,18 @@ int launch_scan(const KalmanArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int kfn_kalman_scan_scratch_bytes(const kfn_kalman_desc* d, size_t* bytes) {
+  KFN_REQUIRE(d && bytes, "kfn_kalman_scan_scratch_bytes: null argument");
+  KFN_REQUIRE(d->S > 0 && d->H > 1 && d->W > 1, "kfn_kalman_scan_scratch_bytes: bad shape S=%d H=%d W=%d", d->S, d->H, d->W);
+  const size_t hw = (size_t)d->H * d->W;
+  *bytes = hw * 16 > 160 * 1024 ? (size_t)d->S * hw * 16 : 0;   // a second copy of the state, only when it cannot live in LDS
+  return KFN_OK;
+}
+
 extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy,
                                   const float* sigma_trans, const float* meas, float* state,
                                   float* records, float* opt_temp, float* opt_nis, float* opt_kf,
-                                  int raw_on_reset, void* stream) {
+                                  int raw_on_reset, void* scratch_buf, void* stream) {
   KFN_REQUIRE(d && flow_xy && sigma_trans && meas && state && records, "kfn_kalman_scan: null argument");
   KFN_REQUIRE(d->S > 0 && d->T > 0 && d->H > 1 && d->W > 1, "kfn_kalman_scan: bad shape S=%d T=%d H=%d W=%d",
               d->S, d->T, d->H, d->W);
@@ -334,11 +342,15 @@ extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy
   a.d = *d;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if ((size_t)HW * 16 > 160 * 1024) {
-    // state larger than the LDS: per-frame launches, state ping-pong in global memory (the
-    // second copy is stream-ordered scratch, the only allocation this library ever makes)
+    // state larger than the LDS: per-frame launches, state ping-pong between `state` and the CALLER's scratch copy
+    // (kfn_kalman_scan_scratch_bytes): nothing is allocated here, the T launches are stream-ordered and capturable.
+    // (A single cooperative launch with a grid barrier per frame was the alternative: ~4 us per barrier against ~1.5 us
+    //  per dependent launch boundary on this part -- MI355X_MICROARCH.md's price list -- so the launches stay.)
     const size_t bytes = (size_t)d->S * HW * sizeof(f32x4);
-    f32x4* scratch = nullptr;
-    KFN_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s));
+    KFN_REQUIRE(scratch_buf != nullptr && (reinterpret_cast<uintptr_t>(scratch_buf) & 15) == 0,
+                "kfn_kalman_scan: a %dx%d grid does not fit the LDS: pass a 16-byte aligned scratch buffer of "
+                "kfn_kalman_scan_scratch_bytes() = %zu bytes", d->H, d->W, bytes);
+    f32x4* scratch = reinterpret_cast<f32x4*>(scratch_buf);
     f32x4* buf[2] = {a.state, scratch};
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)d->S);
     int rc = KFN_OK;
@@ -348,9 +360,7 @@ extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy
     }
     if (rc == KFN_OK && (d->T & 1))
       rc = kfn::check_hip(hipMemcpyAsync(a.state, scratch, bytes, hipMemcpyDeviceToDevice, s), "state copy-back");
-    // the scratch copy is released on every path (stream-ordered: after the launches above)
-    const int rc_free = kfn::check_hip(hipFreeAsync(scratch, s), "hipFreeAsync(scratch)");
-    return rc != KFN_OK ? rc : rc_free;
+    return rc;
   }
   // 768 threads (12 wavefronts, 170-VGPR budget) x 7 pixels cover the 60x80 grid without
   // register spills; larger grids fall back to 1024 threads and the single-buffer form.
@@ -364,8 +374,8 @@ extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy
 
 extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
                                const float* sigma_trans, const float* meas, float* state,
-                               float* records, float* opt_temp, float* opt_nis, void* stream) {
-  return kfn_kalman_scan_ex(d, flow_xy, sigma_trans, meas, state, records, opt_temp, opt_nis, nullptr, 0, stream);
+                               float* records, float* opt_temp, float* opt_nis, void* scratch, void* stream) {
+  return kfn_kalman_scan_ex(d, flow_xy, sigma_trans, meas, state, records, opt_temp, opt_nis, nullptr, 0, scratch, stream);
 }
 
 extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt_nis,

@@ -19,18 +19,27 @@
 //     32x32 MFMA) x 64 output channels.  Wave (wx, wc) accumulates the 18 positions (xi, nu), xi in {3 wx .. 3 wx + 2},
 //     for the 32 channels of column block wc: 18 accumulators of 32x32 = 288 registers.
 //   * V = B^T d B of a SUPER-STEP (16 input channels = 2 chunks of 8) is produced once per workgroup and shared through
-//     LDS: lane = (tile row of the wave's two, tile column, channel pair) gathers its tile's 6x6 patch for 2 channels
-//     (36 loads of 8 bytes; 8 neighbouring lanes read 64 contiguous bytes of a pixel; zero padding = out-of-range
-//     offsets), transforms it in registers (144 packed FMAs as one burst) and stores 36 x 8 bytes.  4 chunk buffers of
-//     [36 positions][2 k-halves][32 tiles][4 floats] (padded: the producer's stores and the consumer's fragment reads are
-//     bank-conflict free) = 153 KiB; the buffers written during super-step k are read during k+1: one barrier per
-//     super-step (144 MFMAs = 9.2 K cycles).
+//     LDS: wave w owns tile COLUMN w of the block, lane = (tile row, channel pair) gathers its tile's 6x6 patch for 2
+//     channels (36 loads of 8 bytes; 8 neighbouring lanes read 64 contiguous bytes of a pixel; patch columns are
+//     wave-uniform scalar offsets, columns outside the image read through a zero-length descriptor, rows outside carry
+//     an offset that fails the range check: zero padding costs no instruction), transforms it in registers (144 packed
+//     FMAs as one burst) and stores 36 x 8 bytes.  4 chunk buffers of [36 positions][2 k-halves][32 tiles][4 floats]
+//     (padded: the producer's stores and the consumer's fragment reads are bank-conflict free) = 153 KiB; the buffers
+//     written during super-step k are read during k+1: one barrier per super-step (144 MFMAs = 9.2 K cycles).
 //   * B fragments as in kfn_wino3.hip: U re-packed [Cin/8][36][cout_pad][8] (one 1 KiB run per (chunk, position, 32
 //     channels)), L2 -> registers through a ring one chunk deep.
 //   * Output transform: the nu pass is local to a wave (all six nu of its three xi); the xi pass splits into the wave's
-//     half and its partner's, so every wave evaluates its PARTIAL 4x4 outputs in registers and adds them into an LDS
-//     image [32 tiles][16 pixels][64 channels] (zero-filled; ds_add_f32 -- two addends per element, so the sum does not
-//     depend on their order); the image leaves as 16-byte stores, 16 lanes per 256 contiguous bytes of a pixel.
+//     half and its partner's (same column block, other xi half).  Through an LDS image [32 tiles][16 pixels][64 channels]
+//     the partners exchange: each writes the two output rows the OTHER finishes, barrier, each adds what it received to
+//     its own partial for the two rows it finishes (a + b in one fixed order per element: deterministic); the image then
+//     leaves as 16-byte stores, 16 lanes per 256 contiguous bytes of a pixel.
+//   * 18 accumulators = 288 registers exceed the 256 of the accumulation file: 16 live there (builtin MFMAs), two in
+//     VGPRs (MFMAs written by hand with VGPR destinations -- hipcc gives all MFMAs of a function one register class).
+//
+// Measured (profiles/r04_wino4_microbench.log, batch 32): 1.43-1.48x wino3_kernel on conv2b / 3b / 4b / 5 / 6, 1.3x on the
+// 64-channel layers; 113-116 executed TFLOP/s = 0.72-0.74 of the fp32 MFMA peak (wino3: 0.88).  Where the rest goes
+// (timing builds, conv4b): patch loads 12 % (7 % issue even when they hit L1 -- 36 loads per 144 MFMAs and wave --, 5 %
+// memory), the transform burst 6 %, weight-fragment latency 2 %, prologue + epilogue ~5 %.
 #include "kfn_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -63,7 +72,8 @@ constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions
 #define KFN_W4_SSLOT 106    // first V store, then one per slot
 #endif
 // timing experiments only (wrong results on purpose; tools/mb/build_w4.sh): bit 0 no transform, 1 no patch loads,
-// 2 no V stores, 3 no B loads in the main loop
+// 2 no V stores, 3 no B loads in the main loop, 4 every patch load of the main loop re-reads super-step 0 (L1/L2-hot
+// activations), 5 every B load re-reads chunk 0 (L2-hot weights)
 #ifndef KFN_W4_DBG
 #define KFN_W4_DBG 0
 #endif
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     constexpr int r = i / 6, c = i % 6;
-    const int sc = ss < s_last ? ss : s_last;     // past the end: re-read the last super-step (nobody consumes it)
+    const int sc = (KFN_W4_DBG & 16) ? 0 : (ss < s_last ? ss : s_last);     // past the end: re-read the last super-step (nobody consumes it)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
     pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)(sc * 64), 0));
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   // this wave's fragment (chunk ch, local position l) = global fragment ch * 36 + 18 wx + l, into ring slot `sl`
   auto b_load = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_)::value;
-    const int q = ch * NPOS + WPOS * wx + l;
+    const int q = ((KFN_W4_DBG & 32) ? 0 : ch) * NPOS + WPOS * wx + l;
     const int qc = q < q_last ? q : q_last;
     bq[sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)qc * b_step, 0));
   };

@@ -251,8 +251,12 @@ class KFNetEngine(object):
             for i, v in enumerate(np.asarray(self.transform, np.float32)[:3, :4].reshape(-1)):
                 d.transform[i] = float(v)
         import ctypes as C
+        need = C.c_size_t(0)
+        _lib.check(lib.kfn_kalman_scan_scratch_bytes(C.byref(d), C.byref(need)), 'kfn_kalman_scan_scratch_bytes')
+        scratch = torch.empty((need.value + 3) // 4, device=self.device) if need.value else None
         _lib.check(lib.kfn_kalman_scan(C.byref(d), self.c_flow.ptr, self.c_sigma.ptr, self.c_meas.ptr,
-                                       states.data_ptr(), rec.data_ptr(), None, None, stream), 'kfn_kalman_scan')
+                                       states.data_ptr(), rec.data_ptr(), None, None,
+                                       scratch.data_ptr() if scratch is not None else None, stream), 'kfn_kalman_scan')
         return rec.view(S, T, self.h, self.w, 4)
 
     def records(self, T):

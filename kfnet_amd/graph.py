@@ -985,6 +985,17 @@ class KalmanScanOp(Op):
         self.nis_gate = nis_gate
         self.transform = transform
         self.t0 = 0
+        self._scratch = None     # second copy of the state for grids that do not fit the LDS (the caller's to provide)
+
+    def scratch_ptr(self, lib, d):
+        need = C.c_size_t(0)
+        _lib.check(lib.kfn_kalman_scan_scratch_bytes(C.byref(d), C.byref(need)), 'kfn_kalman_scan_scratch_bytes')
+        if need.value == 0:
+            return None
+        if self._scratch is None or self._scratch.numel() * 4 < need.value:
+            import torch
+            self._scratch = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=self.state.root_storage.buf.device)
+        return self._scratch.data_ptr()
 
     def launch(self, lib, stream):
         d = _lib.KalmanDesc(S=self.S, T=self.T, H=self.H, W=self.W, t0=int(self.t0),
@@ -998,7 +1009,7 @@ class KalmanScanOp(Op):
                                     self.records.ptr, self.temp.ptr if self.temp is not None else None,
                                     self.nis.ptr if self.nis is not None else None,
                                     self.kf_raw.ptr if self.kf_raw is not None else None,
-                                    int(bool(self.raw_on_reset)), stream)
+                                    int(bool(self.raw_on_reset)), self.scratch_ptr(lib, d), stream)
         _lib.check(rc, 'kfn_kalman_scan')
 
 
@@ -1053,7 +1064,7 @@ class Graph(object):
         self.winograd_fused_min_channels = 32   # (32: the flow-feature tower's feat3, 0.49 -> 0.35 ms at batch 32)
         # F(4x4,3x3) (kfn_conv2d_winograd_f43) for 3x3 stride-1 layers with at least this many INPUT channels (0 = off):
         # the K loop must amortise the 36-position transforms and the cross-wave output reduction
-        self.winograd_f43_min_channels = 512
+        self.winograd_f43_min_channels = 64
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

@@ -258,8 +258,17 @@ def test_kalman_scan_vs_oracle(cfg):
     rec = torch.zeros(S * T * H * W * 4, device='cuda')
     tmp = torch.zeros(S * T * H * W * 4, device='cuda')
     nis = torch.zeros(S * T * H * W * 3, device='cuda')
+    need = C.c_size_t(99)
+    _lib.check(lib.kfn_kalman_scan_scratch_bytes(C.byref(d), C.byref(need)), 'scratch bytes')
+    assert need.value == (S * H * W * 16 if H * W > 10240 else 0)      # a second copy of the state iff it cannot live in LDS
+    scratch = torch.empty(need.value // 4, device='cuda') if need.value else None
+    if need.value:     # the library allocates nothing: without the caller's scratch a large grid is an argument error
+        assert lib.kfn_kalman_scan(C.byref(d), dfl.data_ptr(), dsg.data_ptr(), dme.data_ptr(), dst.data_ptr(),
+                                   rec.data_ptr(), tmp.data_ptr(), nis.data_ptr(), None, stream()) == -1
+        assert b'scratch' in lib.kfn_last_error()
     _lib.check(lib.kfn_kalman_scan(C.byref(d), dfl.data_ptr(), dsg.data_ptr(), dme.data_ptr(), dst.data_ptr(),
-                                   rec.data_ptr(), tmp.data_ptr(), nis.data_ptr(), stream()), 'scan')
+                                   rec.data_ptr(), tmp.data_ptr(), nis.data_ptr(),
+                                   scratch.data_ptr() if scratch is not None else None, stream()), 'scan')
     sync()
     r_rec, r_tmp, r_nis, r_state = _scan_ref(flow, sig, meas, state0, T4, t0, rp, gate)
     g_rec = rec.cpu().numpy().reshape(r_rec.shape)

@@ -88,9 +88,9 @@ def test_default_routes_of_the_3x3_layers():
     from kfnet_amd.graph import WinogradFusedConvOp, WinogradS2ConvOp
     g, net = _build(2)
     lib = _lib.load()            # kfn_conv2d_plan is host code: no GPU needed
-    four_wave = ('conv2b', 'conv6')
-    f43 = ('conv3b', 'conv4b', 'conv5')          # Cin >= 512 and Cout >= 512: F(4x4,3x3), csrc/kfn_wino4.hip (round 4)
-    asked = four_wave + f43 + ('conv1b', 'feat5', 'feat3', 'conv2a', 'conv3a', 'conv4a', 'feat6')
+    four_wave = ()
+    f43 = ('conv1b', 'conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6', 'feat5')   # Cin, Cout >= 64: F(4x4,3x3), csrc/kfn_wino4.hip (round 4)
+    asked = four_wave + f43 + ('feat3', 'conv2a', 'conv3a', 'conv4a', 'feat6')
     names = {}
     for op in g.ops:       # (first op of a name: SCoordNet / the feature tower come before OFlowNet's same-named layers)
         if op.name in asked and op.name not in names:
@@ -99,16 +99,20 @@ def test_default_routes_of_the_3x3_layers():
         assert names[n] == 'wino3_kernel', (n, names[n])
     for n in f43:
         assert names[n] == 'wino4_kernel', (n, names[n])
-    assert names['conv1b'] == 'wino3_pair_kernel'            # 64 -> 64: two waves share one transform
-    assert names['feat5'] == 'wino3_pair_kernel'
     assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
     for n in ('conv2a', 'conv3a', 'conv4a', 'feat6'):
         assert names[n] == 'wino_s2_kernel', (n, names[n])
     by_name = {}
     for op in g.ops:
         by_name.setdefault(op.name, op)
-    assert isinstance(by_name['conv1b'], WinogradFusedConvOp) and by_name['conv1b'].two_wave()
-    assert not by_name['conv2b'].two_wave() and by_name['conv2b'].four_wave()
+    g2, net2 = _build(2, winograd_f43_min_channels=0)      # without F(4x4,3x3): the four-wave F(2x2,3x3) kernel
+    by2 = {}
+    for op in g2.ops:
+        by2.setdefault(op.name, op)
+    c2b = by2['conv2b']
+    assert not c2b.two_wave() and c2b.four_wave() and c2b.kernel_name(lib) == 'wino3_kernel'
+    assert isinstance(by2['conv1b'], WinogradFusedConvOp) and by2['conv1b'].two_wave()      # 64 -> 64: two waves share one transform
+    assert by2['conv1b'].kernel_name(lib) == 'wino3_pair_kernel' and by2['feat5'].kernel_name(lib) == 'wino3_pair_kernel'
     assert isinstance(by_name['conv2a'], WinogradS2ConvOp)
     from kfnet_amd.graph import WinogradF43ConvOp
     op4 = by_name['conv4b']
@@ -119,7 +123,7 @@ def test_default_routes_of_the_3x3_layers():
     g0, net0 = _build(2, winograd_f43_min_channels=0)
     assert all(type(op).__name__ != 'WinogradF43ConvOp' for op in g0.ops)
     # executed MFMA FLOPs of the two-wave form: all 64 channels in one column block (no padding to 128)
-    op = by_name['conv1b']
+    op = by2['conv1b']
     n, ho, wo, co = op.y.shape
     assert op.mfma_flops() == 2.0 * 16 * (-(-((wo + 1) // 2) // 8) * 8) * (-(-(n * ((ho + 1) // 2)) // 4) * 4) * 64 * 64
 

@@ -144,13 +144,14 @@ def main():
     f23 = (2, toom_cook(2, 3, [0, 1, -1]))
     pts = {'0,+-1,+-2': [0, 1, -1, 2, -2], '0,+-1,+-1/2': [0, 1, -1, Fraction(1, 2), Fraction(-1, 2)]}
     f43 = {k: (4, toom_cook(4, 3, v)) for k, v in pts.items()}
-    wide23 = ['conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6']
-    routes = {'direct32': {}, 'f23 (shipped)': {n: f23 for n in wide23}}
+    wide23 = ['conv1b', 'conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6']
+    routes = {'direct32': {}, 'f23 on conv1b..conv6 (round 3)': {n: f23 for n in wide23}}
     for k, v in f43.items():
         r = {n: f23 for n in ('conv2b', 'conv6')}
         r.update({n: v for n in ('conv3b', 'conv4b', 'conv5')})
         routes['f43 on conv3b/4b/5 [%s]' % k] = r
         routes['f43 on conv4b/5 only [%s]' % k] = dict(r, conv3b=f23)
+        routes['f43 on conv1b/2b/3b/4b/5/6 (shipped in round 4) [%s]' % k] = {n: v for n in ('conv1b', 'conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6')}
     out = {'frames': args.frames, 'bar_coord_max_abs': 2e-5, 'variants': {}}
     for t in range(args.frames):
         gold = scoordnet(imgs[t], Wt, torch.float64, {})
