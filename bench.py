@@ -879,8 +879,10 @@ def config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_
     return {'value': round(K * world / med, 3), 'unit': 'frames/s', 'frames_total': K * world, 'frames_per_rank': K,
             'tower_batch': batch, 'ms_per_step': round(med * 1e3 / K, 4), 'repetitions': len(times),
             'timed_seconds': round(float(np.sum(times)), 3), 'handoff': chain,
-            'note': 'the literal BASELINE configs[3]: one %d-frame sequence over %d ranks, median repetition, '
-                    'MAX over ranks' % (K * world, world)}
+            'image': '%dx%d' % (args.height, args.width),
+            'is_literal_config4': bool((args.height, args.width) == (480, 640) and world == 8 and K == 256),
+            'note': 'BASELINE configs[3]: one %d-frame sequence over %d ranks (resets at 500 / 1000 / ... fall inside '
+                    'chunks), median repetition, MAX over ranks' % (K * world, world)}
 
 
 def main():
@@ -1002,8 +1004,7 @@ def main():
     if dist is not None:
         out['handoff'] = chain_timing(lambda timer: run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev, timer=timer),
                                       dist, device, world)
-        if world == 8 and K < 256 and not args.no_config3 and (args.height, args.width) == (480, 640) \
-                and args.conv_operands == 'f32':
+        if world == 8 and K < 256 and not args.no_config3 and args.conv_operands == 'f32':
             out['config4_2048_frames'] = config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index)
     if rank == 0:
         rows = per_kernel_profile(eng, dev_frames)

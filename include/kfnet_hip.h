@@ -411,6 +411,8 @@ int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int 
  * SetVariableByName) from the rank that finished chunk r to the rank that owns chunk r+1.
  * ncclSend / ncclRecv on `stream`, i.e. ordered behind/before the kfn_kalman_scan launches
  * on that stream; no host synchronisation.  librccl is bound at run time (dlopen).
+ *   kfn_comm_available  local probe: run it on every rank BEFORE the collective kfn_comm_init, so that a rank
+ *                       without RCCL is found while the others can still be told;
  *   kfn_comm_unique_id  rank 0 creates the 128-byte id and distributes it out of band
  *                       (torch.distributed / MPI / a file);
  *   kfn_comm_init       collective over all ranks; binds `device` to the calling thread;
@@ -419,6 +421,7 @@ int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int 
  *                       chunk that starts on a reset frame receives nothing). */
 #define KFN_COMM_ID_BYTES 128
 typedef struct kfn_comm kfn_comm;
+int kfn_comm_available(void);   /* KFN_OK if librccl can be bound in this process (no communicator, no socket, no device) */
 int kfn_comm_unique_id(void* id, size_t bytes /* == KFN_COMM_ID_BYTES */);
 int kfn_comm_init(kfn_comm** comm, int rank, int nranks, const void* unique_id, int device);
 int kfn_comm_destroy(kfn_comm* comm);

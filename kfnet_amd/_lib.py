@@ -96,6 +96,7 @@ SYMBOLS = {
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
     'kfn_kalman_fuse2': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    'kfn_comm_available': (_i, []),
     'kfn_comm_unique_id': (_i, [_vp, _sz]),
     'kfn_comm_init': (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),
     'kfn_comm_destroy': (_i, [_vp]),

@@ -87,6 +87,10 @@ int check_state_args(const kfn_comm* c, int peer, const void* state, int H, int 
 
 }  // namespace
 
+// Can this process bind librccl (dlopen + every symbol)?  No communicator, no bootstrap socket, no device access: the
+// probe every rank runs before the collective part of a link set-up (kfnet_amd/dist.py::make_link).
+extern "C" int kfn_comm_available(void) { return need_rccl("kfn_comm_available"); }
+
 extern "C" int kfn_comm_unique_id(void* id, size_t bytes) {
   KFN_REQUIRE(id != nullptr && bytes == KFN_COMM_ID_BYTES, "kfn_comm_unique_id: id must be a %d-byte buffer",
               KFN_COMM_ID_BYTES);

@@ -152,11 +152,13 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
     fails where, so the ranks can never end up on different transports (a rank that cannot bind
     librccl must not leave the others blocked in the id broadcast, and a group that mixes
     ncclSend with torch.distributed.recv hangs at the first hand-off).
-      1. every rank probes the C-ABI side (dlopen + symbols: kfn_comm_unique_id into a scratch
-         buffer) -> all_reduce(MIN);
+      1. every rank checks its LOCAL preconditions (library loads, device index valid; rank 0 obtains the unique id
+         -- the only call that starts RCCL's bootstrap listener) -> all_reduce(MIN);
       2. rank 0 broadcasts its unique id, every rank runs kfn_comm_init -> all_reduce(MIN);
       3. only if every rank succeeded is RcclLink used; otherwise every rank closes what it
-         opened and takes TorchLink -- or, with prefer='cabi', every rank raises."""
+         opened and takes TorchLink -- or, with prefer='cabi', every rank raises.
+    Remaining window: ncclCommInitRank is a collective inside RCCL; a rank that dies INSIDE it (not before: step 1
+    covers everything local) leaves the others to RCCL's own timeout."""
     if dist is None or world <= 1:
         return None
     if prefer == 'torch' or dist.get_backend() != 'nccl':
@@ -168,10 +170,19 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
     lib = None
     uid = None
     try:
+        # every LOCAL precondition is checked here, before the first group operation, so that step 2
+        # (ncclCommInitRank, itself collective) can only fail collectively: the library loads with the entry points
+        # bound, the device index is valid, and -- on rank 0 only: every call opens a bootstrap listener -- RCCL
+        # hands out a unique id (the other ranks only bind librccl: kfn_comm_available)
+        import torch
         lib = _lib.load()
-        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-        _lib.check(lib.kfn_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'kfn_comm_unique_id')
-        uid = bytes(buf.raw)
+        if not (0 <= int(device_index) < torch.cuda.device_count()):
+            raise _lib.KfnError('device index %r out of range' % (device_index,))
+        _lib.check(lib.kfn_comm_available(), 'kfn_comm_available')      # dlopen(librccl) + every symbol; no socket, no device
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(lib.kfn_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'kfn_comm_unique_id')
+            uid = bytes(buf.raw)
     except (_lib.KfnError, OSError) as e:
         why = e
     link = None
@@ -179,6 +190,8 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
         ids = [uid if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         try:
+            if not isinstance(ids[0], (bytes, bytearray)) or len(ids[0]) != _lib.COMM_ID_BYTES:
+                raise ValueError('rank 0 sent no usable RCCL id')     # the same on every rank: fails collectively
             link = RcclLink(rank, world, device_index, unique_id=ids[0])
         except (_lib.KfnError, OSError, ValueError) as e:
             why = e

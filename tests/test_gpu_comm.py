@@ -91,6 +91,24 @@ def test_two_rank_state_transfer_over_rccl(tmp_path):
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+    # ... and the benchmark's own two-rank form on the same two GPUs: the plain command the driver would run, which
+    # must end on the production transport and report RCCL's OWN view of the communicator (Next #4d)
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    b = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '2',
+                        '--min-seconds', '0.5', '--no-kalman-roofline'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert b.returncode == 0, b.stderr[-3000:]
+    line = json.loads([l for l in b.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['dist_backend'] == 'nccl'
+    assert line['rccl_ranks'] == [[0, 2], [1, 2]]                      # ncclCommUserRank / ncclCommCount of every rank
+    assert line['state_link'].startswith('C-ABI kfn_send_state')
+    assert line['rank_devices'] == [0, 1]
+    h = line['handoff']
+    assert h['scan_chain_ms'] > 0 and len(h['handoff_us']) == 2
+    assert h['handoff_us'][1]['recv_wait_us'] is not None and h['handoff_us'][0]['send_us'] is not None
 
 
 def test_eval_gpu_flag_selects_device(tmp_path):

@@ -177,6 +177,11 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     assert out['n_gpus'] == 2 and out['self_launched'] is True
     assert out['config']['frames_total'] == 12 and out['value'] > 0
     assert len(out['rccl_ranks']) == 2 and len(out['rank_devices']) == 2
+    # the serial chain of the sharded configuration, measured: two scans and one hand-off (Next #4c)
+    h = out['handoff']
+    assert len(h['scan_ms_per_rank']) == 2 and h['scan_chain_ms'] >= max(h['scan_ms_per_rank'])
+    assert h['handoff_us'][0]['send_us'] is not None and h['handoff_us'][1]['recv_wait_us'] is not None
+    assert h['handoff_us'][0]['recv_wait_us'] is None and h['handoff_us'][1]['send_us'] is None
     if torch.cuda.device_count() >= 2:
         assert out['dist_backend'] == 'nccl' and out['rank_devices'] == [0, 1]
         assert out['rccl_ranks'] == [[0, 2], [1, 2]], out['rccl_ranks']   # kfn_comm_rank on every rank
@@ -184,6 +189,33 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     else:
         assert out['dist_backend'] == 'gloo' and out['rccl_ranks'] == [None, None]
         assert 'FUNCTIONAL FALLBACK' in out['config']['parallelism']
+
+
+def test_bench_gpus_8_carries_the_config4_block():
+    """The driver's 8-rank command with fewer than 256 steps also runs BASELINE configs[3] -- 8 x 256 = 2048 frames, state
+    handed rank -> rank -- and reports it with the measured chain (Next #4b).  Here the 8 ranks share the
+    box's GPU(s) (gloo fallback when there are fewer than 8) on small frames; the arithmetic path is the driver's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'KFN_DIST_BACKEND')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2',
+           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 8 and out['config']['frames_total'] == 32
+    c4 = out['config4_2048_frames']
+    assert c4['frames_total'] == 2048 and c4['frames_per_rank'] == 256 and c4['value'] > 0
+    assert c4['is_literal_config4'] is False and c4['image'] == '64x96'      # (480x640 on the driver's node)
+    h = c4['handoff']
+    assert len(h['scan_ms_per_rank']) == 8 and h['scan_chain_ms'] >= sum(h['scan_ms_per_rank']) * 0.5
+    # chunks [256 r, 256 r + 256): frames 500, 1000, 1500, 2000 are inside chunks 1, 3, 5, 7 -- every boundary hands over
+    assert all(x['recv_wait_us'] is not None for x in h['handoff_us'][1:]) and h['handoff_us'][0]['recv_wait_us'] is None
+    assert out['summary']['config4_2048_frames']['value'] == c4['value']
 
 
 def test_config5_shape_batch_of_sequences():
