@@ -128,6 +128,7 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_ORDER_AUTO 0
 #define KFN_WINO_ORDER_M_FAST 1
 #define KFN_WINO_ORDER_N_FAST 2
+#define KFN_WINO_ORDER_GROUPS(n) (16 + (n)) /* kfn_conv2d_winograd_f43 only: n channel groups (of 64) of a tile block adjacent */
 #define KFN_WINO_FORM_AUTO 0
 #define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel / wino3_pair_kernel would run */
 
@@ -159,6 +160,7 @@ typedef struct kfn_conv_desc {
 #define KFN_CFG_256x256 13    /* fp16 activations only: 4 waves, wave tile 128x128 (16 accumulators = 256 registers, one wave
                                * per SIMD): half the LDS fragment reads and half the operand staging per MFMA of 128x256 */
 #define KFN_CFG_256x256_W8 14 /* fp16 activations only: 8 waves (2 x 4), wave tile 128x64, two waves per SIMD */
+#define KFN_CFG_512x64 15     /* fp16 activations only: 4 waves side by side in M, wave tile 128x64 (64-channel layers) */
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);

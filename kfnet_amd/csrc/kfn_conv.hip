@@ -970,7 +970,7 @@ const TileCfg kCfgs[] = {{KFN_CFG_160x128, 160, 128, 0.87, 0.70}, {KFN_CFG_128x1
                          {KFN_CFG_128x256, 128, 256, 0.0, 0.82},
                          {KFN_CFG_256x16, 256, 16, 0.50, 0.0},    {KFN_CFG_128x16, 128, 16, 0.45, 0.0},
                          {KFN_CFG_256x64, 256, 64, 0.0, 0.0},     {KFN_CFG_256x256, 256, 256, 0.0, 0.0},
-                         {KFN_CFG_256x256_W8, 256, 256, 0.0, 0.0}};
+                         {KFN_CFG_256x256_W8, 256, 256, 0.0, 0.0}, {KFN_CFG_512x64, 512, 64, 0.0, 0.0}};
 
 const TileCfg* find_cfg(int cfg) {
   for (const TileCfg& c : kCfgs)
@@ -1038,6 +1038,7 @@ int dispatch_f16io(int cfg, const ConvArgs& a, hipStream_t s) {
     case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, BK, MODE_CONV, PREC>(a, s);
     case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, BK, MODE_CONV, PREC>(a, s);
+    case KFN_CFG_512x64: return launch_cfg<4, 2, 4, 1, BK, MODE_CONV, PREC>(a, s);
     default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no fp16-activation instantiation", cfg);
   }
 }
@@ -1272,6 +1273,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
           case KFN_CFG_256x64: return launch_cfg<2, 2, 4, 1, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
+          case KFN_CFG_512x64: return launch_cfg<4, 2, 4, 1, 16, MODE_CONV, PREC_F16_XY_DMA>(a, s);
           default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
         }
       }
@@ -1281,6 +1283,7 @@ extern "C" int kfn_conv2d_nhwc(const kfn_conv_desc* d, const float* x, const flo
           case KFN_CFG_128x128: return launch_cfg<2, 2, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
           case KFN_CFG_256x256: return launch_cfg<4, 4, 2, 2, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
           case KFN_CFG_256x256_W8: return launch_cfg<4, 2, 2, 4, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
+          case KFN_CFG_512x64: return launch_cfg<4, 2, 4, 1, 16, MODE_CONV, PREC_F16_XY_BDMA>(a, s);
           default: return kfn::fail(KFN_ERR_ARG, "kfn_conv2d_nhwc: config %d has no LDS-DMA instantiation", c16);
         }
       }

@@ -71,6 +71,11 @@ constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions
 #define KFN_W4_XSLOT 100    // the transform burst
 #define KFN_W4_SSLOT 106    // first V store, then one per slot
 #endif
+// Line touches (see `touch` below): slot of the first of the three touch loads of a super-step; < 0 = none.  OFF: they move
+// the stall, they do not remove it (measured: conv4b 6.78 ms with, 6.38 without -- profiles/r04_wino4_microbench.log).
+#ifndef KFN_W4_TSLOT
+#define KFN_W4_TSLOT (-1)
+#endif
 // timing experiments only (wrong results on purpose; tools/mb/build_w4.sh): bit 0 no transform, 1 no patch loads,
 // 2 no V stores, 3 no B loads in the main loop, 4 every patch load of the main loop re-reads super-step 0 (L1/L2-hot
 // activations), 5 every B load re-reads chunk 0 (L2-hot weights)
@@ -92,11 +97,25 @@ struct Wino4Args {
   int bw;             // ceil(Tw / 4) column blocks
   int tiles_m, tiles_n;
   int relu;
-  int n_fast;
+  int n_group;        // workgroup order: n_group channel groups (of 64) of one tile block are neighbours, blocks next, group sets slowest
   unsigned long long x_bytes;
   unsigned long long y_bytes;
   unsigned u_bytes;
+#ifdef KFN_WINO4_PROF
+  unsigned long long* prof;   // tools/mb/wino4_prof.hip: [block][wave][8] phase stamps, then [block][wave][11] timeline of one super-step
+#endif
 };
+
+#ifdef KFN_WINO4_PROF
+// (every lane stores the same value to the same address: a lane-0 branch would be divergent control flow, after which
+//  hipcc wraps the gathers' uniform descriptors in waterfall loops -- DESIGN 3.1d's measurement trap)
+#define KFN_STAMP4(i) (p.prof[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter())
+#ifndef KFN_W4_TL_KS
+#define KFN_W4_TL_KS 1      // the super-step whose 16-slot timeline is kept
+#endif
+#else
+#define KFN_STAMP4(i) do { } while (0)
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor4_impl(F& f) {
@@ -172,10 +191,16 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wx = wave & 1, wc = wave >> 1;      // xi half, 32-channel column block
+  KFN_STAMP4(0);
   const int nwg = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap4(blockIdx.x, nwg);
-  const int tm = p.n_fast ? tile / p.tiles_n : tile % p.tiles_m;
-  const int tn = p.n_fast ? tile % p.tiles_n : tile / p.tiles_m;
+  // Workgroups that run side by side on an XCD share its L2: with n_group channel groups of a tile block adjacent the
+  // input block crosses the fabric tiles_n / n_group times (instead of tiles_n) and a weight slice is shared by
+  // 32 / n_group CUs (instead of 32).  n_group divides tiles_n (the launcher sees to it).
+  const int per = p.tiles_m * p.n_group;
+  const int gset = tile / per, rem = tile - gset * per;
+  const int tm = rem / p.n_group;
+  const int tn = gset * p.n_group + (rem - tm * p.n_group);
   const int cb = tm % p.bw, rb = tm / p.bw;
   const int nbase = tn * 64;                    // the workgroup's 64 output channels
   const int n0 = nbase + wc * 32;               // this wave's 32
@@ -219,6 +244,31 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
     }
   }
   const int x_records = (int)(a_rest < two_img ? a_rest : two_img);
+  // ---- line touches -------------------------------------------------------------------------------------
+  // A super-step reads 64 bytes (16 channels) of every patch pixel: every OTHER super-step opens a new 128-byte line of
+  // every pixel, and with 288 line misses per wave in flight the patch loads back up the vector-memory path -- the odd
+  // super-steps ran 13.2 K cycles against 10.3 K for the even ones (tools/mb/wino4_prof.hip).  So the line is opened one
+  // super-step EARLY by three loads per wave in which every lane touches a different pixel of the wave's footprint
+  // (its tile column: 6 patch columns x the 32 core rows of the block = 192 pixels; the two halo rows are left to the
+  // patch loads): 3 instructions instead of 36 raise the same misses, and when the patch loads come they hit the L2.
+  // RESULT (cycle stamps, conv4b): the odd super-steps do drop to 10.6 K -- and the even ones, which now carry the 768
+  // misses of the four waves in three instructions each, rise to 13.5 K: the stall sits in the CU's miss handling
+  // (~140 lines must be in flight per CU at HBM latency to feed this loop), not in who raises the misses.  Kept as an
+  // experiment switch (KFN_W4_TSLOT >= 0), off by default.
+  unsigned tq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int q = lane + 64 * k;              // pixel q of the footprint: row q / 6 of the 32 core rows, patch column q % 6
+    const int rr = q / 6, fc = q - 6 * rr;
+    const int tr = rr >> 2;
+    const int img_rel = tr < brk ? 0 : 1;
+    const int ty = tr < brk ? ty0 + tr : tr - brk;
+    const int yy = 4 * ty + (rr & 3);
+    const int xx = 4 * (cb * BW4 + wave) - 1 + fc;
+    const bool ok = (vr0 + tr < p.vrows) && (yy < p.H) && ((unsigned)xx < (unsigned)p.W);
+    tq[k] = ok ? (unsigned)((img_rel * p.H + yy) * p.W + xx) * (unsigned)(p.ldx * 4) : ROW_POISON;
+  }
+  unsigned touched = 0, tv[3] = {0u, 0u, 0u};   // tv: the touch loads in flight (consumed one super-step later: no wait)
   // V store address of this lane inside a chunk buffer: chunk cp >> 2, k-half (cp >> 1) & 1, pair cp & 1, tile 4 ptr + wave
   // (a ds_write_b64 group of 16 lanes = 8 channel pairs x 2 tile rows: dwords {0,2} + {0,8} + {0,4} + {0,16}: 32 banks once)
   const int v_st = (cp >> 2) * VBUF + ((cp >> 1) & 1) * VHALF + (ptr * 4 + wave) * 16 + (cp & 1) * 8;
@@ -257,6 +307,16 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
     constexpr int g = decltype(gc)::value;
     *reinterpret_cast<f32x2*>(smem4 + (ss & 1) * (CPS * VBUF) + v_st + g * VPOS) = pv[g];
   };
+  // touch the line that super-step `ss` will read (only when it opens a new one: ss even; else a zero-length descriptor
+  // makes the load a no-op -- no control flow in the MFMA stream).  The value is kept alive, never used.
+  auto touch = [&](auto kc_, int ss) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc_)::value;
+    const bool live = ((ss & 1) == 0) && ss <= s_last;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, live ? x_records : 0, 0x00020000);
+    touched |= tv[k];      // the previous super-step's touch: arrived long ago
+    tv[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, tq[k], (unsigned)(ss * 64), 0);
+  };
   // this wave's fragment (chunk ch, local position l) = global fragment ch * 36 + 18 wx + l, into ring slot `sl`
   auto b_load = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_)::value;
@@ -269,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
     vq[sl] = *reinterpret_cast<const f32x4*>(smem4 + (ch & (2 * CPS - 1)) * VBUF + l * VPOS + v_lane);
   };
 
+  KFN_STAMP4(1);
   // ---- prologue: the workgroup produces super-step 0; every wave fills its B ring --------------------------
   sfor4<36>([&](auto ic) { p_gather(ic, 0); });
   sfor4<NB>([&](auto sc) { b_load(sc, 0, decltype(sc)::value); });
@@ -278,6 +339,10 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+  KFN_STAMP4(2);
+#ifdef KFN_WINO4_PROF
+  unsigned long long tl[11];
+#endif
   // ---- main loop: one super-step = 2 chunks x 72 MFMA slots ------------------------------------------------
   // slot j of a chunk -> (position l, k-step t): four positions interleaved (groups 0..3), then the last two
   for (int ks = 0; ks < n_super; ++ks) {
@@ -314,18 +379,36 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
           else if constexpr (cc < CPS - 1) v_read(std::integral_constant<int, sv>{}, ch + 1, l + NVR - WPOS);
         }
         constexpr int sj = cc * SPC + j;
+#ifdef KFN_WINO4_PROF
+        if constexpr (sj % 16 == 0)
+          if (ks == KFN_W4_TL_KS) tl[sj / 16] = __builtin_readcyclecounter();
+#endif
         if constexpr (!(KFN_W4_DBG & 2) && sj < 36 * KFN_W4_GSTEP && sj % KFN_W4_GSTEP == 0)
           p_gather(std::integral_constant<int, sj / KFN_W4_GSTEP>{}, ks + 1);
+        if constexpr (KFN_W4_TSLOT >= 0 && sj >= KFN_W4_TSLOT && sj < KFN_W4_TSLOT + 3)
+          touch(std::integral_constant<int, (sj - KFN_W4_TSLOT >= 0 && sj - KFN_W4_TSLOT < 3) ? sj - KFN_W4_TSLOT : 0>{}, ks + 2);
         if constexpr (!(KFN_W4_DBG & 1) && sj == KFN_W4_XSLOT) bt_d_b6(pv, kc);
         if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_SSLOT && sj < KFN_W4_SSLOT + 36)
           p_store(std::integral_constant<int, sj - KFN_W4_SSLOT>{}, ks + 1);
         __builtin_amdgcn_sched_barrier(0);
       });
     });
+#ifdef KFN_WINO4_PROF
+    if (ks == KFN_W4_TL_KS) tl[9] = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef KFN_WINO4_PROF
+    if (ks == KFN_W4_TL_KS) tl[10] = __builtin_readcyclecounter();
+#endif
   }
+#ifdef KFN_WINO4_PROF
+#pragma unroll
+  for (int i = 0; i < 11; ++i) p.prof[((size_t)gridDim.x * 4) * 8 + ((size_t)blockIdx.x * 4 + wave) * 11 + i] = tl[i];
+#endif
+  KFN_STAMP4(3);
+  asm volatile("" ::"v"(touched), "v"(tv[0]), "v"(tv[1]), "v"(tv[2]));   // (the touch loads must not be optimised away)
 
   // ---- epilogue -------------------------------------------------------------------------------------------
   // Partial output transform of this wave's 18 positions, reduced with the partner wave (same column block, other xi half)
@@ -397,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      KFN_STAMP4(4);
       sfor4<8>([&](auto epc) {
         constexpr int e0 = 2 * decltype(epc)::value;
         f32x2 P[2][4];
@@ -420,6 +504,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  KFN_STAMP4(5);
   // (3) the image leaves: iteration `it` = tile it, pixel row i = wave, column j = lane >> 4, channel quad lane & 15
   {
     const bool relu = p.relu != 0;
@@ -450,9 +535,18 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
                                              rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
     }
   }
+  KFN_STAMP4(6);
+#ifdef KFN_WINO4_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  KFN_STAMP4(7);
+#endif
 }
 
 }  // namespace
+
+#ifdef KFN_WINO4_PROF
+unsigned long long* g_wino4_prof = nullptr;
+#endif
 
 // Can the F(4x4,3x3) kernel take this layer?  (host-side routing; no device access)
 extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
@@ -509,13 +603,25 @@ extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, c
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_f43: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
-  a.n_fast = d->wino_order == KFN_WINO_ORDER_N_FAST ? 1 : 0;
+  // workgroup order: M fastest (1 group), all channel groups of a block adjacent (N fastest), or KFN_WINO_ORDER_GROUPS(n).
+  // AUTO: four groups (two when the layer has fewer) -- the input block then crosses the fabric a quarter as often and a
+  // weight slice is still shared by 8 CUs of the XCD: conv4b 6.28 -> 6.07 ms, conv5 3.26 -> 3.19, conv3b 6.46 -> 6.36,
+  // conv2b equal (same log); 8 groups and N fastest lose again (the weight slices no longer share an L2).
+  int ng = 1;
+  if (d->wino_order == KFN_WINO_ORDER_AUTO) ng = a.tiles_n % 4 == 0 ? 4 : (a.tiles_n % 2 == 0 ? 2 : 1);
+  else if (d->wino_order == KFN_WINO_ORDER_N_FAST) ng = a.tiles_n;
+  else if (d->wino_order >= KFN_WINO_ORDER_GROUPS(1)) ng = d->wino_order - KFN_WINO_ORDER_GROUPS(0);
+  if (ng < 1 || ng > a.tiles_n || a.tiles_n % ng != 0) ng = 1;
+  a.n_group = ng;
   const long in_pix = (long)d->N * d->H * d->W;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
   // the B ring prefetches whole 1 KiB fragments of 32 output channels: the last column block of a 32-but-not-64-multiple
   // cout_pad reads 32 channels past the matrix -- the range check returns zeros for them (their accumulators are never stored)
   a.u_bytes = (unsigned)(36L * d->cout_pad * d->Cin * 4L);
+#ifdef KFN_WINO4_PROF
+  a.prof = g_wino4_prof;
+#endif
   static std::atomic<uint64_t> attr_done{0};
   int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);
   if (rc != KFN_OK) return rc;

@@ -397,7 +397,7 @@ class ConvOp(Op):
     CFG_TILE = {1: (5, 1, 1, 4), 2: (2, 2, 2, 2), 3: (2, 1, 2, 2), 4: (1, 1, 4, 1), 5: (1, 1, 2, 2),
                 6: (2, 1, 4, 1), 7: (3, 1, 2, 2), 8: (5, 1, 1, 8), 9: (2, 4, 2, 2),
                 10: (2, 1, 4, 1), 11: (1, 1, 4, 1), 12: (2, 2, 4, 1),   # 10/11: 16-column variants (PREC tag 3)
-                13: (4, 4, 2, 2), 14: (4, 2, 2, 4)}                     # 256x256: four / eight waves (fp16 activations)
+                13: (4, 4, 2, 2), 14: (4, 2, 2, 4), 15: (4, 2, 4, 1)}   # 256x256: four / eight waves, 512x64 (fp16 activations)
     # template tag PREC of conv_mfma_kernel for fp16 activations: (x is f16, y is f16) -> 4 / 5 / 6
     PREC_F16_IO = {(True, False): 4, (False, True): 5, (True, True): 6}
 

@@ -54,14 +54,14 @@ for (name, lv, ci, co, k, s) in LAYERS:
         t = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), x32.data_ptr(), u.data_ptr(), None, y32.data_ptr(), st), 'w'))
         res.append('f32act wino3 %.3f ms %4.0f TF' % (t, fl / t / 1e9))
         del u
-    cfgs = [(2, '128x128'), (9, '128x256'), (13, '256x256'), (14, '256x256w8')] if co >= 128 else [(7, '192x64'), (3, '128x64'), (12, '256x64')]
+    cfgs = [(2, '128x128'), (9, '128x256'), (13, '256x256'), (14, '256x256w8')] if co >= 128 else [(7, '192x64'), (3, '128x64'), (12, '256x64'), (15, '512x64')]
     if os.environ.get('MB_CFGS'):
         cfgs = [c for c in cfgs if str(c[0]) in os.environ['MB_CFGS'].split(',')]
     for cfg, cn in cfgs:
         for ks in ((16, 32) if (ci % 64 == 0 and not os.environ.get('MB_K16_ONLY')) else (16,)):
             t = conv(x16, y16, cfg, ks, 1, 1, 1)
             res.append('f16act %s k%d %.3f ms %4.0f TF' % (cn, ks, t, fl / t / 1e9))
-            if ks == 16 and cfg in (2, 9, 12, 13, 14):
+            if ks == 16 and cfg in (2, 9, 12, 13, 14, 15):
                 if cfg != 12:
                     t = conv(x16, y16, cfg, ks, 1, 1, 2)
                     res.append('  +B via LDS-DMA %.3f ms %4.0f TF' % (t, fl / t / 1e9))

@@ -2,18 +2,19 @@
 # Regenerates the judged profile summaries of a round on the GPU box:
 #   bash tools/profile_round.sh r01        (writes gpurun_out/prof/<tag>_*; copy into profiles/)
 # Kernel trace and every PMC group are separate rocprofv3 runs (never combined with sys traces).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 finddb() { find "$1" -name '*.db' | head -1; }
-SHORT="--steps 64 --batch 32 --min-seconds 0 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline --no-config3"
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err )
+SHORT="--steps 64 --batch 32 --min-seconds 0 --no-cpu-baseline --no-host-streamed --no-alt-modes --no-kalman-roofline --no-config3 --no-extra-configs --no-eval-png"
+LIGHT="--no-cpu-baseline --no-host-streamed --no-alt-modes --no-extra-configs --no-eval-png"   # the c3 line without the blocks that run other configs
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py $LIGHT > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err )
 python tools/rocpd_stats.py "$(finddb $OUT/kt)" $OUT/${TAG}_kernel_stats.csv > /dev/null
 # same trace with the two towers serialised on one stream: kernel durations without the
 # overlap of the two-stream schedule, directly comparable with bench.py's isolated launches
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt1 -- python $R/bench.py --one-stream --no-cpu-baseline --no-host-streamed --no-alt-modes > $OUT/${TAG}_bench_under_rocprof_one_stream.json 2> $OUT/kt1.err )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt1 -- python $R/bench.py --one-stream $LIGHT > $OUT/${TAG}_bench_under_rocprof_one_stream.json 2> $OUT/kt1.err )
 python tools/rocpd_stats.py "$(finddb $OUT/kt1)" $OUT/${TAG}_kernel_stats_one_stream.csv > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -- python $R/bench.py $SHORT > /dev/null 2> $OUT/$C.err )
@@ -34,8 +35,9 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/sq$i -- python $R/bench.py $SHORT > /dev/null 2> $OUT/sq$i.err )
 done
 python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)"
-# the un-profiled bench line (quotes the fresh PMC traffic copied to profiles/ above)
-python bench.py > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
+# the un-profiled bench lines (they quote the fresh PMC traffic copied to profiles/ above): the 256-frame default and,
+# after the config-5 passes below, the driver's own command
+python bench.py --no-extra-configs > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
 rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
 # ---- BASELINE config 5 (960x540, fp16 convs + fp16 activations, fp32 Kalman): kernel trace + the same PMC passes ----
 C5="--config c5 --no-cpu-baseline --min-seconds 0"
@@ -54,5 +56,6 @@ python tools/pmc_sq.py $OUT/${TAG}_c5_pmc_sq_counters.json "$(finddb $OUT/c5sq1)
 cp $OUT/${TAG}_c5_pmc_traffic.json $R/profiles/${TAG}_c5_pmc_traffic.json    # quoted by the c5 bench line below
 python bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
 python bench.py --config c2 > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_command.json 2> $OUT/bench_driver.err
 rm -rf $OUT/c5kt $OUT/c5FETCH_SIZE $OUT/c5WRITE_SIZE $OUT/c5sq1 $OUT/c5sq2 $OUT/c5sq3
 ls -la $OUT
