@@ -173,9 +173,9 @@ class KFNet():
         net_ops = self.oflownet.ops
         if not g.fuse_oflow_window:
             return
-        # kfn_oflow_tail2 needs 4 x 34 000 B of dynamic LDS per workgroup: gfx950's 160 KiB.  On a part with less the
+        # kfn_oflow_tail2 needs 4 x 32 560 B of dynamic LDS per workgroup: gfx950's 160 KiB.  On a part with less the
         # round-2 launches (gather + conv1a, upconv0 + kfn_oflow_tail) stay in place.
-        if getattr(g, 'lds_bytes_per_cu', 160 * 1024) < 136000:
+        if getattr(g, 'lds_bytes_per_cu', 160 * 1024) < 4 * 32560:
             return
         y0 = conv0.y
         tails = [op for op in net_ops if isinstance(op, OFlowTailOp)]

@@ -18,7 +18,7 @@
 //
 // LDS images (per wave; zero borders written once, interiors rewritten per window):
 //   tail2: concat0 10x10 cells x 56 floats (cell (cy+1, cx+1); channels [0,16) upconv0, [16,48) conv0),
-//          conv6 10x10 x 20, conv5 patch 5x5 x 36 (zero row 0 / column 0: the transposed conv's i-1, j-1 taps).
+//          conv6 10 rows x (10 cells x 16 + 4 pad), conv5 patch 5x5 x 36 (zero row 0 / column 0: the transposed conv's i-1, j-1 taps).
 //          An M-block of conv6 is 8 rows x 2 columns of the window: with 56 floats per cell the A-fragment
 //          ds_read_b128s are bank-conflict free (the 2x8 blocks of kfn_oflow_tail.hip cannot be).
 //   head:  conv0 9x9 cells x 36 floats (TF SAME for stride 2 on an even size pads bottom / right only).
@@ -35,11 +35,14 @@ constexpr int CU = 16;            // upconv0 channels
 constexpr int C2 = 16;            // conv6 channels
 constexpr int C9 = 9 * C0;        // channels of the T / G maps
 constexpr int LD1 = 56;           // floats per cell: concat0 image
-constexpr int LD2 = C2 + 4;       // conv6 image
+constexpr int LD2 = C2;           // conv6 image: 16 floats per cell, rows of 10 cells + 4 floats.  The prediction conv reads it
+constexpr int ROW2 = 10 * LD2 + 4; // with lane = window cell, a ds_read_b128 per (tap, channel quad): with this pitch the 16 lanes of
+                                   // every read group hit 16 different 16-byte slots (20-float cells in rows of 200: 24 double hits
+                                   // per read, 50 M conflict cycles per launch -- round 3's PMC)
 constexpr int LD3 = 36;           // conv5 patch image
 constexpr int LDA = 36;           // head: conv0 image
 constexpr int T1_BYTES = 100 * LD1 * 4;
-constexpr int T2_BYTES = 100 * LD2 * 4;
+constexpr int T2_BYTES = 10 * ROW2 * 4;
 constexpr int T3_BYTES = 25 * LD3 * 4;
 constexpr int TAIL_WAVE_BYTES = T1_BYTES + T2_BYTES + T3_BYTES;
 constexpr int HEAD_WAVE_BYTES = 81 * LDA * 4;
@@ -225,10 +228,10 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
   // conv6 A fragments: M-block mb = window columns 2mb, 2mb+1; row r = cell (r>>1, 2mb + (r&1))
   const int a_base = ((li >> 1) * 10 + (li & 1)) * (LD1 * 4) + kq * 48;
   // conv6 result: element e of block mb = cell (2 kq + (e>>1), 2 mb + (e&1)), channel n
-  const int o_base = ((2 * kq + 1) * 10 + 1) * (LD2 * 4) + li * 4;
+  const int o_base = ((2 * kq + 1) * ROW2 + LD2) * 4 + li * 4;
   // prediction: lane = window cell (ci, cj)
   const int ci = lane >> 3, cj = lane & 7;
-  const int p_base = (ci * 10 + cj) * (LD2 * 4);
+  const int p_base = (ci * ROW2 + cj * LD2) * 4;
 
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.T), 0, (int)a.t_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Gp), 0, (int)a.g_bytes, 0x00020000);
@@ -321,14 +324,14 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        *reinterpret_cast<float*>(t2 + o_base + ((e >> 1) * 10 + 2 * mb + (e & 1)) * (LD2 * 4)) = fmaxf(acc[mb][e], 0.f);
+        *reinterpret_cast<float*>(t2 + o_base + ((e >> 1) * ROW2 + (2 * mb + (e & 1)) * LD2) * 4) = fmaxf(acc[mb][e], 0.f);
     __builtin_amdgcn_wave_barrier();
 
     // ---- prediction conv: one window cell per lane, wave-uniform weights -------------------------
     float lg = bias_p;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const char* cellp = t2 + p_base + ((tap / 3) * 10 + (tap % 3)) * (LD2 * 4);
+      const char* cellp = t2 + p_base + ((tap / 3) * ROW2 + (tap % 3) * LD2) * 4;
       const float* wt = wp + tap * C2;
 #pragma unroll
       for (int q = 0; q < C2 / 4; ++q) {

@@ -76,6 +76,12 @@ constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions
 #ifndef KFN_W4_TSLOT
 #define KFN_W4_TSLOT (-1)
 #endif
+// ... and in how many pieces each of the three touch loads is issued (1, 2 or 4: 64 / 32 / 16 live lanes per piece), one
+// piece every KFN_W4_TSTEP slots: spreads the misses over the super-step
+#ifndef KFN_W4_TPIECES
+#define KFN_W4_TPIECES 1
+#define KFN_W4_TSTEP 1
+#endif
 // timing experiments only (wrong results on purpose; tools/mb/build_w4.sh): bit 0 no transform, 1 no patch loads,
 // 2 no V stores, 3 no B loads in the main loop, 4 every patch load of the main loop re-reads super-step 0 (L1/L2-hot
 // activations), 5 every B load re-reads chunk 0 (L2-hot weights)
@@ -310,12 +316,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   // touch the line that super-step `ss` will read (only when it opens a new one: ss even; else a zero-length descriptor
   // makes the load a no-op -- no control flow in the MFMA stream).  The value is kept alive, never used.
   auto touch = [&](auto kc_, int ss) __attribute__((always_inline)) {
-    constexpr int k = decltype(kc_)::value;
+    constexpr int piece = decltype(kc_)::value;           // piece = k * TPIECES + part
+    constexpr int k = piece / KFN_W4_TPIECES, part = piece % KFN_W4_TPIECES;
     const bool live = ((ss & 1) == 0) && ss <= s_last;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, live ? x_records : 0, 0x00020000);
-    touched |= tv[k];      // the previous super-step's touch: arrived long ago
-    tv[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, tq[k], (unsigned)(ss * 64), 0);
+    touched |= tv[k];      // the previous touch through this register: arrived long ago
+    const unsigned off = (KFN_W4_TPIECES == 1 || (lane * KFN_W4_TPIECES) / 64 == part) ? tq[k] : ROW_POISON;
+    tv[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, (unsigned)(ss * 64), 0);
   };
   // this wave's fragment (chunk ch, local position l) = global fragment ch * 36 + 18 wx + l, into ring slot `sl`
   auto b_load = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
@@ -385,8 +393,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
 #endif
         if constexpr (!(KFN_W4_DBG & 2) && sj < 36 * KFN_W4_GSTEP && sj % KFN_W4_GSTEP == 0)
           p_gather(std::integral_constant<int, sj / KFN_W4_GSTEP>{}, ks + 1);
-        if constexpr (KFN_W4_TSLOT >= 0 && sj >= KFN_W4_TSLOT && sj < KFN_W4_TSLOT + 3)
-          touch(std::integral_constant<int, (sj - KFN_W4_TSLOT >= 0 && sj - KFN_W4_TSLOT < 3) ? sj - KFN_W4_TSLOT : 0>{}, ks + 2);
+        if constexpr (KFN_W4_TSLOT >= 0 && sj >= KFN_W4_TSLOT && sj < KFN_W4_TSLOT + 3 * KFN_W4_TPIECES * KFN_W4_TSTEP &&
+                      (sj - KFN_W4_TSLOT) % KFN_W4_TSTEP == 0)
+          touch(std::integral_constant<int, (sj >= KFN_W4_TSLOT) ? (sj - KFN_W4_TSLOT) / KFN_W4_TSTEP : 0>{}, ks + 2);
         if constexpr (!(KFN_W4_DBG & 1) && sj == KFN_W4_XSLOT) bt_d_b6(pv, kc);
         if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_SSLOT && sj < KFN_W4_SSLOT + 36)
           p_store(std::integral_constant<int, sj - KFN_W4_SSLOT>{}, ks + 1);
