@@ -302,6 +302,9 @@ class Network(object):
             raise NotImplementedError("only stride-2 'SAME' transposed convs are used by the KFNet path")
         g = self.graph
         k = int(kernel_size)
+        if getattr(input, 'dtype', 'f32') != 'f32':
+            raise NotImplementedError('%s: transposed convolutions read fp32 activations only (an fp16 tensor can only feed '
+                                      'Network.conv in the fp16-operand mode)' % name)
         n, h, w, cin = input.shape
         y = g.tensor((n, h * strides, w * strides, filters), name=name)
         f16 = g.conv_operands == 'f16' and cin % 32 == 0
@@ -320,6 +323,8 @@ class Network(object):
         if axis not in (-1, 3):
             raise NotImplementedError('concat is only used on the channel axis')
         g = self.graph
+        if any(getattr(t, 'dtype', 'f32') != 'f32' for t in inputs):
+            raise NotImplementedError('%s: concat is implemented for fp32 activations only' % name)
         n, h, w, _ = inputs[0].shape
         ctot = sum(t.shape[3] for t in inputs)
         out = g.tensor((n, h, w, ctot), name=name)
