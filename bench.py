@@ -17,13 +17,17 @@ Timing: W untimed warm-up steps, then the K-step pass is REPEATED until at least
 barrier + torch.cuda.synchronize() on both sides, timed per rank, MAX over ranks; the line
 reports the MEDIAN repetition (`ms_per_step`, `value`), the repetition count and the spread.
 
-One JSON line on rank 0; extra objects: roofline (dominant kernel = the fp32 MFMA
-implicit-GEMM conv), roofline_kalman (batched persistent scan, HBM), cpu_baseline
-(reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
+One JSON line on rank 0; extra objects: roofline (the dominant kernel instantiation of the step -- round 4: wino4_kernel,
+Winograd F(4x4,3x3) on the fp32 MFMA), roofline_kalman (batched persistent scan, HBM; at T = 64 and T = 256),
+cpu_baseline (reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
 
-`--config c2` / `--config c5` print the line of BASELINE configs[1] (SCoordNet-only single
-480x640 frame, latency) / configs[4] (960x540, batch of sequences, fp16 convs + fp32 Kalman)
-instead; the default (`c3`, configs[2]) is the headline the driver records.
+On one GPU the default (`c3`, BASELINE configs[2]: the headline the driver records) line ALSO carries, each in its own
+block: config3_256_frames (the literal 256-frame pass), host_streamed = value_streamed (SURVEY 8(d)'s definition: H2D of
+the frames and D2H of the records inside the timed region), eval_png_end_to_end (PNG files -> coord_<i>.npy files through
+kfnet_amd.KFNet.eval), config5_960x540 (BASELINE configs[4]: value, roofline of its dominant fp16 kernel, masked parity
+against the fp32 path), config2_single_frame (configs[1], latency), and LAST a `summary` of the numbers a reader wants
+first.  Multi-rank lines carry `handoff` (the measured serial chain of scans and hand-offs) and, at 8 ranks with fewer
+than 256 steps, `config4_2048_frames` (configs[3]).  `--config c2` / `--config c5` print those configurations alone.
 """
 import argparse
 import json
