@@ -128,7 +128,7 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_ORDER_AUTO 0
 #define KFN_WINO_ORDER_M_FAST 1
 #define KFN_WINO_ORDER_N_FAST 2
-#define KFN_WINO_ORDER_GROUPS(n) (16 + (n)) /* kfn_conv2d_winograd_f43 only: n channel groups (of 64) of a tile block adjacent */
+#define KFN_WINO_ORDER_GROUPS(n) (16 + (n)) /* kfn_conv2d_winograd_f43 / _s2: n channel groups (of 64 / 128) of a tile block adjacent */
 #define KFN_WINO_FORM_AUTO 0
 #define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel / wino3_pair_kernel would run */
 

@@ -98,7 +98,7 @@ struct WinoS2Args {
   int bw;
   int tiles_m, tiles_n;
   int relu;
-  int n_fast;          // workgroup order: channel groups of a tile block adjacent (1) or M fastest (0)
+  int n_group;         // workgroup order: n_group channel groups of a tile block adjacent (1 = M fastest, tiles_n = all)
   int wide_store;
   unsigned long long x_bytes;
   unsigned long long y_bytes;
@@ -150,8 +150,10 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   // Workgroups that run side by side on an XCD share its L2.  n_fast: the Cout/128 channel groups of one tile
   // block are neighbours (the input crosses HBM once, every group's weights are live at once); else M fastest
   // (one channel group's weights stay hot, the input is fetched once per channel group).
-  const int tm = p.n_fast ? tile / p.tiles_n : tile % p.tiles_m;
-  const int tn = p.n_fast ? tile % p.tiles_n : tile / p.tiles_m;
+  const int per = p.tiles_m * p.n_group;        // (n_group divides tiles_n)
+  const int gset = tile / per, rem_ = tile - gset * per;
+  const int tm = rem_ / p.n_group;
+  const int tn = gset * p.n_group + (rem_ - tm * p.n_group);
   const int cb = tm % p.bw, rb = tm / p.bw;
   const int n0 = tn * NT + wave * 32;
 
@@ -481,7 +483,16 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_s2: grid too large");
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
-  a.n_fast = d->wino_order == KFN_WINO_ORDER_N_FAST ? 1 : (d->wino_order == KFN_WINO_ORDER_M_FAST ? 0 : KFN_WINO_DEFAULT_N_FAST);
+  {
+    // AUTO: two channel groups of a tile block adjacent (round 4, profiles/r04_wino4_microbench.log: conv4a 7.19 ms against
+    // 7.34 with all eight adjacent and 7.29 with the tile blocks fastest; conv3a / conv2a within 1 % of each other)
+    int ng = a.tiles_n % 2 == 0 ? 2 : (KFN_WINO_DEFAULT_N_FAST ? a.tiles_n : 1);
+    if (d->wino_order == KFN_WINO_ORDER_N_FAST) ng = a.tiles_n;
+    else if (d->wino_order == KFN_WINO_ORDER_M_FAST) ng = 1;
+    else if (d->wino_order >= KFN_WINO_ORDER_GROUPS(1)) ng = d->wino_order - KFN_WINO_ORDER_GROUPS(0);
+    if (ng < 1 || ng > a.tiles_n || a.tiles_n % ng != 0) ng = KFN_WINO_DEFAULT_N_FAST ? a.tiles_n : 1;
+    a.n_group = ng;
+  }
   a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   const long in_pix = (long)d->N * d->H * d->W, out_pix = (long)d->N * a.Ho * a.Wo;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
