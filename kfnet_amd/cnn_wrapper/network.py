@@ -262,17 +262,24 @@ class Network(object):
         # (measured at batch 32, F(2x2,3x3) -> F(4x4,3x3), profiles/r04_wino4_microbench.log: conv2b 10.02 -> 6.99 ms,
         #  conv3b 9.30 -> 6.41, conv4b 9.18 -> 6.26, conv5 4.61 -> 3.28, conv6 1.24 -> 0.85, conv1b 3.66 -> 2.77, feat5 0.23 -> 0.18;
         #  with 32 output channels -- feat3 -- half of the workgroup idles: 0.31 -> 0.47, stays on wino2_kernel)
-        if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43
+        fmin = g.winograd_fused_min_channels
+        fused_ok = (k == 3 and strides == 1 and g.winograd_fused and fmin and cin >= fmin and filters >= fmin
+                    and cin <= g.winograd_fused_max_channels
+                    and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters))
+        # A launch of fewer than winograd_f43_min_workgroups workgroups (of 32 tiles x 64 channels, one per CU) leaves
+        # most of the 256 CUs idle and the smaller F(2x2,3x3) workgroups win -- single frames only (batch 1, F(4x4) ->
+        # F(2x2): conv5 80 workgroups 0.287 -> 0.238 ms, conv6 40: 0.151 -> 0.123, feat5 40: 0.031 -> 0.022; from 160
+        # workgroups up F(4x4) is ahead: conv4b at batch 1 0.288 against 0.479; profiles/r04_wino4_microbench.log, r4z)
+        f43_fills = (not fused_ok
+                     or WinogradF43ConvOp.workgroups(input.shape, filters) >= g.winograd_f43_min_workgroups)
+        if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43 and f43_fills
                 and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel)
             self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu))
             return y
-        fmin = g.winograd_fused_min_channels
         # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs
         #  7.10, conv3b 5.05 vs 5.99, conv4b 4.93 vs 5.42, conv5 2.49 vs 2.73, conv6 0.63 vs 0.77)
-        if (k == 3 and strides == 1 and g.winograd_fused and fmin and cin >= fmin and filters >= fmin
-                and cin <= g.winograd_fused_max_channels
-                and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters)):
+        if fused_ok:
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_fused_kernel)
             self._emit(WinogradFusedConvOp(name, input, y, kern, bias, relu))
             return y

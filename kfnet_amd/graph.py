@@ -559,6 +559,13 @@ class WinogradF43ConvOp(ConvOp):
         ldx = cin if ldx is None else ldx
         return cin % 16 == 0 and (h + 3) // 4 >= 8 and cout % 4 == 0 and 2 * h * w * ldx * 4 < (1 << 30)
 
+    @staticmethod
+    def workgroups(x_shape, cout):
+        """Workgroups of the launch: blocks of 4 x 8 tiles (the tile rows of the batch's images packed) x 64 channels."""
+        n, h, w, _ = x_shape
+        th, tw = (h + 3) // 4, (w + 3) // 4
+        return (-(-tw // 4)) * (-(-(n * th) // 8)) * (-(-cout // 64))
+
     def kernel_name(self, lib):
         return 'wino4_kernel'
 
@@ -1065,6 +1072,7 @@ class Graph(object):
         # F(4x4,3x3) (kfn_conv2d_winograd_f43) for 3x3 stride-1 layers with at least this many INPUT channels (0 = off):
         # the K loop must amortise the 36-position transforms and the cross-wave output reduction
         self.winograd_f43_min_channels = 64
+        self.winograd_f43_min_workgroups = 128   # below this the launch leaves the chip idle: F(2x2,3x3) (Network.conv)
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

@@ -86,7 +86,7 @@ def test_default_routes_of_the_3x3_layers():
     in kfn_conv2d_winograd_fused / kfn_conv2d_winograd_s2 (csrc/kfn_wino2.hip, kfn_wino_s2.hip) that bench.py's
     per-kernel table and roofline rely on."""
     from kfnet_amd.graph import WinogradFusedConvOp, WinogradS2ConvOp
-    g, net = _build(2)
+    g, net = _build(4)
     lib = _lib.load()            # kfn_conv2d_plan is host code: no GPU needed
     four_wave = ()
     f43 = ('conv1b', 'conv2b', 'conv3b', 'conv4b', 'conv5', 'conv6', 'feat5')   # Cin, Cout >= 64: F(4x4,3x3), csrc/kfn_wino4.hip (round 4)
@@ -122,6 +122,18 @@ def test_default_routes_of_the_3x3_layers():
     assert op4.flops() / op4.mfma_flops() == pytest.approx(4.0 * (n4 * 15) / (-(-(n4 * 15) // 8) * 8))   # 36 products per 16 outputs instead of 144
     g0, net0 = _build(2, winograd_f43_min_channels=0)
     assert all(type(op).__name__ != 'WinogradF43ConvOp' for op in g0.ops)
+    # a single frame: launches of fewer than 128 F(4x4) workgroups (conv5: 10 tile blocks x 8 channel groups, conv6: 10 x 4,
+    # feat5: 40 x 1) would leave most CUs idle and go to the F(2x2,3x3) kernels; conv4b (10 x 16 = 160) stays
+    g1, net1 = _build(1)
+    by1 = {}
+    for op in g1.ops:
+        by1.setdefault(op.name, op)
+    assert WinogradF43ConvOp.workgroups(by1['conv4b'].x.shape, 1024) == 160
+    assert WinogradF43ConvOp.workgroups(by1['conv5'].x.shape, 512) == 80
+    assert [type(by1[n]).__name__ for n in ('conv4b', 'conv5', 'conv6', 'feat5')] == \
+        ['WinogradF43ConvOp', 'WinogradFusedConvOp', 'WinogradFusedConvOp', 'WinogradFusedConvOp']
+    g1b, _ = _build(1, winograd_f43_min_workgroups=0)
+    assert sum(type(op).__name__ == 'WinogradF43ConvOp' for op in g1b.ops) == 7
     # executed MFMA FLOPs of the two-wave form: all 64 channels in one column block (no padding to 128)
     op = by2['conv1b']
     n, ho, wo, co = op.y.shape
