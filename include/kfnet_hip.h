@@ -173,7 +173,7 @@ int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles)
 
 /* Which entry points the default graph (kfnet_amd.KFNet / KFNetEngine) launches, and which it does not
  *   ON the default route: kfn_first_conv_u8[_ex], kfn_conv2d_nhwc, kfn_conv2d_winograd_fused, kfn_conv2d_winograd_f43,
- *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head, kfn_oflow_tail2, kfn_kalman_scan[_ex], kfn_eval_metrics,
+ *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head, kfn_oflow_tail2[_f16], kfn_kalman_scan[_ex], kfn_eval_metrics,
  *     kfn_send_state / kfn_recv_state (multi-GPU), kfn_copy_channels (concat fallback).
  *   LEGACY -- earlier forms of the same operators, superseded on the default route, kept as tested stand-alone
  *     operators (and reachable through the Graph switches named in DESIGN.md): kfn_conv2d_winograd (+
@@ -323,6 +323,14 @@ int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int W, int rel
 int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
                     const float* wu_packed, const float* bu, const float* w6_packed, const float* b6,
                     const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream);
+/* kfn_oflow_tail2 for BASELINE config 5 ("fp16 convs"): upconv0 and conv6 multiply on v_mfma_f32_16x16x16_f16 -- their
+ * operands are rounded to IEEE halfs (activations where the MFMA reads them, to nearest even; the weights by the packer), the
+ * accumulation, conv0's T - G, the ReLUs, 'prediction', softmax and soft-argmax stay fp32.  wu_packed_f16 = [18][64][4]
+ * halfs (kfnet_amd.graph.pack_oflow_upconv_kernel_f16), w6_packed_f16 = [27][64][4] halfs (pack_oflow_tail_kernel_f16);
+ * every other argument as for kfn_oflow_tail2. */
+int kfn_oflow_tail2_f16(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
+                        const void* wu_packed_f16, const float* bu, const void* w6_packed_f16, const float* b6,
+                        const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream);
 
 /* ---- the recurrent part: warp + Kalman predict/update + NIS + transform/emit ----------
  * One launch scans T frames of S independent sequences (one workgroup per sequence,

@@ -13,7 +13,7 @@
 // (the class convolutions of the factored cost volume, see kfn_cost_volume_gather in include/kfnet_hip.h) straight
 // into an LDS image, neighbouring windows share 7/8 of their G reads through the L2; upconv0 is 72 MFMAs on the 4x4
 // conv5 patch (one 16x16x32 product per (output parity class, live tap)); nothing but conv1a's [P,4,4,32] and the
-// flow leaves the chip.  All MFMAs are v_mfma_f32_16x16x4_f32 (exact fp32); every layer's weights live in registers
+// flow leaves the chip.  All MFMAs are v_mfma_f32_16x16x4_f32 (exact fp32; kfn_oflow_tail2_f16: 16x16x16 f16 for config 5); every layer's weights live in registers
 // for the whole kernel (conv1a 144, upconv0 72, conv6 108 per lane).
 //
 // LDS images (per wave; zero borders written once, interiors rewritten per window):
@@ -27,6 +27,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOBV = 0x80000000u;   // voffset that always fails the buffer range check -> reads 0
 
@@ -49,6 +50,11 @@ constexpr int HEAD_WAVE_BYTES = 81 * LDA * 4;
 
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// four fp32 values of an LDS image -> the four halfs of a v_mfma_f32_16x16x16_f16 operand (round to nearest even)
+__device__ __forceinline__ f16x4 to_h4(const f32x4& v) {
+  return f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
 }
 
 struct FusedArgs {
@@ -180,9 +186,14 @@ __global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const f
 // ------------------------------------------------------------------------------------------------
 // tail: upconv0 ++ conv0 -> conv6 -> prediction -> softmax -> soft-argmax
 // ------------------------------------------------------------------------------------------------
+// H16 (BASELINE config 5, "fp16 convs"): upconv0 and conv6 on v_mfma_f32_16x16x16_f16 -- the LDS images stay fp32 (conv0's
+// T - G, the ReLUs, 'prediction', softmax and the soft-argmax are fp32 arithmetic as before), a lane's four consecutive
+// channels of an A read are rounded to halfs where they are consumed, the weights arrive as halfs: 27 + 18 operand
+// registers pairs instead of 108 + 72 floats, 108 + 18 MFMAs per window instead of 432 + 72 (at 16x the rate).
+template <bool H16>
 __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const float* __restrict__ x5,
-                                                             const float* __restrict__ wup, const float* __restrict__ bu,
-                                                             const float* __restrict__ w6p, const float* __restrict__ b6,
+                                                             const void* __restrict__ wup_, const float* __restrict__ bu,
+                                                             const void* __restrict__ w6p_, const float* __restrict__ b6,
                                                              const float* __restrict__ wp, const float* __restrict__ bp,
                                                              float* __restrict__ flow, float* __restrict__ logits_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_of[];
@@ -195,13 +206,27 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
   __builtin_amdgcn_wave_barrier();   // the zero fill is ordered before the first interior stores (same wave; pins the compiler)
 
   // conv6: fragment t = tap*12 + j of lane (n, kq) = w6[tap][kq*12 + j][n]   (graph.pack_oflow_tail_kernel)
-  float w6r[108];
+  // H16: fragment t = tap*3 + s, four halfs j = w6[tap][kq*12 + 4s + j][n]    (graph.pack_oflow_tail_kernel_f16)
+  float w6r[H16 ? 1 : 108];
+  f16x4 w6h[H16 ? 27 : 1];
+  if constexpr (H16) {
 #pragma unroll
-  for (int t = 0; t < 108; ++t) w6r[t] = w6p[t * 64 + lane];
+    for (int t = 0; t < 27; ++t) w6h[t] = static_cast<const f16x4*>(w6p_)[t * 64 + lane];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 108; ++t) w6r[t] = static_cast<const float*>(w6p_)[t * 64 + lane];
+  }
   // upconv0: fragment t = tap*8 + j = wu[ky][kx][n][kq*8 + j]                  (graph.pack_oflow_upconv_kernel)
-  float wur[72];
+  // H16: fragment t = tap*2 + s, four halfs j = wu[ky][kx][n][kq*8 + 4s + j]  (graph.pack_oflow_upconv_kernel_f16)
+  float wur[H16 ? 1 : 72];
+  f16x4 wuh[H16 ? 18 : 1];
+  if constexpr (H16) {
 #pragma unroll
-  for (int t = 0; t < 72; ++t) wur[t] = wup[t * 64 + lane];
+    for (int t = 0; t < 18; ++t) wuh[t] = static_cast<const f16x4*>(wup_)[t * 64 + lane];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 72; ++t) wur[t] = static_cast<const float*>(wup_)[t * 64 + lane];
+  }
   const int li = lane & 15, kq = lane >> 4;
   const float bias6 = b6 ? b6[li] : 0.f;
   const float biasu = bu ? bu[li] : 0.f;
@@ -283,10 +308,16 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
       for (int kx = 0; kx < 3; ++kx) {
         const int pa = (ky == 1) ? 1 : 0, pb = (kx == 1) ? 1 : 0;
         const int di = (ky == 2) ? 1 : 0, dj = (kx == 2) ? 1 : 0;
+        if constexpr (H16) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          ud[pa][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[di][dj][j >> 2][j & 3], wur[(ky * 3 + kx) * 8 + j],
-                                                            ud[pa][pb], 0, 0, 0);
+          for (int s = 0; s < 2; ++s)
+            ud[pa][pb] = __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(ua[di][dj][s]), wuh[(ky * 3 + kx) * 2 + s], ud[pa][pb], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            ud[pa][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[di][dj][j >> 2][j & 3], wur[(ky * 3 + kx) * 8 + j],
+                                                              ud[pa][pb], 0, 0, 0);
+        }
       }
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa)
@@ -301,8 +332,26 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
     f32x4 acc[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{bias6, bias6, bias6, bias6};
+    if constexpr (H16) {
+      // (four independent accumulators per tap: a 16x16x16 MFMA is 4 passes, its result is needed again 3 MFMAs later)
 #pragma unroll
-    for (int mp = 0; mp < 2; ++mp) {
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * 10 + (tap % 3)) * (LD1 * 4);
+        f32x4 af[4][3];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            af[mb][s] = *reinterpret_cast<const f32x4*>(t1 + a_base + mb * (2 * LD1 * 4) + toff + s * 16);
+#pragma unroll
+        for (int sq = 0; sq < 3; ++sq)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(af[mb][sq]), w6h[tap * 3 + sq], acc[mb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mp = 0; mp < (H16 ? 0 : 2); ++mp) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int toff = ((tap / 3) * 10 + (tap % 3)) * (LD1 * 4);
@@ -390,21 +439,40 @@ extern "C" int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int
   return KFN_OK;
 }
 
-extern "C" int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
-                               const float* wu_packed, const float* bu, const float* w6_packed, const float* b6,
-                               const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream) {
-  KFN_REQUIRE(x5 && wu_packed && w6_packed && wp && flow_xy, "kfn_oflow_tail2: null argument");
-  KFN_REQUIRE((reinterpret_cast<uintptr_t>(x5) & 15) == 0, "kfn_oflow_tail2: x5 must be 16-byte aligned");
+namespace {
+template <bool H16>
+int launch_tail2(const char* who, const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
+                 const void* wu_packed, const float* bu, const void* w6_packed, const float* b6, const float* wp,
+                 const float* bp, float* flow_xy, float* opt_logits, void* stream) {
+  KFN_REQUIRE(x5 && wu_packed && w6_packed && wp && flow_xy, "%s: null argument", who);
+  KFN_REQUIRE((reinterpret_cast<uintptr_t>(x5) & 15) == 0, "%s: x5 must be 16-byte aligned", who);
+  KFN_REQUIRE(((reinterpret_cast<uintptr_t>(wu_packed) | reinterpret_cast<uintptr_t>(w6_packed)) & 7) == 0,
+              "%s: packed weights must be 8-byte aligned", who);
   FusedArgs a;
-  int rc = fill_args(a, T, Gp, N, H, W, relu0, "kfn_oflow_tail2");
+  int rc = fill_args(a, T, Gp, N, H, W, relu0, who);
   if (rc != KFN_OK) return rc;
-  static std::atomic<uint64_t> attr_done{0};
-  rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(oflow_tail2_kernel), 4 * TAIL_WAVE_BYTES, attr_done);
+  static std::atomic<uint64_t> attr_done{0};   // (one per instantiation)
+  rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(oflow_tail2_kernel<H16>), 4 * TAIL_WAVE_BYTES, attr_done);
   if (rc != KFN_OK) return rc;
   int blocks = kfn::ceil_div(a.P, 4);
   if (blocks > 256) blocks = 256;      // one workgroup of four waves per CU
-  hipLaunchKernelGGL(oflow_tail2_kernel, dim3(blocks), dim3(256), 4 * TAIL_WAVE_BYTES, (hipStream_t)stream, a, x5,
+  hipLaunchKernelGGL(oflow_tail2_kernel<H16>, dim3(blocks), dim3(256), 4 * TAIL_WAVE_BYTES, (hipStream_t)stream, a, x5,
                      wu_packed, bu, w6_packed, b6, wp, bp, flow_xy, opt_logits);
   KFN_LAUNCH_CHECK("oflow_tail2_kernel");
   return KFN_OK;
+}
+}  // namespace
+
+extern "C" int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
+                               const float* wu_packed, const float* bu, const float* w6_packed, const float* b6,
+                               const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream) {
+  return launch_tail2<false>("kfn_oflow_tail2", T, Gp, N, H, W, relu0, x5, wu_packed, bu, w6_packed, b6, wp, bp, flow_xy,
+                             opt_logits, stream);
+}
+
+extern "C" int kfn_oflow_tail2_f16(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
+                                   const void* wu_packed_f16, const float* bu, const void* w6_packed_f16, const float* b6,
+                                   const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream) {
+  return launch_tail2<true>("kfn_oflow_tail2_f16", T, Gp, N, H, W, relu0, x5, wu_packed_f16, bu, w6_packed_f16, b6, wp, bp,
+                            flow_xy, opt_logits, stream);
 }

@@ -848,6 +848,16 @@ def pack_oflow_tail_kernel(w):
     return np.ascontiguousarray(wt.transpose(0, 2, 1, 3).reshape(108, 64))
 
 
+def pack_oflow_tail_kernel_f16(w):
+    """conv6 for kfn_oflow_tail2_f16: [27][64][4] halfs -- fragment t = tap*3 + s of lane (kq, n) holds
+    w[tap][kq*12 + 4s + j][n], j = 0..3 (the B operand of one v_mfma_f32_16x16x16_f16: the same 12 consecutive input
+    channels per lane and tap as pack_oflow_tail_kernel, four to an MFMA)."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 48, 16)
+    wt = w.reshape(9, 4, 3, 4, 16)                     # [tap][kq][s][j][n]
+    return np.ascontiguousarray(wt.transpose(0, 2, 1, 4, 3).reshape(27, 64, 4)).astype(np.float16)
+
+
 class OFlowTailOp(Op):
     """OFlowNet conv6 + 'prediction' conv + softmax + soft-argmax in one launch (kfn_oflow_tail): one wave per
     window, the 8x8x48 patch resident in LDS, conv6's weights in registers."""
@@ -891,6 +901,15 @@ def pack_oflow_upconv_kernel(w):
     return np.ascontiguousarray(wt.transpose(0, 3, 2, 1).reshape(72, 64))
 
 
+def pack_oflow_upconv_kernel_f16(w):
+    """upconv0 for kfn_oflow_tail2_f16: [18][64][4] halfs -- fragment t = tap*2 + s of lane (kq, n) holds
+    w[tap][n][kq*8 + 4s + j], j = 0..3."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 16, 32)
+    wt = w.reshape(9, 16, 4, 2, 4)                     # [tap][n][kq][s][j]
+    return np.ascontiguousarray(wt.transpose(0, 3, 2, 1, 4).reshape(18, 64, 4)).astype(np.float16)
+
+
 class OFlowHeadOp(Op):
     """conv0 (from the factored cost-volume maps) + conv1a in one window-resident launch (kfn_oflow_head)."""
 
@@ -922,9 +941,10 @@ class OFlowTail2Op(Op):
     """upconv0 + conv0 (recomputed from the maps) + conv6 + 'prediction' + softmax + soft-argmax in one
     window-resident launch (kfn_oflow_tail2); neither concat0 nor upconv0's output exist in memory."""
 
-    def __init__(self, t, gp, relu0, x5, ku, bu, k6, b6, kp, bpred, flow, logits=None):
+    def __init__(self, t, gp, relu0, x5, ku, bu, k6, b6, kp, bpred, flow, logits=None, operands_f16=False):
         self.name = 'oflow_tail2[upconv0+conv6+prediction+softargmax]'
         self.t, self.gp, self.relu0, self.x5 = t, gp, relu0, x5
+        self.operands_f16 = operands_f16      # ku / k6 packed by the *_f16 packers -> kfn_oflow_tail2_f16 (config 5)
         self.ku, self.bu, self.k6, self.b6, self.kp, self.bpred, self.flow, self.logits = ku, bu, k6, b6, kp, bpred, flow, logits
 
     def kernel_name(self, lib):
@@ -944,11 +964,13 @@ class OFlowTail2Op(Op):
         n, h, w, c9 = self.t.shape
         n = _scaled(n, self.t.graph)
         assert c9 == 288 and self.t.ld == c9 and self.gp.ld == c9 and self.x5.is_whole() and self.x5.shape[1:] == (4, 4, 32)
-        _lib.check(lib.kfn_oflow_tail2(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.x5.ptr, self.ku.ptr,
-                                       self.bu.ptr if self.bu is not None else None, self.k6.ptr,
-                                       self.b6.ptr if self.b6 is not None else None, self.kp.ptr,
-                                       self.bpred.ptr if self.bpred is not None else None, self.flow.ptr,
-                                       self.logits.ptr if self.logits is not None else None, stream), 'kfn_oflow_tail2')
+        fn = lib.kfn_oflow_tail2_f16 if self.operands_f16 else lib.kfn_oflow_tail2
+        _lib.check(fn(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.x5.ptr, self.ku.ptr,
+                      self.bu.ptr if self.bu is not None else None, self.k6.ptr,
+                      self.b6.ptr if self.b6 is not None else None, self.kp.ptr,
+                      self.bpred.ptr if self.bpred is not None else None, self.flow.ptr,
+                      self.logits.ptr if self.logits is not None else None, stream),
+                   'kfn_oflow_tail2_f16' if self.operands_f16 else 'kfn_oflow_tail2')
 
 
 class CopyChannelsOp(Op):
@@ -1057,6 +1079,7 @@ class Graph(object):
         # conv6 + prediction + soft-argmax): conv0's [P,8,8,32] output, concat0 and the gather launch disappear.
         # Needs the factored cost volume and the fused tail.
         self.fuse_oflow_window = True
+        self.oflow_tail_f16 = True   # conv_operands == 'f16' only: upconv0 / conv6 of that launch on fp16 MFMAs (kfn_oflow_tail2_f16)
         self.lds_bytes_per_cu = 160 * 1024   # gfx950; KFNetEngine overwrites it with kfn_device_info's answer before the
                                              # graph is built (the window-resident OFlowNet tail needs 136 000 B per workgroup)
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels
