@@ -173,7 +173,7 @@ int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles)
 
 /* Which entry points the default graph (kfnet_amd.KFNet / KFNetEngine) launches, and which it does not
  *   ON the default route: kfn_first_conv_u8[_ex], kfn_conv2d_nhwc, kfn_conv2d_winograd_fused, kfn_conv2d_winograd_f43,
- *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head, kfn_oflow_tail2[_f16], kfn_kalman_scan[_ex], kfn_eval_metrics,
+ *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head[_f16], kfn_oflow_tail2[_f16], kfn_kalman_scan[_ex], kfn_eval_metrics,
  *     kfn_send_state / kfn_recv_state (multi-GPU), kfn_copy_channels (concat fallback).
  *   LEGACY -- earlier forms of the same operators, superseded on the default route, kept as tested stand-alone
  *     operators (and reachable through the Graph switches named in DESIGN.md): kfn_conv2d_winograd (+
@@ -320,6 +320,11 @@ int kfn_oflow_tail(const float* x, const float* w6_packed, const float* b6, cons
  * relu0 = conv0's activation flag.  One wave per window; all weights in registers; exact fp32 MFMAs. */
 int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* w1_packed,
                    const float* b1, float* y, void* stream);
+/* kfn_oflow_head for BASELINE config 5: conv1a multiplies on v_mfma_f32_16x16x16_f16 (operands rounded to halfs where the
+ * MFMA reads them / by the packer; conv0's T - G, the accumulation, bias and ReLU fp32; y fp32).  w1_packed_f16 =
+ * [36][64][4] halfs (kfnet_amd.graph.pack_oflow_head_kernel_f16). */
+int kfn_oflow_head_f16(const float* T, const float* Gp, int N, int H, int W, int relu0, const void* w1_packed_f16,
+                       const float* b1, float* y, void* stream);
 int kfn_oflow_tail2(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* x5,
                     const float* wu_packed, const float* bu, const float* w6_packed, const float* b6,
                     const float* wp, const float* bp, float* flow_xy, float* opt_logits, void* stream);

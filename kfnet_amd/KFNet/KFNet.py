@@ -168,7 +168,8 @@ class KFNet():
         conv0's output, upconv0's output and concat0 are then never written.  Applied only when the graph has
         exactly the reference's wiring (cnn_wrapper/OFlowNet.py:19-20,36-41); otherwise nothing changes."""
         from ..graph import (OFlowHeadOp, OFlowTail2Op, OFlowTailOp, pack_bias, pack_oflow_head_kernel,
-                             pack_oflow_tail_kernel_f16, pack_oflow_upconv_kernel, pack_oflow_upconv_kernel_f16)
+                             pack_oflow_head_kernel_f16, pack_oflow_tail_kernel_f16, pack_oflow_upconv_kernel,
+                             pack_oflow_upconv_kernel_f16)
         g = self.graph
         net_ops = self.oflownet.ops
         if not g.fuse_oflow_window:
@@ -205,17 +206,17 @@ class KFNet():
                 ok = False
         if not ok:
             return
-        # "fp16 convs" (BASELINE config 5): upconv0 and conv6 multiply in fp16 like OFlowNet's other layers in that mode
-        # (16x the MFMA rate: the tail is MFMA-bound in fp32); conv1a stays fp32 -- the head is bound by the T / G reads
+        # "fp16 convs" (BASELINE config 5): conv1a, upconv0 and conv6 multiply in fp16 like OFlowNet's other layers in that
+        # mode (both launches are MFMA-bound in fp32: 0.37 -> 0.1x ms and 1.29 -> 0.3x ms per 16 frames of 540x960)
         h16 = g.conv_operands == 'f16' and g.oflow_tail_f16
-        c1a.kernel.pack = pack_oflow_head_kernel
+        c1a.kernel.pack = pack_oflow_head_kernel_f16 if h16 else pack_oflow_head_kernel
         up0.kernel.pack = pack_oflow_upconv_kernel_f16 if h16 else pack_oflow_upconv_kernel
         if h16:
             tail.k6.pack = pack_oflow_tail_kernel_f16
         for b in (c1a.bias, up0.bias):
             if b is not None:
                 b.pack = pack_bias
-        head = OFlowHeadOp(tt, gp, conv0.relu, c1a.kernel, c1a.bias, c1a.y, cin)
+        head = OFlowHeadOp(tt, gp, conv0.relu, c1a.kernel, c1a.bias, c1a.y, cin, operands_f16=h16)
         tail2 = OFlowTail2Op(tt, gp, conv0.relu, up0.x, up0.kernel, up0.bias, tail.k6, tail.b6, tail.kp, tail.bpred,
                              tail.flow, operands_f16=h16)
         for lst in (g.ops, net_ops):

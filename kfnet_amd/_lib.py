@@ -88,6 +88,7 @@ SYMBOLS = {
     'kfn_flow_head': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'kfn_oflow_tail': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'kfn_oflow_head': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'kfn_oflow_head_f16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'kfn_oflow_tail2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_oflow_tail2_f16': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kfn_kalman_scan_scratch_bytes': (_i, [C.POINTER(KalmanDesc), C.POINTER(_sz)]),

@@ -118,7 +118,10 @@ __device__ __forceinline__ f32x4 conv0_value(f32x4 t, f32x4 g, bool relu) {
 // ------------------------------------------------------------------------------------------------
 // head: conv0 -> conv1a
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const float* __restrict__ w1p,
+// H16 (kfn_oflow_head_f16, BASELINE config 5): conv1a on v_mfma_f32_16x16x16_f16 -- the conv0 image stays fp32, a lane's
+// four consecutive channels are rounded to halfs where the MFMA reads them; 36 MFMAs per window instead of 144.
+template <bool H16>
+__global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const void* __restrict__ w1p_,
                                                             const float* __restrict__ b1, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem_of[];
   const int lane = threadIdx.x & 63;
@@ -128,9 +131,16 @@ __global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const f
   __builtin_amdgcn_wave_barrier();   // the zero fill is ordered before the first interior stores (same wave; pins the compiler)
 
   // conv1a weights: fragment t = (tap*8 + j)*2 + nb of lane (n = l%16, kq = l/16) = w[tap][kq*8 + j][nb*16 + n]
-  float wreg[144];
+  // H16: fragment t = (tap*2 + s)*2 + nb, four halfs j = w[tap][kq*8 + 4s + j][nb*16 + n]   (graph.pack_oflow_head_kernel_f16)
+  float wreg[H16 ? 1 : 144];
+  f16x4 wh[H16 ? 36 : 1];
+  if constexpr (H16) {
 #pragma unroll
-  for (int t = 0; t < 144; ++t) wreg[t] = w1p[t * 64 + lane];
+    for (int t = 0; t < 36; ++t) wh[t] = static_cast<const f16x4*>(w1p_)[t * 64 + lane];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 144; ++t) wreg[t] = static_cast<const float*>(w1p_)[t * 64 + lane];
+  }
   const int li = lane & 15, kq = lane >> 4;
   const float bias0 = b1 ? b1[li] : 0.f, bias1 = b1 ? b1[16 + li] : 0.f;
 
@@ -161,17 +171,41 @@ __global__ __launch_bounds__(256, 2) void oflow_head_kernel(FusedArgs a, const f
     __builtin_amdgcn_wave_barrier();
 
     f32x4 acc[2] = {f32x4{bias0, bias0, bias0, bias0}, f32x4{bias1, bias1, bias1, bias1}};
+    if constexpr (H16) {
+      // all 18 A reads first (the MFMAs are 4 passes each: read-wait-multiply per tap would be LDS latency, 36 times),
+      // four independent accumulators (nb, s), summed at the end
+      f32x4 av[9][2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3) * 9 + (tap % 3)) * (LDA * 4);
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(tA + a_base + toff);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(tA + a_base + toff + 16);
+      for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+        for (int sq = 0; sq < 2; ++sq)
+          av[tap][sq] = *reinterpret_cast<const f32x4*>(tA + a_base + ((tap / 3) * 9 + (tap % 3)) * (LDA * 4) + sq * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 4 ? a0[j & 3] : a1[j & 3], wreg[(tap * 8 + j) * 2 + nb],
-                                                         acc[nb], 0, 0, 0);
+      for (int tap = 0; tap < 9; ++tap) {
+        const f16x4 h0 = to_h4(av[tap][0]), h1 = to_h4(av[tap][1]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(h0, wh[(tap * 2 + 0) * 2 + nb], acc[nb], 0, 0, 0);
+          acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(h1, wh[(tap * 2 + 1) * 2 + nb], acc2[nb], 0, 0, 0);
+        }
+      }
+      acc[0] += acc2[0];
+      acc[1] += acc2[1];
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * 9 + (tap % 3)) * (LDA * 4);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(tA + a_base + toff);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(tA + a_base + toff + 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 4 ? a0[j & 3] : a1[j & 3], wreg[(tap * 8 + j) * 2 + nb],
+                                                           acc[nb], 0, 0, 0);
+      }
     }
     // accumulator element e of lane (n, kq) = output cell (kq, e), channel nb*16 + n; ReLU (OFlowNet.py:20)
     float* yp = y + (size_t)p * (16 * C0);
@@ -297,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
 #pragma unroll
         for (int s = 0; s < 2; ++s)
           ua[di][dj][s] = *reinterpret_cast<const f32x4*>(t3 + u_base - (di * 5 + dj) * (LD3 * 4) + s * 16);
+    if constexpr (H16) __builtin_amdgcn_sched_barrier(0);   // the eight reads as one group (4-pass MFMAs hide no LDS latency)
     f32x4 ud[2][2];
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa)
@@ -334,20 +369,29 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
     for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{bias6, bias6, bias6, bias6};
     if constexpr (H16) {
       // (four independent accumulators per tap: a 16x16x16 MFMA is 4 passes, its result is needed again 3 MFMAs later)
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // and the 12 A reads of tap + 1 are issued as one group before the 12 MFMAs of tap: left to itself the compiler
+      // emits read - wait - MFMA triples, 108 LDS latencies per window
+      f32x4 af[2][4][3];
+      auto a_reads = [&](int tap, f32x4 (&dst)[4][3]) __attribute__((always_inline)) {
         const int toff = ((tap / 3) * 10 + (tap % 3)) * (LD1 * 4);
-        f32x4 af[4][3];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
           for (int s = 0; s < 3; ++s)
-            af[mb][s] = *reinterpret_cast<const f32x4*>(t1 + a_base + mb * (2 * LD1 * 4) + toff + s * 16);
+            dst[mb][s] = *reinterpret_cast<const f32x4*>(t1 + a_base + mb * (2 * LD1 * 4) + toff + s * 16);
+      };
+      a_reads(0, af[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) a_reads(tap + 1, af[(tap + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sq = 0; sq < 3; ++sq)
 #pragma unroll
           for (int mb = 0; mb < 4; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(af[mb][sq]), w6h[tap * 3 + sq], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(af[tap & 1][mb][sq]), w6h[tap * 3 + sq], acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
@@ -377,20 +421,32 @@ __global__ __launch_bounds__(256, 1) void oflow_tail2_kernel(FusedArgs a, const 
     __builtin_amdgcn_wave_barrier();
 
     // ---- prediction conv: one window cell per lane, wave-uniform weights -------------------------
-    float lg = bias_p;
+    // The 36 reads go out as one group (one wave per SIMD: nothing else hides an LDS latency per read -- 36 of them were
+    // 3.6 K cycles per window), then 144 FMAs in four independent chains (one per channel quad).
+    f32x4 xv[9][C2 / 4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int q = 0; q < C2 / 4; ++q)
+        xv[tap][q] = *reinterpret_cast<const f32x4*>(t2 + p_base + ((tap / 3) * ROW2 + (tap % 3) * LD2) * 4 + q * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    float lq[C2 / 4];
+#pragma unroll
+    for (int q = 0; q < C2 / 4; ++q) lq[q] = 0.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const char* cellp = t2 + p_base + ((tap / 3) * ROW2 + (tap % 3) * LD2) * 4;
+      // (wave-uniform scalar loads; hipcc hoists the 144 of them out of the window loop and spills the SGPRs to VGPR
+      //  lanes: 156 v_readlane per window.  Per-lane copies end up in AGPRs and cost a v_accvgpr_read each: no better.)
       const float* wt = wp + tap * C2;
 #pragma unroll
       for (int q = 0; q < C2 / 4; ++q) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(cellp + q * 16);
-        lg = fmaf(xv.x, wt[q * 4 + 0], lg);
-        lg = fmaf(xv.y, wt[q * 4 + 1], lg);
-        lg = fmaf(xv.z, wt[q * 4 + 2], lg);
-        lg = fmaf(xv.w, wt[q * 4 + 3], lg);
+        lq[q] = fmaf(xv[tap][q].x, wt[q * 4 + 0], lq[q]);
+        lq[q] = fmaf(xv[tap][q].y, wt[q * 4 + 1], lq[q]);
+        lq[q] = fmaf(xv[tap][q].z, wt[q * 4 + 2], lq[q]);
+        lq[q] = fmaf(xv[tap][q].w, wt[q * 4 + 3], lq[q]);
       }
     }
+    const float lg = ((lq[0] + lq[1]) + (lq[2] + lq[3])) + bias_p;
     if (logits_out) logits_out[(size_t)p * 64 + lane] = lg;
     // ---- softmax over the 64 cells + soft-argmax (DPP reductions: kfn_common.h) -----------
     const float mx = kfn::wave_max_dpp(lg);
@@ -422,21 +478,35 @@ int fill_args(FusedArgs& a, const float* T, const float* Gp, int N, int H, int W
 
 }  // namespace
 
-extern "C" int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* w1_packed,
-                              const float* b1, float* y, void* stream) {
-  KFN_REQUIRE(w1_packed && y, "kfn_oflow_head: null argument");
+namespace {
+template <bool H16>
+int launch_head(const char* who, const float* T, const float* Gp, int N, int H, int W, int relu0, const void* w1_packed,
+                const float* b1, float* y, void* stream) {
+  KFN_REQUIRE(w1_packed && y, "%s: null argument", who);
+  KFN_REQUIRE((reinterpret_cast<uintptr_t>(w1_packed) & 7) == 0, "%s: packed weights must be 8-byte aligned", who);
   FusedArgs a;
-  int rc = fill_args(a, T, Gp, N, H, W, relu0, "kfn_oflow_head");
+  int rc = fill_args(a, T, Gp, N, H, W, relu0, who);
   if (rc != KFN_OK) return rc;
-  static std::atomic<uint64_t> attr_done{0};
-  rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(oflow_head_kernel), 4 * HEAD_WAVE_BYTES, attr_done);
+  static std::atomic<uint64_t> attr_done{0};   // (one per instantiation)
+  rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(oflow_head_kernel<H16>), 4 * HEAD_WAVE_BYTES, attr_done);
   if (rc != KFN_OK) return rc;
   int blocks = kfn::ceil_div(a.P, 4);
   if (blocks > 512) blocks = 512;      // two workgroups of four waves per CU, each wave walks its windows
-  hipLaunchKernelGGL(oflow_head_kernel, dim3(blocks), dim3(256), 4 * HEAD_WAVE_BYTES, (hipStream_t)stream, a, w1_packed,
-                     b1, y);
+  hipLaunchKernelGGL(oflow_head_kernel<H16>, dim3(blocks), dim3(256), 4 * HEAD_WAVE_BYTES, (hipStream_t)stream, a,
+                     w1_packed, b1, y);
   KFN_LAUNCH_CHECK("oflow_head_kernel");
   return KFN_OK;
+}
+}  // namespace
+
+extern "C" int kfn_oflow_head(const float* T, const float* Gp, int N, int H, int W, int relu0, const float* w1_packed,
+                              const float* b1, float* y, void* stream) {
+  return launch_head<false>("kfn_oflow_head", T, Gp, N, H, W, relu0, w1_packed, b1, y, stream);
+}
+
+extern "C" int kfn_oflow_head_f16(const float* T, const float* Gp, int N, int H, int W, int relu0, const void* w1_packed_f16,
+                                  const float* b1, float* y, void* stream) {
+  return launch_head<true>("kfn_oflow_head_f16", T, Gp, N, H, W, relu0, w1_packed_f16, b1, y, stream);
 }
 
 namespace {

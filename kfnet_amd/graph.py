@@ -892,6 +892,15 @@ def pack_oflow_head_kernel(w):
     return np.ascontiguousarray(wt.transpose(0, 2, 3, 1, 4).reshape(144, 64))
 
 
+def pack_oflow_head_kernel_f16(w):
+    """conv1a for kfn_oflow_head_f16: [36][64][4] halfs -- fragment t = (tap*2 + s)*2 + nb of lane (kq, n) holds
+    w[tap][kq*8 + 4s + j][nb*16 + n], j = 0..3 (the B operand of one v_mfma_f32_16x16x16_f16)."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 32, 32)
+    wt = w.reshape(9, 4, 2, 4, 2, 16)                  # [tap][kq][s][j][nb][n]
+    return np.ascontiguousarray(wt.transpose(0, 2, 4, 1, 5, 3).reshape(36, 64, 4)).astype(np.float16)
+
+
 def pack_oflow_upconv_kernel(w):
     """TF conv2d_transpose kernel [3,3,Cout=16,Cin=32] (OFlowNet upconv0) -> the per-lane fragments [72][64] of
     kfn_oflow_tail2: fragment t = tap*8 + j of lane (kq, n) is w[tap][n][kq*8 + j]."""
@@ -913,9 +922,10 @@ def pack_oflow_upconv_kernel_f16(w):
 class OFlowHeadOp(Op):
     """conv0 (from the factored cost-volume maps) + conv1a in one window-resident launch (kfn_oflow_head)."""
 
-    def __init__(self, t, gp, relu0, k1, b1, y, cin):
+    def __init__(self, t, gp, relu0, k1, b1, y, cin, operands_f16=False):
         self.name = 'oflow_head[conv0+conv1a]'
         self.t, self.gp, self.relu0, self.k1, self.b1, self.y, self.cin = t, gp, relu0, k1, b1, y, cin
+        self.operands_f16 = operands_f16      # k1 packed by pack_oflow_head_kernel_f16 -> kfn_oflow_head_f16 (config 5)
 
     def kernel_name(self, lib):
         return 'oflow_head_kernel'
@@ -933,8 +943,10 @@ class OFlowHeadOp(Op):
         n, h, w, c9 = self.t.shape
         n = _scaled(n, self.t.graph)
         assert c9 == 288 and self.t.ld == c9 and self.gp.ld == c9 and self.y.is_whole() and self.y.shape[1:] == (4, 4, 32)
-        _lib.check(lib.kfn_oflow_head(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.k1.ptr,
-                                      self.b1.ptr if self.b1 is not None else None, self.y.ptr, stream), 'kfn_oflow_head')
+        fn = lib.kfn_oflow_head_f16 if self.operands_f16 else lib.kfn_oflow_head
+        _lib.check(fn(self.t.ptr, self.gp.ptr, n, h, w, int(self.relu0), self.k1.ptr,
+                      self.b1.ptr if self.b1 is not None else None, self.y.ptr, stream),
+                   'kfn_oflow_head_f16' if self.operands_f16 else 'kfn_oflow_head')
 
 
 class OFlowTail2Op(Op):
@@ -1079,7 +1091,9 @@ class Graph(object):
         # conv6 + prediction + soft-argmax): conv0's [P,8,8,32] output, concat0 and the gather launch disappear.
         # Needs the factored cost volume and the fused tail.
         self.fuse_oflow_window = True
-        self.oflow_tail_f16 = True   # conv_operands == 'f16' only: upconv0 / conv6 of that launch on fp16 MFMAs (kfn_oflow_tail2_f16)
+        # conv_operands == 'f16' only: conv1a / upconv0 / conv6 inside the two window-resident launches on fp16 MFMAs
+        # (kfn_oflow_head_f16, kfn_oflow_tail2_f16) like OFlowNet's other layers in that mode
+        self.oflow_tail_f16 = True
         self.lds_bytes_per_cu = 160 * 1024   # gfx950; KFNetEngine overwrites it with kfn_device_info's answer before the
                                              # graph is built (the window-resident OFlowNet tail needs 136 000 B per workgroup)
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels

@@ -423,22 +423,6 @@ def test_oflow_tail_vs_oracle(P):
                                   flow2.data_ptr(), None, P, 48, 16, stream()), 'oflow_tail')
     sync()
     assert torch.equal(flow, flow2)
-    # BASELINE config 5's form: upconv0 / conv6 on fp16 MFMAs (operands rounded to halfs, fp32 accumulation and everything
-    # around them fp32).  Tolerance: 2^-11 relative per operand over K = 432 products of O(1) logits -- a wrong fragment
-    # layout is an O(1) error
-    from kfnet_amd.graph import pack_oflow_tail_kernel_f16, pack_oflow_upconv_kernel_f16
-    duh, d6h = dev(pack_oflow_upconv_kernel_f16(wu)), dev(pack_oflow_tail_kernel_f16(w6))
-    assert duh.dtype == torch.float16 and tuple(duh.shape) == (18, 64, 4) and tuple(d6h.shape) == (27, 64, 4)
-    flow3 = torch.zeros(P * 2, device='cuda')
-    logits3 = torch.zeros(P * 64, device='cuda')
-    _lib.check(lib.kfn_oflow_tail2_f16(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, d5.data_ptr(), duh.data_ptr(), dbu.data_ptr(),
-                                       d6h.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), flow3.data_ptr(),
-                                       logits3.data_ptr(), stream()), 'oflow_tail2_f16')
-    sync()
-    tol16 = 4e-3 * max(1.0, float(np.abs(ref_logits).max()))
-    e_l = np.abs(logits3.cpu().numpy().reshape(P, 64) - ref_logits).max()
-    e_f = np.abs(flow3.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max()
-    assert 0 < e_l < tol16 and e_f < 20 * tol16, (e_l, e_f, tol16)
     assert lib.kfn_oflow_tail(dx.data_ptr(), d6.data_ptr(), None, dwp.data_ptr(), None, flow2.data_ptr(), None, P, 32, 16,
                               stream()) == -3
 
@@ -1133,6 +1117,19 @@ def test_oflow_head_vs_oracle(shape):
     ref = O.conv2d_same(_oracle_conv0(f, w0, b0, N, H, W), w1, b1, 2, True)          # [P,4,4,32]
     err = np.abs(got[:P * 512].reshape(ref.shape) - ref).max()
     assert err < 4e-5 * max(1.0, float(np.abs(ref).max())), err
+    # BASELINE config 5's form: conv1a on fp16 MFMAs (operands rounded to halfs: 2^-11 relative each over K = 288; a wrong
+    # fragment layout is an O(1) error), everything around it fp32
+    from kfnet_amd.graph import pack_oflow_head_kernel_f16
+    dw1h = dev(pack_oflow_head_kernel_f16(w1))
+    assert dw1h.dtype == torch.float16 and tuple(dw1h.shape) == (36, 64, 4)
+    y16 = torch.full((P * 16 * 32 + 64,), -7.0, device='cuda')
+    _lib.check(lib.kfn_oflow_head_f16(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, dw1h.data_ptr(), db1.data_ptr(),
+                                      y16.data_ptr(), stream()), 'oflow_head_f16')
+    sync()
+    got16 = y16.cpu().numpy()
+    assert np.all(got16[P * 512:] == -7.0)
+    err16 = np.abs(got16[:P * 512].reshape(ref.shape) - ref).max()
+    assert 0 < err16 < 4e-3 * max(1.0, float(np.abs(ref).max())), err16
 
 
 @pytest.mark.parametrize('shape', [(2, 7, 9), (1, 60, 80), (3, 5, 4)])
@@ -1181,3 +1178,19 @@ def test_oflow_tail2_vs_oracle(shape):
                                    stream()), 'oflow_tail2')
     sync()
     assert torch.equal(flow, flow2)
+    # BASELINE config 5's form: upconv0 / conv6 on fp16 MFMAs (operands rounded to halfs, fp32 accumulation and everything
+    # around them fp32).  Tolerance: 2^-11 relative per operand over K = 432 products of O(1) logits -- a wrong fragment
+    # layout is an O(1) error
+    from kfnet_amd.graph import pack_oflow_tail_kernel_f16, pack_oflow_upconv_kernel_f16
+    duh, d6h = dev(pack_oflow_upconv_kernel_f16(wu)), dev(pack_oflow_tail_kernel_f16(w6))
+    assert duh.dtype == torch.float16 and tuple(duh.shape) == (18, 64, 4) and tuple(d6h.shape) == (27, 64, 4)
+    flow3 = torch.zeros(P * 2, device='cuda')
+    logits3 = torch.zeros(P * 64, device='cuda')
+    _lib.check(lib.kfn_oflow_tail2_f16(T.data_ptr(), Gp.data_ptr(), N, H, W, 1, d5.data_ptr(), duh.data_ptr(), dbu.data_ptr(),
+                                       d6h.data_ptr(), db6.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), flow3.data_ptr(),
+                                       logits3.data_ptr(), stream()), 'oflow_tail2_f16')
+    sync()
+    tol16 = 4e-3 * max(1.0, float(np.abs(ref_logits).max()))
+    e_l = np.abs(logits3.cpu().numpy().reshape(P, 64) - ref_logits).max()
+    e_f = np.abs(flow3.cpu().numpy().reshape(P, 2) - pr.dot(offs)).max()
+    assert 0 < e_l < tol16 and e_f < 20 * tol16, (e_l, e_f, tol16)
