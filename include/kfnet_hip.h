@@ -164,6 +164,16 @@ typedef struct kfn_conv_desc {
 
 int kfn_conv2d_nhwc(const kfn_conv_desc* desc, const float* x, const float* w_packed,
                     const float* bias /* [Cout] or NULL */, float* y, void* stream);
+/* 3x3 stride-1 SAME convolution 64 -> 64 channels on fp16 activations (x_dtype = y_dtype = KFN_ACT_F16, operand_dtype =
+ * KFN_OPERAND_F16; SCoordNet's conv1b in BASELINE config 5, cnn_wrapper/SCoordNet.py:20): the weights stay in registers for
+ * a workgroup's life, the workgroup walks down a strip of 128 / 192 pixels and reads every input row from the LDS once for
+ * the three output rows it feeds (csrc/kfn_conv64.hip).  Same arithmetic as kfn_conv2d_nhwc on that descriptor (fp16
+ * products, fp32 accumulation, bias, ReLU, one RNE rounding), another summation order.  w_packed = [2][36][64][8] halfs
+ * (kfnet_amd.graph.pack_conv64_rows_kernel); x, y, w_packed, bias 16-byte aligned; ldx, ldy multiples of 8 elements.
+ * kfn_conv3x3_c64_f16_supported(desc) = 1 when the launch takes the layer (KFN_ERR_UNSUPPORTED otherwise). */
+int kfn_conv3x3_c64_f16_supported(const kfn_conv_desc* desc);
+int kfn_conv3x3_c64_f16(const kfn_conv_desc* desc, const void* x, const void* w_packed, const float* bias, void* y,
+                        void* stream);
 /* Output spatial size for a descriptor (TF SAME rule); host-side shape inference. */
 int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
 /* Which kernel instantiation kfn_conv2d_nhwc will launch for `desc`: tile config
@@ -172,7 +182,7 @@ int kfn_conv2d_out_shape(const kfn_conv_desc* desc, int* Ho, int* Wo);
 int kfn_conv2d_plan(const kfn_conv_desc* desc, int* config, int* bk, int* tiles);
 
 /* Which entry points the default graph (kfnet_amd.KFNet / KFNetEngine) launches, and which it does not
- *   ON the default route: kfn_first_conv_u8[_ex], kfn_conv2d_nhwc, kfn_conv2d_winograd_fused, kfn_conv2d_winograd_f43,
+ *   ON the default route: kfn_first_conv_u8[_ex], kfn_conv2d_nhwc, kfn_conv3x3_c64_f16 (config 5), kfn_conv2d_winograd_fused, kfn_conv2d_winograd_f43,
  *     kfn_conv2d_winograd_s2, kfn_pad_nhwc, kfn_oflow_head[_f16], kfn_oflow_tail2[_f16], kfn_kalman_scan[_ex], kfn_eval_metrics,
  *     kfn_send_state / kfn_recv_state (multi-GPU), kfn_copy_channels (concat fallback).
  *   LEGACY -- earlier forms of the same operators, superseded on the default route, kept as tested stand-alone

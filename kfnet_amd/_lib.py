@@ -78,6 +78,8 @@ SYMBOLS = {
     'kfn_winograd_s2_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_conv2d_winograd_f43': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_f43_supported': (_i, [C.POINTER(ConvDesc)]),
+    'kfn_conv3x3_c64_f16': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    'kfn_conv3x3_c64_f16_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_first_conv_u8_ex': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'kfn_cost_volume': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -12,7 +12,7 @@ NotImplementedError (there is deliberately no CPU/eager fallback in the product 
 import numpy as np
 
 from .. import _lib
-from ..graph import (ConvOp, CopyChannelsOp, FirstConvOp, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
+from ..graph import (Conv64RowsF16Op, ConvOp, CopyChannelsOp, FirstConvOp, pack_conv64_rows_kernel, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
                      WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
@@ -240,6 +240,12 @@ class Network(object):
             op = WindowFcConvOp(name, input, y, kern, bias, relu)
             op.operand_dtype = _lib.OPERAND_F16
             self._emit(op)
+            return y
+        if (f16 and g.conv64_rows_f16 and k == 3 and strides == 1 and biased
+                and Conv64RowsF16Op.supported(input, y, cin, filters)):
+            # (measured, 16 frames of 540x960: 1.05 ms on the 256x64 implicit-GEMM tile, LDS-bound at 0.23 of the fp16 peak)
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_conv64_rows_kernel)
+            self._emit(Conv64RowsF16Op(name, input, y, kern, bias, relu))
             return y
         if f16:
             # fp16 activations on either side: the tap-innermost kernels with chunk-major weights

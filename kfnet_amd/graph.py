@@ -586,6 +586,49 @@ class WinogradF43ConvOp(ConvOp):
         _lib.check(rc, 'kfn_conv2d_winograd_f43[%s]' % self.name)
 
 
+def pack_conv64_rows_kernel(w):
+    """TF HWIO [3,3,64,64] -> the A fragments of kfn_conv3x3_c64_f16 (csrc/kfn_conv64.hip): [2 channel halves][36][64 lanes][8]
+    halfs -- fragment f = (dy*3 + dx)*4 + c of lane l (row i = l % 32, k half hk = l // 32) holds
+    w[dy][dx][16c + 8hk + t][32 half + i], t = 0..7 (v_mfma_f32_32x32x16_f16 with the WEIGHTS as the A operand)."""
+    w = np.asarray(w, np.float32)
+    assert w.shape == (3, 3, 64, 64)
+    wt = w.reshape(3, 3, 4, 2, 8, 2, 32)               # [dy][dx][c][hk][t][half][i]
+    out = wt.transpose(5, 0, 1, 2, 3, 6, 4)            # [half][dy][dx][c][hk][i][t]
+    return np.ascontiguousarray(out.reshape(2, 36, 64, 8)).astype(np.float16)
+
+
+class Conv64RowsF16Op(ConvOp):
+    """3x3 stride-1 SAME conv 64 -> 64 on fp16 activations through kfn_conv3x3_c64_f16 (csrc/kfn_conv64.hip): weights
+    resident in registers, every input row read from LDS once for the three output rows it feeds -- SCoordNet's conv1b in
+    BASELINE config 5."""
+
+    def __init__(self, name, x, y, kernel, bias, relu):
+        ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu, operand_dtype=_lib.OPERAND_F16)
+
+    @staticmethod
+    def supported(x, y, cin, cout):
+        n, h, w, _ = x.shape
+        return (cin == 64 and cout == 64 and x.dtype == 'f16' and y.dtype == 'f16' and x.ld % 8 == 0 and y.ld % 8 == 0
+                and h * w * max(x.ld, y.ld) * 2 < (1 << 31))
+
+    def kernel_name(self, lib):
+        w = self.x.shape[2]
+        return 'conv64_rows_kernel<%d>' % (3 if -(-w // 192) * 192 <= -(-w // 128) * 128 else 2)
+
+    def mfma_flops(self):
+        """FLOPs the MFMAs execute: the strips' padded width, plus two halo-row steps per chunk of rows (not counted: the
+        chunk count is the launcher's choice) -- the nominal FLOPs scaled by the width padding."""
+        w = self.x.shape[2]
+        wp = min(-(-w // 192) * 192, -(-w // 128) * 128)
+        return self.flops() * wp / float(w)
+
+    def launch(self, lib, stream, phases=3):
+        d = self.desc()
+        rc = lib.kfn_conv3x3_c64_f16(C.byref(d), self.x.ptr, self.kernel.ptr,
+                                     self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        _lib.check(rc, 'kfn_conv3x3_c64_f16[%s]' % self.name)
+
+
 class WinogradS2ConvOp(ConvOp):
     """3x3 stride-2 SAME conv of an even-sized image through kfn_conv2d_winograd_s2 (polyphase + F(2,2):
     25 MFMA streams into 9 accumulators per 2x2 outputs instead of 36 direct taps)."""
@@ -1094,6 +1137,9 @@ class Graph(object):
         # conv_operands == 'f16' only: conv1a / upconv0 / conv6 inside the two window-resident launches on fp16 MFMAs
         # (kfn_oflow_head_f16, kfn_oflow_tail2_f16) like OFlowNet's other layers in that mode
         self.oflow_tail_f16 = True
+        # conv_operands == 'f16', fp16 activations in and out, 3x3 stride 1, 64 -> 64 channels (SCoordNet conv1b): the
+        # row-streaming kernel with register-resident weights (kfn_conv3x3_c64_f16) instead of the implicit GEMM
+        self.conv64_rows_f16 = True
         self.lds_bytes_per_cu = 160 * 1024   # gfx950; KFNetEngine overwrites it with kfn_device_info's answer before the
                                              # graph is built (the window-resident OFlowNet tail needs 136 000 B per workgroup)
         # Winograd F(2x2,3x3) for 3x3 stride-1 convs with at least this many in/out channels

@@ -578,6 +578,74 @@ def test_conv_fp16_activations(case, config, k_step):
     assert np.all(np.abs(y - ref) <= tol), float((np.abs(y - ref) - tol).max())
 
 
+C64_CASES = [
+    # N, H, W, ldx, ldy, x_off, y_off, relu, bias
+    (1, 16, 24, 64, 64, 0, 0, True, True),       # one 128-pixel strip, mostly padding
+    (2, 13, 200, 64, 64, 0, 0, True, True),      # two 128-pixel strips, ragged second one; odd height
+    (1, 9, 192, 64, 64, 0, 0, False, True),      # one full 192-pixel strip, no ReLU
+    (3, 5, 131, 72, 80, 8, 16, True, True),      # strided views in and out (ldx / ldy in elements), 3 images
+    (1, 1, 70, 64, 64, 0, 0, True, False),       # a single row: both vertical taps read zero rows; no bias
+    (2, 2, 385, 64, 64, 0, 0, True, True),       # 385 = 2 x 192 + 1: a strip with one live column
+    (1, 37, 960, 64, 64, 0, 0, True, True),      # BASELINE config 5's width: 5 strips of 192, several chunks of rows
+    (1, 67, 320, 64, 64, 0, 0, True, True),      # many chunks: the chunk seams (halo rows recomputed by the neighbour)
+]
+
+
+@pytest.mark.parametrize('case', C64_CASES)
+def test_conv3x3_c64_f16_vs_oracle(case):
+    """kfn_conv3x3_c64_f16 (csrc/kfn_conv64.hip: weights in registers, a workgroup walks down a pixel strip, every input row
+    feeds three output rows' accumulators) == an fp64 convolution of the fp16 input with the fp16-rounded weights, to the fp32
+    accumulation bound + half an fp16 ulp (the output is ONE RNE rounding of the fp32 result) -- the bar of
+    test_conv_fp16_activations; guard rows and the untouched channel columns keep their sentinels."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_conv64_rows_kernel
+    lib = _lib.load()
+    n, h, w, ldx, ldy, x_off, y_off, relu, with_bias = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.normal(size=(n, h, w, 64)).astype(np.float16)
+    wt = (rng.normal(size=(3, 3, 64, 64)) / np.sqrt(9 * 64)).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32) if with_bias else None
+    xb = np.full((n * h * w, ldx), 7.0, dtype=np.float16)
+    xb[:, x_off:x_off + 64] = x.reshape(-1, 64)
+    xd = dev(xb)
+    GUARD = 8
+    yd = torch.full((n * h * w + GUARD, ldy), -123.0, dtype=torch.float16, device='cuda')
+    wd_, bd = dev(pack_conv64_rows_kernel(wt)), (dev(b) if with_bias else None)
+    assert wd_.dtype == torch.float16 and tuple(wd_.shape) == (2, 36, 64, 8)
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=64, ldx=ldx, Cout=64, cout_pad=64, ldy=ldy, kh=3, kw=3, stride=1, relu=int(relu),
+                      operand_dtype=_lib.OPERAND_F16, x_dtype=_lib.ACT_F16, y_dtype=_lib.ACT_F16)
+    assert lib.kfn_conv3x3_c64_f16_supported(C.byref(d)) == 1
+    for _ in range(2):      # twice: a race between the row ring, the output tiles and the barrier would not repeat
+        _lib.check(lib.kfn_conv3x3_c64_f16(C.byref(d), xd.data_ptr() + 2 * x_off, wd_.data_ptr(),
+                                           bd.data_ptr() if bd is not None else None, yd.data_ptr() + 2 * y_off, stream()), 'c64')
+        sync()
+        yh = yd.cpu().numpy().astype(np.float32)
+        assert np.all(yh[n * h * w:] == -123.0)
+        mask = np.ones(ldy, dtype=bool)
+        mask[y_off:y_off + 64] = False
+        assert np.all(yh[:n * h * w][:, mask] == -123.0)
+        got = yh[:n * h * w, y_off:y_off + 64].reshape(n, h, w, 64)
+        ref = O.conv2d_same(x.astype(np.float64), wt.astype(np.float16).astype(np.float64), b, 1, relu)
+        tol = _conv_tol(x.astype(np.float32), wt) + np.abs(ref) * 2.0 ** -11 + 1e-7
+        assert np.all(np.abs(got - ref) <= tol), float((np.abs(got - ref) - tol).max())
+        yd.fill_(-123.0)
+
+
+def test_conv3x3_c64_f16_rejects_what_it_cannot_do():
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    ok = dict(N=1, H=8, W=8, Cin=64, ldx=64, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1, relu=1,
+              operand_dtype=_lib.OPERAND_F16, x_dtype=_lib.ACT_F16, y_dtype=_lib.ACT_F16)
+    assert lib.kfn_conv3x3_c64_f16_supported(C.byref(_lib.ConvDesc(**ok))) == 1
+    for bad in (dict(Cin=32, ldx=32), dict(Cout=128, cout_pad=128, ldy=128), dict(stride=2), dict(kh=1, kw=1), dict(x_dtype=0),
+                dict(y_dtype=0), dict(operand_dtype=0), dict(ldx=68), dict(ldy=66), dict(transposed=1), dict(epilogue=1)):
+        d = _lib.ConvDesc(**dict(ok, **bad))
+        assert lib.kfn_conv3x3_c64_f16_supported(C.byref(d)) == 0, bad
+        assert lib.kfn_conv3x3_c64_f16(C.byref(d), 16, 16, None, 16, None) == -3, bad      # KFN_ERR_UNSUPPORTED, before any launch
+
+
 @pytest.mark.parametrize('case', F16_ACT_CASES + [(2, 30, 40, 512, 512, 3, 1), (1, 17, 23, 256, 320, 3, 2),
                                                   (2, 68, 120, 1024, 512, 3, 1)])
 @pytest.mark.parametrize('config,path', [(2, 2), (9, 2), (2, 3), (9, 3), (12, 3)])
