@@ -53,7 +53,7 @@ __device__ __forceinline__ void sfor64(F&& f) {
   sfor64_impl<0, N>(f);
 }
 
-template <int PXB>
+template <int PXB, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
   constexpr int SW = 64 * PXB;
   constexpr int ROWB = (SW + 2) * PS;
@@ -90,11 +90,6 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
   f16x8 wr[36];
 #pragma unroll
   for (int f = 0; f < 36; ++f) wr[f] = p.w[(hc * 36 + f) * 64 + lane];
-  f32x4 bias4[4];      // element e = 4 g + i of an accumulator is channel 32 hc + 8 g + 4 h + i
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    bias4[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + 32 * hc + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool relu = p.relu != 0;
 
   // ---- this thread's pieces of an input row: piece = tid + 256 i -> (LDS pixel px = piece / 8, slot = piece % 8) ---------
   unsigned in_col[NI];       // byte offset inside an image row, or OOB (left / right of the image, past the row's pieces)
@@ -147,6 +142,13 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
     for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[s][pb][e] = 0.f;
+  // an output row's accumulators START from the bias (element e = 4 g + i is channel 32 hc + 8 g + 4 h + i): no bias adds later
+  f32x16 bias_c;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + 32 * hc + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias_c[4 * g] = b4.x; bias_c[4 * g + 1] = b4.y; bias_c[4 * g + 2] = b4.z; bias_c[4 * g + 3] = b4.w;
+  }
 
   // ---- prologue: input row r0 - 1 ---------------------------------------------------------------------------------------
   row_load(r0 - 1);
@@ -155,14 +157,31 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  int cur = 0, ob = 0;
-  // One step = input row ri.  Accumulator sets by phase ph = (ri - (r0 - 1)) % 3: `fresh` = output row ri + 1 (kernel row 0,
-  // starts from zero), `mid` = row ri (kernel row 1), `done` = row ri - 1 (kernel row 2; complete after this step).
+  int cur = 0;
+  // One step = input row ri, in ring[cur].  Accumulator sets by phase ph = (ri - (r0 - 1)) % 3: `fresh` = output row ri + 1
+  // (kernel row 0, starts from the bias), `mid` = row ri (kernel row 1), `done` = row ri - 1 (kernel row 2: pixel block pb of it
+  // is complete after fragment group 3 pb + 2).  One wave per SIMD: everything that is not an MFMA is placed into the MFMA
+  // stream a few instructions per gap (a v_mfma_f32_32x32x16_f16 covers ~5 issue slots):
+  //   groups 0 / 1      the output row finished in the PREVIOUS step leaves: out tile [cur ^ 1] -> registers -> global
+  //   groups 3pb+3, +4  the done row's pixel block pb: ReLU, one RNE rounding, 8-byte pieces into out tile [cur]
+  //   tail              the last pixel block's pieces, the next input row registers -> ring[cur ^ 1], the step's barrier
+  // No control flow inside: rows that must not be stored get an out-of-range store offset, loads past the chunk are harmless.
+  u32x4 ov[NO];
+  auto tile_piece = [&](auto donec, auto pbc, auto gc) __attribute__((always_inline)) {
+    constexpr int DONE = decltype(donec)::value, pb = decltype(pbc)::value, g = decltype(gc)::value;
+    f16x4 hv = {(_Float16)acc[DONE][pb][4 * g], (_Float16)acc[DONE][pb][4 * g + 1], (_Float16)acc[DONE][pb][4 * g + 2],
+                (_Float16)acc[DONE][pb][4 * g + 3]};   // RNE; max(round(v), 0) == round(max(v, 0))
+    if constexpr (RELU) hv = __builtin_elementwise_max(hv, f16x4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
+    *reinterpret_cast<f16x4*>(otile + cur * OUTB + o_base + 32 * pb * PS + 16 * g) = hv;
+  };
   auto step = [&](auto phc, int ri) __attribute__((always_inline)) {
     constexpr int ph = decltype(phc)::value;
     constexpr int FRESH = ph, MID = (ph + 2) % 3, DONE = (ph + 1) % 3;
-    if (ri < r1) row_load(ri + 1);            // (uniform) the next input row, under this row's MFMAs
+    row_load(ri + 1);                               // the next input row, under this row's MFMAs
     const char* const rb = ring + cur * ROWB;
+    const char* const prev_tile = otile + (cur ^ 1) * OUTB;
+    const bool prev_emit = ri - 2 >= r0;            // the row finished in the previous step (ri - 2) belongs to this chunk
+    const unsigned prev_soff = prev_emit ? (unsigned)(ri - 2) * row_bytes_y : 0u;
     f16x8 bf[2][4];
     auto frag_reads = [&](auto gc, f16x8 (&dst)[4]) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
@@ -177,72 +196,79 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
       constexpr int g = decltype(gc)::value;
       constexpr int pb = g / 3, dx = g % 3;
       if constexpr (g + 1 < NG) frag_reads(std::integral_constant<int, g + 1>{}, bf[(g + 1) & 1]);
+      if constexpr (g == 0) {
+#pragma unroll
+        for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(prev_tile + out_lds[i]);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const f16x8 b = bf[g & 1][c];
-        if constexpr (dx == 0) {
-          if (c == 0) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[FRESH][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(0 * 3 + dx) * 4 + c], b, zero, 0, 0, 0);
-          } else {
-            acc[FRESH][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(0 * 3 + dx) * 4 + c], b, acc[FRESH][pb], 0, 0, 0);
-          }
-        } else {
+        if (dx == 0 && c == 0)
+          acc[FRESH][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(0 * 3 + dx) * 4 + c], b, bias_c, 0, 0, 0);
+        else
           acc[FRESH][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(0 * 3 + dx) * 4 + c], b, acc[FRESH][pb], 0, 0, 0);
-        }
         acc[MID][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(1 * 3 + dx) * 4 + c], b, acc[MID][pb], 0, 0, 0);
         acc[DONE][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[(2 * 3 + dx) * 4 + c], b, acc[DONE][pb], 0, 0, 0);
+        // ---- the fillers of this gap ----
+        if constexpr (g == 1) {                     // the previous row's pieces leave (NO = 2 PXB <= 8 stores over 4 gaps)
+#pragma unroll
+          for (int i = c; i < NO; i += 4)
+            __builtin_amdgcn_raw_buffer_store_b128(ov[i], rsY, prev_emit ? out_col[i] : OOB, prev_soff, KFN_NT_STORE_AUX);
+        }
+        if constexpr (g >= 3 && (g - 3) % 3 < 2) {  // pixel block (g - 3) / 3 of the done row: pieces 2 * ((g - 3) % 3) + c / 2 ...
+          constexpr int epb = (g - 3) / 3;
+          if (c % 2 == 0) {
+            if constexpr ((g - 3) % 3 == 0) {
+              if (c == 0) tile_piece(std::integral_constant<int, DONE>{}, std::integral_constant<int, epb>{}, std::integral_constant<int, 0>{});
+              else tile_piece(std::integral_constant<int, DONE>{}, std::integral_constant<int, epb>{}, std::integral_constant<int, 1>{});
+            } else {
+              if (c == 0) tile_piece(std::integral_constant<int, DONE>{}, std::integral_constant<int, epb>{}, std::integral_constant<int, 2>{});
+              else tile_piece(std::integral_constant<int, DONE>{}, std::integral_constant<int, epb>{}, std::integral_constant<int, 3>{});
+            }
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    const int ro = ri - 1;                       // the finished output row
-    const bool emit = ro >= r0;                  // (uniform; ro < r1 always: ri <= r1)
-    if (emit) {
-      char* const ot = otile + ob * OUTB;
-#pragma unroll
-      for (int pb = 0; pb < PXB; ++pb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v = {acc[DONE][pb][4 * g], acc[DONE][pb][4 * g + 1], acc[DONE][pb][4 * g + 2], acc[DONE][pb][4 * g + 3]};
-          v += bias4[g];
-          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          const f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // RNE
-          *reinterpret_cast<f16x4*>(ot + o_base + 32 * pb * PS + 16 * g) = hv;
-        }
-    }
-    if (ri < r1) row_store(cur ^ 1);
+    // tail: the last pixel block of the done row, the next input row into the ring, the barrier
+    sfor64<4>([&](auto gc) {
+      tile_piece(std::integral_constant<int, DONE>{}, std::integral_constant<int, PXB - 1>{}, gc);
+    });
+    row_store(cur ^ 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS stores are done before the barrier releases the readers
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (emit) {
-      const char* const ot = otile + ob * OUTB;
-      const unsigned soff = (unsigned)ro * row_bytes_y;
-#pragma unroll
-      for (int i = 0; i < NO; ++i) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ot + out_lds[i]);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsY, out_col[i], soff, KFN_NT_STORE_AUX);
-      }
-      ob ^= 1;
-    }
     cur ^= 1;
   };
 
+  int last = r0 - 1;
   for (int ri = r0 - 1; ri <= r1; ri += 3) {
     step(std::integral_constant<int, 0>{}, ri);
-    if (ri + 1 <= r1) step(std::integral_constant<int, 1>{}, ri + 1);
-    if (ri + 2 <= r1) step(std::integral_constant<int, 2>{}, ri + 2);
+    last = ri;
+    if (ri + 1 <= r1) { step(std::integral_constant<int, 1>{}, ri + 1); last = ri + 1; }
+    if (ri + 2 <= r1) { step(std::integral_constant<int, 2>{}, ri + 2); last = ri + 2; }
+  }
+  // the row finished by the last step (r1 - 1, in out tile [cur ^ 1] after the flip) leaves
+  {
+    const char* const prev_tile = otile + (cur ^ 1) * OUTB;
+    const unsigned soff = (unsigned)(last - 1) * row_bytes_y;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(prev_tile + out_lds[i]);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (last - 1 >= r0) ? out_col[i] : OOB, soff, KFN_NT_STORE_AUX);
+    }
   }
 }
 
-template <int PXB>
+template <int PXB, bool RELU>
 int launch64(const C64Args& a, int grid, hipStream_t stream) {
   constexpr int SW = 64 * PXB;
   constexpr int LDS = 2 * (SW + 2) * PS + 2 * SW * PS;
   static std::atomic<uint64_t> attr_done{0};
-  int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(conv64_rows_kernel<PXB>), LDS, attr_done);
+  int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(conv64_rows_kernel<PXB, RELU>), LDS, attr_done);
   if (rc != KFN_OK) return rc;
-  hipLaunchKernelGGL(conv64_rows_kernel<PXB>, dim3(grid), dim3(256), LDS, stream, a);
+  hipLaunchKernelGGL((conv64_rows_kernel<PXB, RELU>), dim3(grid), dim3(256), LDS, stream, a);
   KFN_LAUNCH_CHECK("conv64_rows_kernel");
   return KFN_OK;
 }
@@ -306,5 +332,7 @@ extern "C" int kfn_conv3x3_c64_f16(const kfn_conv_desc* d, const void* x, const 
   a.chunks = kfn::ceil_div(d->H, a.rows_per_chunk);
   const long grid = strips_total * a.chunks;
   KFN_REQUIRE(grid < (1L << 31), "kfn_conv3x3_c64_f16: grid too large");
-  return pxb == 3 ? launch64<3>(a, (int)grid, (hipStream_t)stream) : launch64<2>(a, (int)grid, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (pxb == 3) return a.relu ? launch64<3, true>(a, (int)grid, st) : launch64<3, false>(a, (int)grid, st);
+  return a.relu ? launch64<2, true>(a, (int)grid, st) : launch64<2, false>(a, (int)grid, st);
 }

@@ -613,7 +613,7 @@ class Conv64RowsF16Op(ConvOp):
 
     def kernel_name(self, lib):
         w = self.x.shape[2]
-        return 'conv64_rows_kernel<%d>' % (3 if -(-w // 192) * 192 <= -(-w // 128) * 128 else 2)
+        return 'conv64_rows_kernel<%d, %s>' % (3 if -(-w // 192) * 192 <= -(-w // 128) * 128 else 2, 'true' if self.relu else 'false')
 
     def mfma_flops(self):
         """FLOPs the MFMAs execute: the strips' padded width, plus two halo-row steps per chunk of rows (not counted: the
