@@ -76,6 +76,18 @@ constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions
 #ifndef KFN_W4_TSLOT
 #define KFN_W4_TSLOT (-1)
 #endif
+// The transform as 12 one-dimensional passes of 2 x 6 packed instructions, each half in its own MFMA gap (1), instead of one
+// burst of 144 at XSLOT (0): row pass r (patch row r: its six loads went out at slots 12 r .. 12 r + 10) in slots RS0 + 8 r
+// and + 1, column pass c in slots CS0 + 6 c and + 1, its six V stores (positions 6 xi + c) in the six slots after it.
+// MEASURED (profiles/r04_wino4_microbench.log, r4t): no gain -- conv2b 6.99 -> 7.11 ms, conv3b 6.41 -> 6.48, conv4b 6.26 ->
+// 6.16, conv5 / conv1b equal: a packed fp32 instruction costs the MFMA stream the same wherever it stands.  OFF.
+#ifndef KFN_W4_XDIST
+#define KFN_W4_XDIST 0
+#define KFN_W4_RS0 60
+#define KFN_W4_CS0 102
+#endif
+static_assert(!KFN_W4_XDIST || (KFN_W4_RS0 + 8 * 5 + 1 < KFN_W4_CS0 && KFN_W4_CS0 + 6 * 5 + 2 + 6 <= 144 && KFN_W4_RS0 >= 12 * 0 + 10),
+              "distributed transform schedule");
 // ... and in how many pieces each of the three touch loads is issued (1, 2 or 4: 64 / 32 / 16 live lanes per piece), one
 // piece every KFN_W4_TSTEP slots: spreads the misses over the super-step
 #ifndef KFN_W4_TPIECES
@@ -183,6 +195,28 @@ __device__ __forceinline__ void bt6(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, 
   d2 = pk_sub4(a, b);
   d3 = pk_fma4(e, k.p2, c);
   d4 = pk_fma4(e, k.m2, c);
+}
+// the same pass in two halves of six instructions (the temporaries live across one MFMA slot)
+struct BtTmp {
+  f32x2 a, b, c, e, u, v;
+};
+__device__ __forceinline__ void bt6_a(const f32x2& d1, const f32x2& d2, const f32x2& d3, const f32x2& d4, const f32x2& d5,
+                                      const BtConst& k, BtTmp& t) {
+  t.a = pk_fma4(d2, k.m4, d4);
+  t.b = pk_fma4(d1, k.m4, d3);
+  t.c = pk_sub4(d4, d2);
+  t.e = pk_sub4(d3, d1);
+  t.u = pk_fma4(d2, k.m5, d4);
+  t.v = pk_fma4(d3, k.m5, d5);
+}
+__device__ __forceinline__ void bt6_b(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5, const BtConst& k,
+                                      const BtTmp& t) {
+  d0 = pk_fma4(d0, k.p4, t.u);
+  d5 = pk_fma4(d1, k.p4, t.v);
+  d1 = pk_add4(t.a, t.b);
+  d2 = pk_sub4(t.a, t.b);
+  d3 = pk_fma4(t.e, k.p2, t.c);
+  d4 = pk_fma4(t.e, k.m2, t.c);
 }
 __device__ __forceinline__ void bt_d_b6(f32x2 (&v)[36], const BtConst& k) {   // v[6 r + c] -> v[6 xi + nu]
 #pragma unroll
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
   f32x4 bq[NB];        // B ring
   f32x4 vq[NVR];       // V fragment ring
   BtConst kc;
+  BtTmp bt_tmp;        // (distributed transform: the six temporaries of a pass between its two slots)
   kc.p4 = f32x2{4.f, 4.f}; kc.m4 = f32x2{-4.f, -4.f}; kc.m5 = f32x2{-5.f, -5.f}; kc.p2 = f32x2{2.f, 2.f}; kc.m2 = f32x2{-2.f, -2.f};
 
   auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
@@ -396,9 +431,29 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
         if constexpr (KFN_W4_TSLOT >= 0 && sj >= KFN_W4_TSLOT && sj < KFN_W4_TSLOT + 3 * KFN_W4_TPIECES * KFN_W4_TSTEP &&
                       (sj - KFN_W4_TSLOT) % KFN_W4_TSTEP == 0)
           touch(std::integral_constant<int, (sj >= KFN_W4_TSLOT) ? (sj - KFN_W4_TSLOT) / KFN_W4_TSTEP : 0>{}, ks + 2);
-        if constexpr (!(KFN_W4_DBG & 1) && sj == KFN_W4_XSLOT) bt_d_b6(pv, kc);
-        if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_SSLOT && sj < KFN_W4_SSLOT + 36)
-          p_store(std::integral_constant<int, sj - KFN_W4_SSLOT>{}, ks + 1);
+        if constexpr (KFN_W4_XDIST) {
+          if constexpr (!(KFN_W4_DBG & 1)) {
+            constexpr int rr = (sj - KFN_W4_RS0) / 8, rh = (sj - KFN_W4_RS0) % 8;
+            if constexpr (sj >= KFN_W4_RS0 && rr < 6 && rh == 0)
+              bt6_a(pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+            if constexpr (sj >= KFN_W4_RS0 && rr < 6 && rh == 1)
+              bt6_b(pv[6 * rr], pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+            constexpr int cc6 = (sj - KFN_W4_CS0) / 6, ch6 = (sj - KFN_W4_CS0) % 6;
+            if constexpr (sj >= KFN_W4_CS0 && cc6 < 6 && ch6 == 0)
+              bt6_a(pv[6 + cc6], pv[12 + cc6], pv[18 + cc6], pv[24 + cc6], pv[30 + cc6], kc, bt_tmp);
+            if constexpr (sj >= KFN_W4_CS0 && cc6 < 6 && ch6 == 1)
+              bt6_b(pv[cc6], pv[6 + cc6], pv[12 + cc6], pv[18 + cc6], pv[24 + cc6], pv[30 + cc6], kc, bt_tmp);
+          }
+          // store k = 6 nu + xi (position 6 xi + nu) in slot CS0 + 2 + k: the six of column pass nu right behind it
+          if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_CS0 + 2 && sj < KFN_W4_CS0 + 2 + 36) {
+            constexpr int k = sj - (KFN_W4_CS0 + 2);
+            p_store(std::integral_constant<int, 6 * (k % 6) + k / 6>{}, ks + 1);
+          }
+        } else {
+          if constexpr (!(KFN_W4_DBG & 1) && sj == KFN_W4_XSLOT) bt_d_b6(pv, kc);
+          if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_SSLOT && sj < KFN_W4_SSLOT + 36)
+            p_store(std::integral_constant<int, sj - KFN_W4_SSLOT>{}, ks + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
     });
