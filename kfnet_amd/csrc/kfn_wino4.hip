@@ -80,14 +80,17 @@ constexpr int SPC = 72;                    // MFMA slots per chunk: 18 positions
 // burst of 144 at XSLOT (0): row pass r (patch row r: its six loads went out at slots 12 r .. 12 r + 10) in slots RS0 + 8 r
 // and + 1, column pass c in slots CS0 + 6 c and + 1, its six V stores (positions 6 xi + c) in the six slots after it.
 // MEASURED (profiles/r04_wino4_microbench.log, r4t): no gain -- conv2b 6.99 -> 7.11 ms, conv3b 6.41 -> 6.48, conv4b 6.26 ->
-// 6.16, conv5 / conv1b equal: a packed fp32 instruction costs the MFMA stream the same wherever it stands.  OFF.
+// 6.16, conv5 / conv1b equal: a packed fp32 instruction costs the MFMA stream the same wherever it stands.  XDIST = 2 (the
+// same in 48 quarters of six PLAIN v_fma / v_add / v_sub, -DKFN_W4_RS0=62 -DKFN_W4_CS0=106): 7.57 / 7.02 / 6.72 ms, worse.  OFF.
 #ifndef KFN_W4_XDIST
 #define KFN_W4_XDIST 0
 #define KFN_W4_RS0 60
 #define KFN_W4_CS0 102
 #endif
-static_assert(!KFN_W4_XDIST || (KFN_W4_RS0 + 8 * 5 + 1 < KFN_W4_CS0 && KFN_W4_CS0 + 6 * 5 + 2 + 6 <= 144 && KFN_W4_RS0 >= 12 * 0 + 10),
+static_assert(KFN_W4_XDIST != 1 || (KFN_W4_RS0 + 8 * 5 + 1 < KFN_W4_CS0 && KFN_W4_CS0 + 6 * 5 + 2 + 6 <= 144 && KFN_W4_RS0 >= 12 * 0 + 10),
               "distributed transform schedule");
+static_assert(KFN_W4_XDIST != 2 || (KFN_W4_RS0 + 8 * 5 + 3 < KFN_W4_CS0 && KFN_W4_CS0 + 4 * 5 + 4 + 6 <= 144 && KFN_W4_RS0 >= 10),
+              "distributed plain-instruction transform schedule");
 // ... and in how many pieces each of the three touch loads is issued (1, 2 or 4: 64 / 32 / 16 live lanes per piece), one
 // piece every KFN_W4_TSTEP slots: spreads the misses over the super-step
 #ifndef KFN_W4_TPIECES
@@ -217,6 +220,43 @@ __device__ __forceinline__ void bt6_b(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3
   d2 = pk_sub4(t.a, t.b);
   d3 = pk_fma4(t.e, k.p2, t.c);
   d4 = pk_fma4(t.e, k.m2, t.c);
+}
+// ... and in four quarters of six PLAIN fp32 instructions (component Z = 0 | 1 of every pair; inline asm so that the
+// compiler does not re-pack them): KFN_W4_XDIST == 2
+__device__ __forceinline__ float pl_fma(float a, float k, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float pl_add(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float pl_sub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int Z>
+__device__ __forceinline__ void bt6_qa(const f32x2& d1, const f32x2& d2, const f32x2& d3, const f32x2& d4, const f32x2& d5,
+                                       const BtConst& k, BtTmp& t) {
+  t.a[Z] = pl_fma(d2[Z], k.m4.x, d4[Z]);
+  t.b[Z] = pl_fma(d1[Z], k.m4.x, d3[Z]);
+  t.c[Z] = pl_sub(d4[Z], d2[Z]);
+  t.e[Z] = pl_sub(d3[Z], d1[Z]);
+  t.u[Z] = pl_fma(d2[Z], k.m5.x, d4[Z]);
+  t.v[Z] = pl_fma(d3[Z], k.m5.x, d5[Z]);
+}
+template <int Z>
+__device__ __forceinline__ void bt6_qb(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5, const BtConst& k,
+                                       const BtTmp& t) {
+  d0[Z] = pl_fma(d0[Z], k.p4.x, t.u[Z]);
+  d5[Z] = pl_fma(d1[Z], k.p4.x, t.v[Z]);
+  d1[Z] = pl_add(t.a[Z], t.b[Z]);
+  d2[Z] = pl_sub(t.a[Z], t.b[Z]);
+  d3[Z] = pl_fma(t.e[Z], k.p2.x, t.c[Z]);
+  d4[Z] = pl_fma(t.e[Z], k.m2.x, t.c[Z]);
 }
 __device__ __forceinline__ void bt_d_b6(f32x2 (&v)[36], const BtConst& k) {   // v[6 r + c] -> v[6 xi + nu]
 #pragma unroll
@@ -431,7 +471,34 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
         if constexpr (KFN_W4_TSLOT >= 0 && sj >= KFN_W4_TSLOT && sj < KFN_W4_TSLOT + 3 * KFN_W4_TPIECES * KFN_W4_TSTEP &&
                       (sj - KFN_W4_TSLOT) % KFN_W4_TSTEP == 0)
           touch(std::integral_constant<int, (sj >= KFN_W4_TSLOT) ? (sj - KFN_W4_TSLOT) / KFN_W4_TSTEP : 0>{}, ks + 2);
-        if constexpr (KFN_W4_XDIST) {
+        if constexpr (KFN_W4_XDIST == 2) {
+          // quarters: row pass r in slots RS0 + 8 r + q, column pass c in slots CS0 + 4 c + q, q = 0..3 = (half a, Z 0), (half a, Z 1),
+          // (half b, Z 0), (half b, Z 1); the six stores of column c in the six slots behind its pass
+          if constexpr (!(KFN_W4_DBG & 1)) {
+            constexpr int rr = (sj - KFN_W4_RS0) / 8, rq = (sj - KFN_W4_RS0) % 8;
+            if constexpr (sj >= KFN_W4_RS0 && rr < 6 && rq < 4) {
+              if constexpr (rq == 0) bt6_qa<0>(pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+              if constexpr (rq == 1) bt6_qa<1>(pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+              if constexpr (rq == 2) bt6_qb<0>(pv[6 * rr], pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+              if constexpr (rq == 3) bt6_qb<1>(pv[6 * rr], pv[6 * rr + 1], pv[6 * rr + 2], pv[6 * rr + 3], pv[6 * rr + 4], pv[6 * rr + 5], kc, bt_tmp);
+            }
+            constexpr int c4 = (sj - KFN_W4_CS0) / 4, cq = (sj - KFN_W4_CS0) % 4;
+            if constexpr (sj >= KFN_W4_CS0 && c4 < 6) {
+              if constexpr (cq == 0) bt6_qa<0>(pv[6 + c4], pv[12 + c4], pv[18 + c4], pv[24 + c4], pv[30 + c4], kc, bt_tmp);
+              if constexpr (cq == 1) bt6_qa<1>(pv[6 + c4], pv[12 + c4], pv[18 + c4], pv[24 + c4], pv[30 + c4], kc, bt_tmp);
+              if constexpr (cq == 2) bt6_qb<0>(pv[c4], pv[6 + c4], pv[12 + c4], pv[18 + c4], pv[24 + c4], pv[30 + c4], kc, bt_tmp);
+              if constexpr (cq == 3) bt6_qb<1>(pv[c4], pv[6 + c4], pv[12 + c4], pv[18 + c4], pv[24 + c4], pv[30 + c4], kc, bt_tmp);
+            }
+          }
+          if constexpr (!(KFN_W4_DBG & 4) && sj >= KFN_W4_CS0 + 4) {
+            // store k of column nu = k / 6 (position 6 (k % 6) + nu) in slot CS0 + 4 nu + 4 + (k % 6)
+            sfor4<6>([&](auto nuc) {
+              constexpr int nu = decltype(nuc)::value;
+              constexpr int xi = sj - (KFN_W4_CS0 + 4 * nu + 4);
+              if constexpr (xi >= 0 && xi < 6) p_store(std::integral_constant<int, 6 * xi + nu>{}, ks + 1);
+            });
+          }
+        } else if constexpr (KFN_W4_XDIST == 1) {
           if constexpr (!(KFN_W4_DBG & 1)) {
             constexpr int rr = (sj - KFN_W4_RS0) / 8, rh = (sj - KFN_W4_RS0) % 8;
             if constexpr (sj >= KFN_W4_RS0 && rr < 6 && rh == 0)
