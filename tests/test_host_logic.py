@@ -215,6 +215,80 @@ def test_round3_weight_layouts_follow_their_documented_index_formulas():
     assert np.all(u2[:, :, 24:, :] == 0)
 
 
+def test_round4_fp16_weight_layouts_follow_their_documented_index_formulas():
+    """The half-precision operand layouts of config 5's own kernels (round 4), element by element against the index
+    expressions of their docstrings: kfn_conv3x3_c64_f16's A fragments and the 16x16x16 B fragments of the window-resident
+    OFlowNet kernels; a CPU emulation of the conv64 kernel's MFMA bookkeeping (weights as A, pixels as B, three kernel rows
+    on three accumulator sets) reproduces the oracle's convolution."""
+    from kfnet_amd.graph import (pack_conv64_rows_kernel, pack_oflow_head_kernel_f16, pack_oflow_tail_kernel_f16,
+                                 pack_oflow_upconv_kernel_f16)
+    rng = np.random.default_rng(12)
+    w = rng.normal(size=(3, 3, 64, 64)).astype(np.float32)
+    a = pack_conv64_rows_kernel(w)
+    assert a.shape == (2, 36, 64, 8) and a.dtype == np.float16
+    for (half, dy, dx, c, lane, t) in [(0, 0, 0, 0, 0, 0), (1, 2, 1, 3, 63, 7), (0, 1, 2, 2, 37, 5), (1, 0, 2, 1, 31, 0)]:
+        i, hk = lane % 32, lane // 32
+        assert a[half, (dy * 3 + dx) * 4 + c, lane, t] == np.float16(w[dy, dx, 16 * c + 8 * hk + t, 32 * half + i])
+    # emulate the kernel's arithmetic on one 3-row, 32-pixel patch: D[ch][px] += A[ch][k] B[k][px] per (dy, dx, c)
+    x = rng.normal(size=(3, 34, 64)).astype(np.float16).astype(np.float64)      # input rows r-1, r, r+1; pixels -1 .. 32
+    af = a.astype(np.float64)
+    out = np.zeros((64, 32))
+    for half in range(2):
+        for dy in range(3):
+            for dx in range(3):
+                for c in range(4):
+                    frag = af[half, (dy * 3 + dx) * 4 + c]                       # [lane][t] -> A[i][k = 8 hk + t]
+                    A = np.zeros((32, 16))
+                    for lane in range(64):
+                        A[lane % 32, 8 * (lane // 32):8 * (lane // 32) + 8] = frag[lane]
+                    B = x[dy, dx:dx + 32, 16 * c:16 * c + 16].T                  # [k][px]: pixel j + dx of the LDS row
+                    out[32 * half:32 * half + 32] += A @ B
+    ref = np.einsum('yxc,yxco->o', x[:, 0:3], w.astype(np.float16).astype(np.float64))   # pixel 0 of the output row
+    assert np.allclose(out[:, 0], ref, rtol=1e-12, atol=1e-12)
+    ref31 = np.einsum('yxc,yxco->o', x[:, 31:34], w.astype(np.float16).astype(np.float64))
+    assert np.allclose(out[:, 31], ref31, rtol=1e-12, atol=1e-12)
+    # oflow_head_f16: fragment t = (tap*2 + s)*2 + nb of lane (kq, n), half j = w[tap][kq*8 + 4s + j][nb*16 + n]
+    w1 = rng.normal(size=(3, 3, 32, 32)).astype(np.float32)
+    h = pack_oflow_head_kernel_f16(w1)
+    assert h.shape == (36, 64, 4) and h.dtype == np.float16
+    for (tap, s_, nb, kq, n, j) in [(0, 0, 0, 0, 0, 0), (8, 1, 1, 3, 15, 3), (4, 0, 1, 2, 7, 2)]:
+        assert h[(tap * 2 + s_) * 2 + nb, kq * 16 + n, j] == np.float16(w1[tap // 3, tap % 3, kq * 8 + 4 * s_ + j, nb * 16 + n])
+    # oflow_tail2_f16 upconv0: fragment t = tap*2 + s, half j = w[tap][n][kq*8 + 4s + j]
+    wu = rng.normal(size=(3, 3, 16, 32)).astype(np.float32)
+    u = pack_oflow_upconv_kernel_f16(wu)
+    assert u.shape == (18, 64, 4)
+    for (tap, s_, kq, n, j) in [(0, 0, 0, 0, 0), (8, 1, 3, 15, 3), (5, 1, 1, 9, 2)]:
+        assert u[tap * 2 + s_, kq * 16 + n, j] == np.float16(wu[tap // 3, tap % 3, n, kq * 8 + 4 * s_ + j])
+    # oflow_tail2_f16 conv6: fragment t = tap*3 + s, half j = w[tap][kq*12 + 4s + j][n]
+    w6 = rng.normal(size=(3, 3, 48, 16)).astype(np.float32)
+    t6 = pack_oflow_tail_kernel_f16(w6)
+    assert t6.shape == (27, 64, 4)
+    for (tap, s_, kq, n, j) in [(0, 0, 0, 0, 0), (8, 2, 3, 15, 3), (3, 1, 2, 8, 1)]:
+        assert t6[tap * 3 + s_, kq * 16 + n, j] == np.float16(w6[tap // 3, tap % 3, kq * 12 + 4 * s_ + j, n])
+
+
+def test_config5_graph_routes_conv1b_and_the_window_kernels_to_their_fp16_forms():
+    """conv_operands = 'f16' (BASELINE config 5): SCoordNet's conv1b goes to kfn_conv3x3_c64_f16, the two window-resident
+    OFlowNet launches to their _f16 entry points with half-precision packers; the fp32 graph keeps the fp32 forms; every
+    switch turns its route off."""
+    g, net = _build(B=2, H=540, W=960, conv_operands='f16')
+    by = {}
+    for op in g.ops:
+        by.setdefault(op.name, op)
+    assert type(by['conv1b']).__name__ == 'Conv64RowsF16Op' and by['conv1b'].kernel.pack.__name__ == 'pack_conv64_rows_kernel'
+    assert by['conv1b'].kernel_name(_lib.load()) == 'conv64_rows_kernel<3, true>'          # 960 = 5 x 192
+    head = [op for op in g.ops if op.name.startswith('oflow_head')][0]
+    tail = [op for op in g.ops if op.name.startswith('oflow_tail2')][0]
+    assert head.operands_f16 and head.k1.pack.__name__ == 'pack_oflow_head_kernel_f16'
+    assert tail.operands_f16 and tail.ku.pack.__name__ == 'pack_oflow_upconv_kernel_f16' and tail.k6.pack.__name__ == 'pack_oflow_tail_kernel_f16'
+    g32, _ = _build(B=2, H=540, W=960)
+    assert all(type(op).__name__ != 'Conv64RowsF16Op' and not getattr(op, 'operands_f16', False) for op in g32.ops)
+    goff, _ = _build(B=2, H=540, W=960, conv_operands='f16', conv64_rows_f16=False, oflow_tail_f16=False)
+    assert all(type(op).__name__ != 'Conv64RowsF16Op' and not getattr(op, 'operands_f16', False) for op in goff.ops)
+    d = by['conv1b'].desc()
+    assert _lib.load().kfn_conv3x3_c64_f16_supported(ctypes.byref(d)) == 1                # host code: no GPU needed
+
+
 def test_variable_scope_names():
     g = Graph()
     with variable_scope('A'):
