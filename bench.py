@@ -751,7 +751,8 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
         k = by_kernel.setdefault(r[1], [0, 0.0, 0.0, 0.0])
         k[0] += 1; k[1] += r[2]; k[2] += r[3]; k[3] += r[4]
     heavy_ms = sum(r[3] for r in rows)
-    is16 = lambda name: name.endswith('<true>') or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7', '8'))
+    is16 = lambda name: (name.endswith('<true>') or name.startswith('conv64_rows_kernel')
+                         or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7', '8')))
     k16 = {k: v for k, v in by_kernel.items() if is16(k)}
     dom = max(k16, key=lambda k: k16[k][2])
     n_dom, fl_dom, ms_dom, ex_dom = k16[dom]
@@ -760,8 +761,8 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
     out = {'metric': 'frames/sec on 960x540 seq', 'value': round(S * T / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
            'steps': S * T, 'warmup': S * T, 'ms_per_step': round(med * 1e3 / (S * T), 4), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f16 conv operands (f32 accumulate), f16 activations in SCoordNet, f32 first-layer arithmetic / OFlowNet '
-                    'window kernels / Kalman',
+           'dtype': 'f16 conv operands (f32 accumulate) incl. the convolutions inside the window-resident OFlowNet kernels, f16 '
+                    'activations in SCoordNet, f32 first-layer arithmetic / cost-volume subtraction / softmax / Kalman',
            'data': 'synthetic (rolled random texture uint8 frames, seeded random weights)',
            'repetitions': len(times), 'gpu_telemetry': tele.summary(),
            'config': {'workload': 'BASELINE configs[4]: %d sequences x %d frames of %dx%d (grid 68x120), fp16 convs + '
@@ -781,11 +782,15 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
                                 'tile going global -> LDS directly (buffer_load ... lds), PREC 8 = both operand tiles that way (the '
                                 'eight-wave 256x256 tile <4,2,2,4,...>), PREC 4 = fp16 in / fp32 out, PREC 1 = '
                                 'fp16 operands rounded while staging fp32 activations (OFlowNet, feature tower); '
+                                'conv64_rows_kernel = the 64 -> 64 layer with register-resident weights (kfn_conv3x3_c64_f16); '
+                                'oflow_*_kernel<true> = the window-resident OFlowNet launches with their convolutions on '
+                                'v_mfma_f32_16x16x16_f16; '
                                 'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
                                 'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},
            'kernels_ms_per_batch': {k: {'launches': v[0], 'ms': round(v[2], 4),
                                         'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[1] else None}
                                     for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])[:8]},
+           'per_layer_ms_per_batch': {'%s#%d' % (r[0], i): round(r[3], 4) for i, r in enumerate(rows)},
            'tolerance': 'own tolerance (tests/test_gpu_e2e.py::test_config5_tolerance_at_bench_scale): coord max-abs <= 2e-2, '
                         'confidence max-rel <= 5e-2 on every pixel away from the steps of the reference sampler; see '
                         'parity_vs_fp32_path'}

@@ -971,7 +971,7 @@ class OFlowHeadOp(Op):
         self.operands_f16 = operands_f16      # k1 packed by pack_oflow_head_kernel_f16 -> kfn_oflow_head_f16 (config 5)
 
     def kernel_name(self, lib):
-        return 'oflow_head_kernel'
+        return 'oflow_head_kernel<%s>' % ('true' if self.operands_f16 else 'false')
 
     def flops(self):
         """Nominal FLOPs of the two layers this launch completes: conv0 on every window cell + conv1a."""
@@ -1003,7 +1003,7 @@ class OFlowTail2Op(Op):
         self.ku, self.bu, self.k6, self.b6, self.kp, self.bpred, self.flow, self.logits = ku, bu, k6, b6, kp, bpred, flow, logits
 
     def kernel_name(self, lib):
-        return 'oflow_tail2_kernel'
+        return 'oflow_tail2_kernel<%s>' % ('true' if self.operands_f16 else 'false')
 
     def flops(self):
         """Nominal (dense, 9-tap) FLOPs of upconv0 (counted per INPUT cell like every transposed conv),
