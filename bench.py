@@ -94,6 +94,9 @@ def parse():
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
                     help="f16 = BASELINE config 5's fp16-operand convs (fp32 accumulate, fp32 Kalman); NOT the headline")
+    ap.add_argument('--graph-option', action='append', default=[], metavar='NAME=VALUE',
+                    help='a routing switch of kfnet_amd.graph.Graph for an A/B run of the main engine, e.g. '
+                         'winograd_f43_eight_wave=0 (recorded in the line as graph_options)')
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
     return ap.parse_args()
@@ -943,9 +946,13 @@ def main():
     lo = rank * K
     need_prev = 1 if needs_state(lo, 500) else 0
     frames_all = synthetic_sequence(K + need_prev, args.height, args.width, seed=1, start=lo - need_prev)
+    gopts = {}
+    for kv in args.graph_option:
+        name, _, val = kv.partition('=')
+        gopts[name] = int(val) if val.lstrip('-').isdigit() else val
     eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=B, transform=T4, reset_period=500,
                       max_chunk=max(K, Wm, B), device=str(device), autotune=args.autotune,
-                      conv_operands=args.conv_operands, use_graph=args.graph)
+                      conv_operands=args.conv_operands, use_graph=args.graph, graph_options=gopts or None)
     eng.two_streams = not args.one_stream
     dev_all = eng.upload_frames(frames_all)
     dev_prev = dev_all[0] if need_prev else None
@@ -1001,6 +1008,7 @@ def main():
                                      '' if ndev >= world else
                                      ' -- FUNCTIONAL FALLBACK: only %d GPU(s) visible, ranks share them and the state '
                                      'goes through the host (gloo); not an xGMI number' % ndev)},
+        'graph_options': gopts or None,
         'state_link': link.name if link is not None else None,
         'dist_backend': backend,
         'devices_visible': ndev,

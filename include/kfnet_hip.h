@@ -99,7 +99,7 @@ typedef struct kfn_conv_desc {
                           * Activations and outputs stay fp32 in memory unless x_dtype / y_dtype say
                           * otherwise. */
   int32_t wino_order;    /* Winograd kernels only: workgroup order, KFN_WINO_ORDER_* (0 = the kernel's default) */
-  int32_t wino_form;     /* kfn_conv2d_winograd_fused only: KFN_WINO_FORM_* (0 = auto) */
+  int32_t wino_form;     /* kfn_conv2d_winograd_fused / _f43: KFN_WINO_FORM_* (0 = auto) */
   int32_t x_dtype;       /* KFN_ACT_F32 / KFN_ACT_F16: element type of the input activations in memory */
   int32_t y_dtype;       /* ... of the output activations.  KFN_ACT_F16 needs operand_dtype == KFN_OPERAND_F16
                           * (BASELINE config 5: fp16 activations end to end); ldx / ldy count ELEMENTS. */
@@ -131,6 +131,8 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_ORDER_GROUPS(n) (16 + (n)) /* kfn_conv2d_winograd_f43 / _s2: n channel groups (of 64 / 128) of a tile block adjacent */
 #define KFN_WINO_FORM_AUTO 0
 #define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel / wino3_pair_kernel would run */
+#define KFN_WINO_FORM_F43_FOUR_WAVE 2  /* kfn_conv2d_winograd_f43: wino4_kernel (four waves, 32x32x2 MFMA tiles) */
+#define KFN_WINO_FORM_F43_EIGHT_WAVE 3 /* kfn_conv2d_winograd_f43: wino4b_kernel (eight waves, 16x16x4 MFMA tiles) */
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1
@@ -244,6 +246,12 @@ int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void
  * from kfn_conv2d_nhwc by ~3x the F(2x2,3x3) round-off (1.4e-6 on the network's coordinates, tools/experiments/
  * f43_error_budget.py).  u4_packed = [Cin/8][36][cout_pad][8]: U[6 xi + nu] = (G g G^T)[xi][nu] in fp64, rounded once,
  * u4[((ci/8)*36 + 6*xi+nu)*cout_pad + co][ci%8] (kfnet_amd.graph.pack_winograd_f43_kernel).
+ * Two kernels behind the entry point, chosen by kfn_conv_desc.wino_form, and the weight layout goes with the choice:
+ *   KFN_WINO_FORM_AUTO / KFN_WINO_FORM_F43_FOUR_WAVE: wino4_kernel, four waves on 32x32x2 MFMA tiles, the layout above;
+ *   KFN_WINO_FORM_F43_EIGHT_WAVE: wino4b_kernel, two waves per SIMD on 16x16x4 tiles (3-13 % faster: what the default graph
+ *     launches), u4_packed = [Cin/8][18 position pairs][cout_pad][4 k][2 positions][2 k-steps]:
+ *     u4b[((ci/8)*18 + p/2)*cout_pad + co][4*((ci%8)/2) + 2*(p%2) + ci%2], p = 6*xi+nu
+ *     (kfnet_amd.graph.pack_winograd_f43_kernel_b) -- same U, same size, a lane's operands of two positions contiguous.
  * Needs Cin % 16 == 0, H >= 29, Cout % 4 == 0, ldy % 4 == 0, ldx % 2 == 0, y 16-byte aligned, two images of the input
  * below 1 GiB, fp32 operands and activations, no fused head epilogue (kfn_winograd_f43_supported() == 1);
  * KFN_ERR_UNSUPPORTED otherwise. */

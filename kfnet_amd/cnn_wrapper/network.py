@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _lib
 from ..graph import (Conv64RowsF16Op, ConvOp, CopyChannelsOp, FirstConvOp, pack_conv64_rows_kernel, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
-                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel,
+                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel, pack_winograd_f43_kernel_b,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
                      pack_winograd_s2_kernel, current_scope, pack_conv_kernel_chunked)
@@ -280,8 +280,9 @@ class Network(object):
                      or WinogradF43ConvOp.workgroups(input.shape, filters) >= g.winograd_f43_min_workgroups)
         if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43 and f43_fills
                 and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld)):
-            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel)
-            self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu))
+            e8 = bool(g.winograd_f43_eight_wave)
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel_b if e8 else pack_winograd_f43_kernel)
+            self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
             return y
         # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs
         #  7.10, conv3b 5.05 vs 5.99, conv4b 4.93 vs 5.42, conv5 2.49 vs 2.73, conv6 0.63 vs 0.77)

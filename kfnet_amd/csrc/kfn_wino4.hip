@@ -103,6 +103,10 @@ static_assert(KFN_W4_XDIST != 2 || (KFN_W4_RS0 + 8 * 5 + 3 < KFN_W4_CS0 && KFN_W
 #ifndef KFN_W4_DBG
 #define KFN_W4_DBG 0
 #endif
+// which form kfn_conv2d_winograd_f43 launches when kfn_conv_desc.wino_form is AUTO: 0 = four waves (wino4_kernel), 1 = eight
+#ifndef KFN_W4_DEFAULT_EIGHT_WAVE
+#define KFN_W4_DEFAULT_EIGHT_WAVE 0
+#endif
 static_assert(36 * KFN_W4_GSTEP <= KFN_W4_XSLOT && KFN_W4_XSLOT < KFN_W4_SSLOT && KFN_W4_SSLOT + 36 <= CPS * SPC, "producer schedule");
 static_assert(36 % NB == 0 && 36 % NVR == 0 && LDS_OUT <= LDS_V, "ring slots are compile-time constants per super-step");
 
@@ -673,6 +677,398 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
 #endif
 }
 
+
+// =====================================================================================================================
+// The EIGHT-WAVE form (two waves per SIMD): wino4b_kernel.
+// One wave per SIMD hides nothing of its own loads / transform / LDS traffic (timing builds above: 0.91 -> 0.72 of the MFMA
+// peak is instruction issue of the producer work).  288 accumulator registers per wave forbid a second wave on 32x32x2
+// tiles; on v_mfma_f32_16x16x4_f32 (same FLOP rate, 8 passes) a wave can own 18 positions x 32 tiles x SIXTEEN channels =
+// 36 accumulators of 4 registers = 144: eight waves = position half wx (the output reduction stays two-way) x channel
+// quarter wq.  Same tile block (4 x 8 tiles x 64 channels), same weight packing, same LDS budget:
+//   * V of a chunk: [36 positions][4 k][16 rows][2 tile halves][2 k-steps] floats -- lane (row r, k) of the A operand reads
+//     ONE ds_read_b128 per (chunk, position) = both tile halves x both k-steps; input channel of (k, k-step s) = 2 k + s,
+//     so the B operand's pair is 8 contiguous bytes of the packed weights.  Rows are stored at r ^ k: the reads stay
+//     conflict-free (a read group holds rows {0-3, 12-15} of one k and {4-11} of the next) and the producer's 4-byte stores
+//     spread over 16 banks instead of 4.
+//   * producer: all eight waves, one CHANNEL per lane (36 patch registers instead of 72, plain instead of packed
+//     transform arithmetic): wave w = tile column w & 3, tile rows 4 (w >> 2) .. + 3, lane = (tile row, channel of the
+//     super-step's 16) -- 16 lanes read 64 contiguous bytes of a pixel.
+//   * weights re-packed per PAIR of positions (graph.pack_winograd_f43_kernel_b): one 16-byte load per lane, chunk and pair.
+//   * epilogue: lane (channel, k) holds tiles 16 th + 4 k + e; the partner exchange and the 16-byte image reads as above, the
+//     image tile pitch 1028 floats (the four k groups of a store on different banks).
+constexpr int B_VPOS = 256;                       // floats per position
+constexpr int B_VBUF = NPOS * B_VPOS;             // floats per chunk buffer
+constexpr int B_LDS_V = 2 * CPS * B_VBUF * 4;     // 147 456 B
+constexpr int B_TILE = 1028;                      // floats per tile of the output image
+constexpr int B_LDS_OUT = 32 * B_TILE * 4;        // 131 584 B
+constexpr int B_LDS = B_LDS_V > B_LDS_OUT ? B_LDS_V : B_LDS_OUT;
+#ifndef KFN_W4B_NB
+#define KFN_W4B_NB 6
+#endif
+constexpr int NBB = KFN_W4B_NB;                   // B ring in position PAIRS (16 bytes per lane and pair)
+constexpr int NVB = 4;                            // V ring (16 bytes per lane and fragment)
+static_assert(18 % NBB == 0 && 36 % NVB == 0 && NBB <= WPOS / 2 && NVB <= WPOS, "ring slots are compile-time constants per super-step");
+#ifndef KFN_W4B_GSTEP
+#define KFN_W4B_GSTEP 2
+#define KFN_W4B_XSLOT 100
+#define KFN_W4B_SSLOT 106
+#endif
+static_assert(36 * KFN_W4B_GSTEP <= KFN_W4B_XSLOT && KFN_W4B_XSLOT < KFN_W4B_SSLOT && KFN_W4B_SSLOT + 36 <= CPS * SPC,
+              "producer schedule (eight-wave form)");
+// timing experiments only (wrong results on purpose): bit 0 no transform, 1 no patch loads, 2 no V stores, 3 no B loads in the loop
+#ifndef KFN_W4B_DBG
+#define KFN_W4B_DBG 0
+#endif
+#ifndef KFN_W4B_STAGGER
+#define KFN_W4B_STAGGER 0
+#endif
+#ifndef KFN_W4B_GPS
+#define KFN_W4B_GPS 2     // staggered form: patch loads per slot (36 loads in the first 18 slots of the half)
+#define KFN_W4B_HX 56     // ... the transform's slot inside the half
+#define KFN_W4B_SPS 3     // ... V stores per slot (36 stores in the 12 slots behind the transform)
+#endif
+#ifndef KFN_W4B_XDIST
+#define KFN_W4B_XDIST 0
+#endif
+#ifndef KFN_W4B_XOFF
+#define KFN_W4B_XOFF 22   // stagger form 2: the late waves' transform at XSLOT + XOFF, their 36 stores two per slot behind it
+#endif
+
+// one 1-D pass of B^T on six values, in place (bt6 above, one channel)
+__device__ __forceinline__ void bt6s(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
+  const float a = __builtin_fmaf(d2, -4.f, d4);
+  const float b = __builtin_fmaf(d1, -4.f, d3);
+  const float c = d4 - d2;
+  const float e = d3 - d1;
+  const float u = __builtin_fmaf(d2, -5.f, d4);
+  const float v = __builtin_fmaf(d3, -5.f, d5);
+  d0 = __builtin_fmaf(d0, 4.f, u);
+  d5 = __builtin_fmaf(d1, 4.f, v);
+  d1 = a + b;
+  d2 = a - b;
+  d3 = __builtin_fmaf(e, 2.f, c);
+  d4 = __builtin_fmaf(e, -2.f, c);
+}
+__device__ __forceinline__ void bt_d_b6s(float (&v)[36]) {   // v[6 r + c] -> v[6 xi + nu]
+#pragma unroll
+  for (int r = 0; r < 6; ++r) bt6s(v[6 * r + 0], v[6 * r + 1], v[6 * r + 2], v[6 * r + 3], v[6 * r + 4], v[6 * r + 5]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) bt6s(v[c], v[6 + c], v[12 + c], v[18 + c], v[24 + c], v[30 + c]);
+}
+
+__global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];   // [4][B_VBUF] floats, later the output image
+  float* const smf = reinterpret_cast<float*>(smem4);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wx = wave & 1, wq = wave >> 1;      // position half, 16-channel quarter
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap4(blockIdx.x, nwg);
+  const int per = p.tiles_m * p.n_group;
+  const int gset = tile / per, rem = tile - gset * per;
+  const int tm = rem / p.n_group;
+  const int tn = gset * p.n_group + (rem - tm * p.n_group);
+  const int cb = tm % p.bw, rb = tm / p.bw;
+  const int nbase = tn * 64;
+  const int n0 = nbase + wq * 16;
+
+  const int vr0 = rb * BH4;
+  const int img0 = vr0 / p.Th;
+  const int ty0 = vr0 - img0 * p.Th;
+  const int brk = (p.Th - ty0 < BH4) ? (p.Th - ty0) : BH4;
+  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_rest = p.x_bytes - a_base;
+  const unsigned long long two_img = 2ull * p.H * p.W * p.ldx * 4ull;
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u4), 0, p.u_bytes, 0x00020000);
+
+  // ---- PRODUCER: tile (row ptr = 4 (wave >> 2) + (lane >> 4), column tc = wave & 3), channel c16 = lane & 15 of the super-step's
+  // 16 (chunk pch = c16 >> 3): 16 lanes read 64 contiguous bytes of a pixel, a load instruction touches four rows (the 8-channel
+  // x 8-row form touched eight 32-byte pieces: twice the L1 transactions of the four-wave kernel) ---------
+  const int c16 = lane & 15, c8 = c16 & 7, pch = c16 >> 3;
+  const int tc = wave & 3, ptr = 4 * (wave >> 2) + (lane >> 4);
+  unsigned roff[6];
+  unsigned coff[6];
+  bool cok[6];
+  {
+    const int img_rel = ptr < brk ? 0 : 1;
+    const int ty = ptr < brk ? ty0 + ptr : ptr - brk;
+    const int tx = cb * BW4 + tc;
+    const bool row_tile_ok = (vr0 + ptr < p.vrows);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = 4 * ty - 1 + r;
+      roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
+                    ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(c16 * 4) : ROW_POISON;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = 4 * tx - 1 + c;
+      cok[c] = (tx < p.Tw) && ((unsigned)xx < (unsigned)p.W);
+      coff[c] = cok[c] ? (unsigned)(xx * p.ldx * 4) : 0u;
+    }
+  }
+  const int x_records = (int)(a_rest < two_img ? a_rest : two_img);
+  // V store address (floats) inside a super-step's buffer pair: chunk pch, k = c8 >> 1, k-step = c8 & 1, tile t = 4 ptr + tc
+  const int pt = 4 * ptr + tc;
+  const int v_st = pch * B_VBUF + (c8 >> 1) * 64 + (((pt & 15) ^ (c8 >> 1)) * 4) + (pt >> 4) * 2 + (c8 & 1);
+  const int n_chunks = p.Cin / 8;
+  const int n_super = n_chunks / CPS;
+  const int s_last = n_super - 1;
+
+  // ---- CONSUMER: A row rl = lane & 15 (tiles rl, 16 + rl), k = kl = lane >> 4; B column nl = lane & 15 (channel n0 + nl) -------
+  const int rl = lane & 15, kl = lane >> 4;
+  const int v_lane = (WPOS * wx) * B_VPOS + kl * 64 + ((rl ^ kl) * 4);                 // floats; + l * B_VPOS
+  // B: U4b [Cin/8][18 position pairs][cout_pad][4 k][2 positions][2 k-steps] (graph.pack_winograd_f43_kernel_b): one
+  // 16-byte load per (chunk, pair of positions) and lane
+  const unsigned voff_b = (unsigned)(((n0 + rl) * 16 + kl * 4) * 4);
+  const unsigned b_step = (unsigned)p.cout_pad * 64u;
+  const int q_last = n_chunks * (NPOS / 2) - 1;
+
+  f32x4 acc[WPOS][2];
+#pragma unroll
+  for (int l = 0; l < WPOS; ++l)
+#pragma unroll
+    for (int th = 0; th < 2; ++th) acc[l][th] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float pv[36];
+  f32x4 bq[NBB];       // ring of position PAIRS
+  f32x4 vq[NVB];
+
+  auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int r = i / 6, c = i % 6;
+    const int sc = ss < s_last ? ss : s_last;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
+    pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)(sc * 64), 0));
+  };
+  auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    smf[(ss & 1) * (CPS * B_VBUF) + v_st + g * B_VPOS] = pv[g];
+  };
+  auto b_load = [&](auto sl_, int ch, int pr) __attribute__((always_inline)) {      // pair pr (0..8) of this wave's positions
+    constexpr int sl = decltype(sl_)::value;
+    const int q = ch * (NPOS / 2) + (WPOS / 2) * wx + pr;
+    const int qc = q < q_last ? q : q_last;
+    bq[sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)qc * b_step, 0));
+  };
+  auto v_read = [&](auto sl_, int ch, int l) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_)::value;
+    vq[sl] = *reinterpret_cast<const f32x4*>(smf + (ch & (2 * CPS - 1)) * B_VBUF + l * B_VPOS + v_lane);
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------
+  sfor4<36>([&](auto ic) { p_gather(ic, 0); });
+  sfor4<NBB>([&](auto sc) { b_load(sc, 0, decltype(sc)::value); });
+  bt_d_b6s(pv);
+  sfor4<36>([&](auto gc) { p_store(gc, 0); });
+  // The two waves of a SIMD (w and w + 4) do their producer work in different HALVES of a super-step (KFN_W4B_STAGGER): in
+  // lockstep both would stand in the same transform burst / load group at the same time and the MFMA pipe would idle
+  // (timing builds: the transform alone cost 9.5 % that way).  Waves 0-3 gather, transform and store in slots 0..71, waves
+  // 4-7 in slots 72..143 -- nothing of the patch lives across the barrier (a half-super-step SHIFT of the late waves did:
+  // 36 more live registers, spills in the loop, 108 -> 87 TFLOP/s).
+  const bool late = KFN_W4B_STAGGER && wave >= 4;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- main loop: one super-step = 2 chunks x 72 MFMA slots (9 pairs of positions x 2 k-steps x 2 positions x 2 tile halves) ----
+  auto super_step = [&](auto latec, int ks) __attribute__((always_inline)) {
+    constexpr bool LATE = decltype(latec)::value;
+    // producer slots of this wave inside the 144 (staggered: inside its half): KFN_W4B_GPS gathers per slot from G0, the
+    // transform at XS, KFN_W4B_SPS stores per slot from S0
+    // KFN_W4B_STAGGER: 0 = every wave on one schedule; 1 = waves 0-3 produce in slots 0..71, waves 4-7 in 72..143 (measured
+    // worse: the bursts get denser); 2 = the same loads, the late waves' transform burst and stores KFN_W4B_XOFF slots later
+    constexpr int G0 = KFN_W4B_STAGGER == 1 ? (LATE ? 72 : 0) : 0;
+    constexpr int XS = KFN_W4B_STAGGER == 1 ? G0 + KFN_W4B_HX : KFN_W4B_XSLOT + ((KFN_W4B_STAGGER == 2 && LATE) ? KFN_W4B_XOFF : 0);
+    constexpr int S0 = KFN_W4B_STAGGER == 1 ? G0 + KFN_W4B_HX + 2 : (KFN_W4B_STAGGER == 2 && LATE) ? XS + 2 : KFN_W4B_SSLOT;
+    constexpr int GPS = KFN_W4B_STAGGER == 1 ? KFN_W4B_GPS : 1, GST = KFN_W4B_STAGGER == 1 ? 1 : KFN_W4B_GSTEP;
+    constexpr int SPS = KFN_W4B_STAGGER == 1 ? KFN_W4B_SPS : (KFN_W4B_STAGGER == 2 && LATE) ? 2 : 1;
+    static_assert(G0 + GST * (35 / GPS) < XS && XS < S0 && S0 + (35 / SPS) < (KFN_W4B_STAGGER == 1 ? G0 + 72 : 144), "producer schedule");
+    const int c0 = ks * CPS;
+    sfor4<NVB>([&](auto gc) { v_read(gc, c0, decltype(gc)::value); });
+    sfor4<CPS>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      const int ch = c0 + cc;
+      sfor4<SPC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int pr = j / 8, sk = (j % 8) / 4, lp = ((j % 8) / 2) % 2, th = j % 2;
+        constexpr int l = 2 * pr + lp;
+        constexpr int qs = cc * WPOS + l;
+        constexpr int qp = cc * (WPOS / 2) + pr;       // pair index inside the super-step (18 per wave)
+        constexpr int sb = qp % NBB, sv = qs % NVB;
+        acc[l][th] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[sv][2 * th + sk], bq[sb][2 * lp + sk], acc[l][th], 0, 0, 0);
+        if constexpr (sk == 1 && th == 1 && lp == 1 && !(KFN_W4B_DBG & 8)) {   // the pair's last MFMA: its B slot is free
+          if constexpr (pr + NBB < WPOS / 2) b_load(std::integral_constant<int, sb>{}, ch, pr + NBB);
+          else b_load(std::integral_constant<int, sb>{}, ch + 1, pr + NBB - WPOS / 2);
+        }
+        if constexpr (sk == 1 && th == 1) {      // the last MFMA of fragment (ch, l): its V slot is free
+          if constexpr (l + NVB < WPOS) v_read(std::integral_constant<int, sv>{}, ch, l + NVB);
+          else if constexpr (cc < CPS - 1) v_read(std::integral_constant<int, sv>{}, ch + 1, l + NVB - WPOS);
+        }
+        constexpr int sj = cc * SPC + j;
+        if constexpr (!(KFN_W4B_DBG & 2) && sj >= G0 && (sj - G0) % GST == 0 && (sj - G0) / GST * GPS < 36) {
+          sfor4<GPS>([&](auto uc) {
+            constexpr int gi = (sj - G0) / GST * GPS + decltype(uc)::value;
+            if constexpr (gi < 36) p_gather(std::integral_constant<int, gi>{}, ks + 1);
+          });
+        }
+        if constexpr (KFN_W4B_XDIST) {
+          // the transform as 12 passes in 12 different slots (two waves per SIMD: a pass of 12 instructions can sit under the
+          // partner's MFMAs, a burst of 144 on both waves at once cannot): row pass r (its loads went out by slot 12 r + 10) at
+          // slot 42 + 12 r, column pass c at 104 + 2 c, store k = 6 nu + xi (position 6 xi + nu) at slot 106 + k
+          if constexpr (!(KFN_W4B_DBG & 1)) {
+            if constexpr (sj >= 42 && (sj - 42) % 12 == 0 && (sj - 42) / 12 < 6) {
+              constexpr int r = (sj - 42) / 12;
+              bt6s(pv[6 * r], pv[6 * r + 1], pv[6 * r + 2], pv[6 * r + 3], pv[6 * r + 4], pv[6 * r + 5]);
+            }
+            if constexpr (sj >= 104 && (sj - 104) % 2 == 0 && (sj - 104) / 2 < 6) {
+              constexpr int c = (sj - 104) / 2;
+              bt6s(pv[c], pv[6 + c], pv[12 + c], pv[18 + c], pv[24 + c], pv[30 + c]);
+            }
+          }
+          if constexpr (!(KFN_W4B_DBG & 4) && sj >= 106 && sj < 142) {
+            constexpr int k = sj - 106;
+            p_store(std::integral_constant<int, 6 * (k % 6) + k / 6>{}, ks + 1);
+          }
+        } else {
+          if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6s(pv);
+          if constexpr (!(KFN_W4B_DBG & 4) && sj >= S0 && (sj - S0) * SPS < 36) {
+            sfor4<SPS>([&](auto uc) {
+              constexpr int gi = (sj - S0) * SPS + decltype(uc)::value;
+              if constexpr (gi < 36) p_store(std::integral_constant<int, gi>{}, ks + 1);
+            });
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if (late) {
+    for (int ks = 0; ks < n_super; ++ks) super_step(std::true_type{}, ks);
+  } else {
+    for (int ks = 0; ks < n_super; ++ks) super_step(std::false_type{}, ks);
+  }
+
+  // ---- epilogue: partial output transform of this wave's 18 positions, exchange with the partner (other xi half, same channel
+  // quarter = wave ^ 1) through the image [32 tiles][B_TILE], as in wino4_kernel.  Lane (nl, kl): tiles 16 th + 4 kl + e. ----
+  {
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f};
+    float* const img = smf + (4 * kl) * B_TILE + wq * 16 + rl;
+    auto rows = [&](auto lower_half, auto thc, auto e0c, auto i0c, f32x2 (&P)[2][4]) __attribute__((always_inline)) {
+      constexpr bool LOWER = decltype(lower_half)::value;
+      constexpr int th = decltype(thc)::value, e0 = decltype(e0c)::value, i0 = decltype(i0c)::value;
+      f32x2 R[3][4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        f32x2 M[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) M[nu] = f32x2{acc[6 * a + nu][th][e0], acc[6 * a + nu][th][e0 + 1]};
+        const f32x2 s1 = pk_add4(M[1], M[2]), d1 = pk_sub4(M[1], M[2]);
+        const f32x2 s2 = pk_add4(M[3], M[4]), d2 = pk_sub4(M[3], M[4]);
+        R[a][0] = pk_add4(pk_add4(M[0], s1), s2);
+        R[a][1] = pk_fma4(d2, k2, d1);
+        R[a][2] = pk_fma4(s2, k4, s1);
+        R[a][3] = pk_add4(pk_fma4(d2, k8, d1), M[5]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (LOWER) {
+          if constexpr (i0 == 0) {
+            P[0][j] = pk_add4(R[0][j], pk_add4(R[1][j], R[2][j]));
+            P[1][j] = pk_sub4(R[1][j], R[2][j]);
+          } else {
+            P[0][j] = pk_add4(R[1][j], R[2][j]);
+            P[1][j] = pk_sub4(R[1][j], R[2][j]);
+          }
+        } else {
+          if constexpr (i0 == 0) {
+            P[0][j] = pk_add4(R[0][j], R[1][j]);
+            P[1][j] = pk_mul4(pk_sub4(R[0][j], R[1][j]), k2);
+          } else {
+            P[0][j] = pk_mul4(pk_add4(R[0][j], R[1][j]), k4);
+            P[1][j] = pk_fma4(pk_sub4(R[0][j], R[1][j]), k8, R[2][j]);
+          }
+        }
+      }
+    };
+    auto reduce = [&](auto lower_half) __attribute__((always_inline)) {
+      constexpr bool LOWER = decltype(lower_half)::value;
+      constexpr int I_MINE = LOWER ? 0 : 2, I_THEIRS = LOWER ? 2 : 0;
+      sfor4<4>([&](auto qc) {
+        constexpr int th = decltype(qc)::value / 2, e0 = 2 * (decltype(qc)::value % 2);
+        f32x2 P[2][4];
+        rows(lower_half, std::integral_constant<int, th>{}, std::integral_constant<int, e0>{}, std::integral_constant<int, I_THEIRS>{}, P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              img[(16 * th + e0 + h) * B_TILE + ((I_THEIRS + i) * 4 + j) * 64] = h == 0 ? P[i][j].x : P[i][j].y;
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sfor4<4>([&](auto qc) {
+        constexpr int th = decltype(qc)::value / 2, e0 = 2 * (decltype(qc)::value % 2);
+        f32x2 P[2][4];
+        rows(lower_half, std::integral_constant<int, th>{}, std::integral_constant<int, e0>{}, std::integral_constant<int, I_MINE>{}, P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float* const q = img + (16 * th + e0 + h) * B_TILE + ((I_MINE + i) * 4 + j) * 64;
+              *q = *q + (h == 0 ? P[i][j].x : P[i][j].y);
+            }
+      });
+    };
+    if (wx == 0) reduce(std::true_type{});
+    else reduce(std::false_type{});
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // the image leaves: iteration `it` = tiles 2 it, 2 it + 1 (wave >> 2), pixel row i = wave & 3, column j = lane >> 4, channel quad lane & 15
+  {
+    const bool relu = p.relu != 0;
+    const unsigned long long y_base = (unsigned long long)img0 * p.H * p.W * p.ldy * 4ull;
+    const unsigned long long y_rest = p.y_bytes - y_base;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+    const int j = lane >> 4, nq = nbase + 4 * (lane & 15);
+    const int pi = wave & 3, tsel = wave >> 2;
+    const bool q_ok = nq < p.Cout;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && q_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + nq);
+    const unsigned voff = (unsigned)((j * p.ldy + nq) * 4);
+    const int pix_bytes = p.ldy * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int t = 2 * it + tsel;
+      f32x4 v = *reinterpret_cast<const f32x4*>(smf + t * B_TILE + (4 * pi + j) * 64 + 4 * (lane & 15));
+      v += bv;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int tr = t >> 2, tcc = t & 3;
+      const int img_rel = tr < brk ? 0 : 1;
+      const int ty = tr < brk ? ty0 + tr : tr - brk;
+      const int tx = cb * BW4 + tcc;
+      const int oy = 4 * ty + pi;
+      const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
+      const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
+      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef KFN_WINO4_PROF
@@ -753,6 +1149,17 @@ extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, c
 #ifdef KFN_WINO4_PROF
   a.prof = g_wino4_prof;
 #endif
+  // kfn_conv_desc.wino_form: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE pick the kernel (A/B measurements); AUTO = the default below
+  const bool eight = d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE ||
+                     (d->wino_form != KFN_WINO_FORM_F43_FOUR_WAVE && KFN_W4_DEFAULT_EIGHT_WAVE);
+  if (eight) {
+    static std::atomic<uint64_t> attr_done_b{0};
+    int rcb = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4b_kernel), B_LDS, attr_done_b);
+    if (rcb != KFN_OK) return rcb;
+    hipLaunchKernelGGL(wino4b_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), B_LDS, (hipStream_t)stream, a);
+    KFN_LAUNCH_CHECK("wino4b_kernel");
+    return KFN_OK;
+  }
   static std::atomic<uint64_t> attr_done{0};
   int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);
   if (rc != KFN_OK) return rc;

@@ -296,6 +296,16 @@ def pack_winograd_f43_kernel(w):
     return np.ascontiguousarray(u.reshape(36, cp, ci // 8, 8).transpose(2, 0, 1, 3))
 
 
+def pack_winograd_f43_kernel_b(w):
+    """The same U for the EIGHT-WAVE form of kfn_conv2d_winograd_f43 (kfn_conv_desc.wino_form = KFN_WINO_FORM_F43_EIGHT_WAVE,
+    wino4b_kernel): U4b [Cin/8][18 position pairs][cout_pad][4 k][2 positions][2 k-steps] -- lane (channel n, k) of a
+    16x16x4 B operand reads 16 contiguous bytes per (chunk, pair): positions 2q and 2q + 1, input channels 2k and 2k + 1."""
+    u = pack_winograd_f43_kernel(w)                     # [Cin/8][36][cp][8]
+    nc, _, cp, _ = u.shape
+    v = u.reshape(nc, 18, 2, cp, 4, 2)                  # [chunk][pair][pp][n][k][s]
+    return np.ascontiguousarray(v.transpose(0, 1, 3, 4, 2, 5).reshape(nc, 18, cp, 16))
+
+
 def pack_winograd_s2_kernel(w):
     """TF HWIO [3,3,Cin,Cout] -> the 16 weight fragments [Cin/8][16][cout_pad][8] of kfn_conv2d_winograd_s2
     (3x3 stride-2 conv as four stride-1 polyphase filters under F(2,2), csrc/kfn_wino_s2.hip): with
@@ -547,11 +557,19 @@ class WinogradFusedConvOp(ConvOp):
 
 
 class WinogradF43ConvOp(ConvOp):
-    """3x3 stride-1 SAME conv through kfn_conv2d_winograd_f43 (csrc/kfn_wino4.hip): F(4x4,3x3), 36 positions split over
-    the four waves of a workgroup (18 accumulators each), one launch, no workspace -- for the Cin >= 512 layers."""
+    """3x3 stride-1 SAME conv through kfn_conv2d_winograd_f43 (csrc/kfn_wino4.hip): F(4x4,3x3), one launch, no workspace.
+    eight_wave (Graph.winograd_f43_eight_wave, the default): wino4b_kernel -- two waves per SIMD on 16x16x4 MFMA tiles, 36
+    accumulators of 4 registers per wave, weights packed per pair of positions (pack_winograd_f43_kernel_b); else
+    wino4_kernel -- four waves on 32x32x2 tiles, 18 accumulators of 16 registers (pack_winograd_f43_kernel)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu):
+    def __init__(self, name, x, y, kernel, bias, relu, eight_wave=True):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
+        self.eight_wave = eight_wave
+
+    def desc(self):
+        d = ConvOp.desc(self)
+        d.wino_form = _lib.WINO_FORM_F43_EIGHT_WAVE if self.eight_wave else _lib.WINO_FORM_F43_FOUR_WAVE
+        return d
 
     @staticmethod
     def supported(x_shape, cin, cout, ldx=None):
@@ -567,7 +585,7 @@ class WinogradF43ConvOp(ConvOp):
         return (-(-tw // 4)) * (-(-(n * th) // 8)) * (-(-cout // 64))
 
     def kernel_name(self, lib):
-        return 'wino4_kernel'
+        return 'wino4b_kernel' if self.eight_wave else 'wino4_kernel'
 
     def mfma_flops(self):
         """FLOPs the MFMAs execute: 36 positions x (tile blocks padded to 4x8 tiles of 4x4 pixels, batch rows packed) x
@@ -1156,6 +1174,9 @@ class Graph(object):
         # the K loop must amortise the 36-position transforms and the cross-wave output reduction
         self.winograd_f43_min_channels = 64
         self.winograd_f43_min_workgroups = 128   # below this the launch leaves the chip idle: F(2x2,3x3) (Network.conv)
+        # the eight-wave form of the F(4x4,3x3) kernel (wino4b_kernel; measured at batch 32 against the four-wave form, same
+        # box: conv1b 2.66 -> 2.34 ms, conv2b 6.98 -> 6.54, conv3b 6.43 -> 6.13, conv4b 6.08 -> 5.85)
+        self.winograd_f43_eight_wave = True
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

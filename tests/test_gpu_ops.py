@@ -832,16 +832,18 @@ F43_CASES = [(2, 32, 16, 16, 64), (3, 60, 80, 32, 64), (2, 30, 40, 64, 128), (5,
              (3, 29, 35, 32, 100), (2, 120, 160, 16, 64), (9, 32, 16, 512, 64), (2, 60, 80, 1024, 128)]
 
 
+@pytest.mark.parametrize('form', [2, 3])      # KFN_WINO_FORM_F43_FOUR_WAVE (wino4_kernel), _EIGHT_WAVE (wino4b_kernel)
 @pytest.mark.parametrize('relu', [1, 0])
 @pytest.mark.parametrize('case', F43_CASES)
-def test_winograd_f43_vs_oracle(case, relu):
-    """kfn_conv2d_winograd_f43 (F(4x4,3x3): 36 positions over the four waves of a workgroup, the xi half of the output
-    transform reduced across waves through LDS) == oracle up to fp32 round-off; strided input and output windows, guard
-    rows behind the tensor untouched.  Tolerance 8x the direct kernel's: the transforms carry factors up to 8."""
+def test_winograd_f43_vs_oracle(case, relu, form):
+    """kfn_conv2d_winograd_f43 (F(4x4,3x3): 36 positions over the waves of a workgroup -- four waves on 32x32x2 MFMA tiles or
+    eight on 16x16x4 --, the xi half of the output transform reduced across waves through LDS) == oracle up to fp32
+    round-off; strided input and output windows, guard rows behind the tensor untouched.  Tolerance 8x the direct
+    kernel's: the transforms carry factors up to 8."""
     import torch
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib
-    from kfnet_amd.graph import pack_winograd_f43_kernel
+    from kfnet_amd.graph import pack_winograd_f43_kernel, pack_winograd_f43_kernel_b
     lib = _lib.load()
     n, h, w, ci, co = case
     rng = np.random.default_rng(n * 1000 + h * 10 + ci + 43)
@@ -850,13 +852,14 @@ def test_winograd_f43_vs_oracle(case, relu):
     b = rng.normal(size=co).astype(np.float32)
     ldx, ldy = ci + 8, co + 8
     d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
-                      stride=1, relu=relu)
+                      stride=1, relu=relu, wino_form=form)
     assert lib.kfn_winograd_f43_supported(C.byref(d)) == 1
     GUARD = 64
     xb = np.full((n * h * w, ldx), 9.0, dtype=np.float32)      # the columns behind Cin must never be read into the sum
     xb[:, :ci] = x.reshape(-1, ci)
     y = torch.full((n * h * w + GUARD, ldy), -5.0, device='cuda')
-    dx, du, db = dev(xb), dev(pack_winograd_f43_kernel(wt)), dev(np.concatenate([b, np.zeros((-co) % 4, np.float32)]))
+    pack = pack_winograd_f43_kernel_b if form == 3 else pack_winograd_f43_kernel      # the eight-wave form reads pairs of positions
+    dx, du, db = dev(xb), dev(pack(wt)), dev(np.concatenate([b, np.zeros((-co) % 4, np.float32)]))
     _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
                                            stream()), 'wino4')
     sync()

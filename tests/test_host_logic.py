@@ -98,7 +98,19 @@ def test_default_routes_of_the_3x3_layers():
     for n in four_wave:
         assert names[n] == 'wino3_kernel', (n, names[n])
     for n in f43:
-        assert names[n] == 'wino4_kernel', (n, names[n])
+        assert names[n] == 'wino4b_kernel', (n, names[n])      # the eight-wave form (Graph.winograd_f43_eight_wave)
+    g4, _ = _build(4, winograd_f43_eight_wave=False)
+    k4 = [op for op in g4.ops if op.name == 'conv4b'][0]
+    assert k4.kernel_name(lib) == 'wino4_kernel' and k4.kernel.pack.__name__ == 'pack_winograd_f43_kernel' and k4.desc().wino_form == 2
+    k8 = [op for op in g.ops if op.name == 'conv4b'][0]
+    assert k8.kernel.pack.__name__ == 'pack_winograd_f43_kernel_b' and k8.desc().wino_form == 3
+    # the pair layout against its index formula (include/kfnet_hip.h)
+    from kfnet_amd.graph import pack_winograd_f43_kernel, pack_winograd_f43_kernel_b
+    wr = np.random.default_rng(5).normal(size=(3, 3, 16, 40)).astype(np.float32)
+    ua, ub = pack_winograd_f43_kernel(wr), pack_winograd_f43_kernel_b(wr)
+    assert ua.shape == (2, 36, 64, 8) and ub.shape == (2, 18, 64, 16)
+    for (ci, co, pp) in [(0, 0, 0), (13, 39, 35), (6, 17, 22), (9, 5, 7)]:
+        assert ub[ci // 8, pp // 2, co, 4 * ((ci % 8) // 2) + 2 * (pp % 2) + ci % 2] == ua[ci // 8, pp, co, ci % 8]
     assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
     for n in ('conv2a', 'conv3a', 'conv4a', 'feat6'):
         assert names[n] == 'wino_s2_kernel', (n, names[n])

@@ -48,7 +48,8 @@ for (name, H, W, ci, co) in LAYERS:
         t_out = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd(C.byref(d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ws.data_ptr(), 2, st), 'w'))
         del ws
     dd = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=1, relu=1,
-                       operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32, wino_order=int(os.environ.get('MB_F43_ORDER', ORDER)))
+                       operand_dtype=_lib.OPERAND_F16 if F16 else _lib.OPERAND_F32, wino_order=int(os.environ.get('MB_F43_ORDER', ORDER)),
+                       wino_form=int(os.environ.get('MB_F43_FORM', '0')))   # 2 four waves (wino4_kernel), 3 eight waves (wino4b_kernel)
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     if F16:
         w9 = w9.half()
