@@ -730,6 +730,9 @@ static_assert(36 * KFN_W4B_GSTEP <= KFN_W4B_XSLOT && KFN_W4B_XSLOT < KFN_W4B_SSL
 #ifndef KFN_W4B_XDIST
 #define KFN_W4B_XDIST 0
 #endif
+#ifndef KFN_W4B_PRIO
+#define KFN_W4B_PRIO 0
+#endif
 #ifndef KFN_W4B_XOFF
 #define KFN_W4B_XOFF 22   // stagger form 2: the late waves' transform at XSLOT + XOFF, their 36 stores two per slot behind it
 #endif
@@ -948,11 +951,19 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+#if KFN_W4B_PRIO
+  // static priority for the second-dispatched half: at equal priority the issue arbitration goes by age and waves 4-7 lose every
+  // contested slot (MI355X_MICROARCH: two waves per SIMD, item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   if (late) {
     for (int ks = 0; ks < n_super; ++ks) super_step(std::true_type{}, ks);
   } else {
     for (int ks = 0; ks < n_super; ++ks) super_step(std::false_type{}, ks);
   }
+#if KFN_W4B_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   // ---- epilogue: partial output transform of this wave's 18 positions, exchange with the partner (other xi half, same channel
   // quarter = wave ^ 1) through the image [32 tiles][B_TILE], as in wino4_kernel.  Lane (nl, kl): tiles 16 th + 4 kl + e. ----
