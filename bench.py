@@ -17,7 +17,7 @@ Timing: W untimed warm-up steps, then the K-step pass is REPEATED until at least
 barrier + torch.cuda.synchronize() on both sides, timed per rank, MAX over ranks; the line
 reports the MEDIAN repetition (`ms_per_step`, `value`), the repetition count and the spread.
 
-One JSON line on rank 0; extra objects: roofline (the dominant kernel instantiation of the step -- round 4: wino4_kernel,
+One JSON line on rank 0; extra objects: roofline (the dominant kernel instantiation of the step -- round 4: wino4b_kernel,
 Winograd F(4x4,3x3) on the fp32 MFMA), roofline_kalman (batched persistent scan, HBM; at T = 64 and T = 256),
 cpu_baseline (reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
 
@@ -1054,7 +1054,7 @@ def main():
             'unit': 'TFLOP/s', 'frac': round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
             'traffic': traffic,
             'algorithmic_tflops': round(tf, 2), 'algorithmic_frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': ('wino3_kernel / wino2_kernel = single-kernel Winograd F(2x2,3x3), wino4_kernel = F(4x4,3x3) '
+            'note': ('wino3_kernel / wino2_kernel = single-kernel Winograd F(2x2,3x3), wino4b_kernel / wino4_kernel = F(4x4,3x3) on eight / four waves '
                      '(kfn_conv2d_winograd_fused, fp32; the waves of a workgroup share one input transform through LDS): '
                      'achieved = FLOPs the MFMAs execute (16/36 resp. 9/36 of the nominal direct-convolution FLOPs + tile-block '
                      'padding) / time, algorithmic_* counts the nominal FLOPs of SURVEY App. C and may exceed the MFMA peak; '
