@@ -706,7 +706,10 @@ constexpr int B_LDS = B_LDS_V > B_LDS_OUT ? B_LDS_V : B_LDS_OUT;
 #define KFN_W4B_NB 6
 #endif
 constexpr int NBB = KFN_W4B_NB;                   // B ring in position PAIRS (16 bytes per lane and pair)
-constexpr int NVB = 4;                            // V ring (16 bytes per lane and fragment)
+#ifndef KFN_W4B_NVB
+#define KFN_W4B_NVB 4
+#endif
+constexpr int NVB = KFN_W4B_NVB;                  // V ring (16 bytes per lane and fragment)
 static_assert(18 % NBB == 0 && 36 % NVB == 0 && NBB <= WPOS / 2 && NVB <= WPOS, "ring slots are compile-time constants per super-step");
 #ifndef KFN_W4B_GSTEP
 #define KFN_W4B_GSTEP 2
