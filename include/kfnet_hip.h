@@ -99,7 +99,7 @@ typedef struct kfn_conv_desc {
                           * Activations and outputs stay fp32 in memory unless x_dtype / y_dtype say
                           * otherwise. */
   int32_t wino_order;    /* Winograd kernels only: workgroup order, KFN_WINO_ORDER_* (0 = the kernel's default) */
-  int32_t wino_form;     /* kfn_conv2d_winograd_fused / _f43: KFN_WINO_FORM_* (0 = auto) */
+  int32_t wino_form;     /* kfn_conv2d_winograd_fused / _f43 / _s2: KFN_WINO_FORM_* (0 = auto) */
   int32_t x_dtype;       /* KFN_ACT_F32 / KFN_ACT_F16: element type of the input activations in memory */
   int32_t y_dtype;       /* ... of the output activations.  KFN_ACT_F16 needs operand_dtype == KFN_OPERAND_F16
                           * (BASELINE config 5: fp16 activations end to end); ldx / ldy count ELEMENTS. */
@@ -133,6 +133,7 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_FORM_ONE_WAVE 1 /* force wino2_kernel (one wave per 32 output channels) where wino3_kernel / wino3_pair_kernel would run */
 #define KFN_WINO_FORM_F43_FOUR_WAVE 2  /* kfn_conv2d_winograd_f43: wino4_kernel (four waves, 32x32x2 MFMA tiles) */
 #define KFN_WINO_FORM_F43_EIGHT_WAVE 3 /* kfn_conv2d_winograd_f43: wino4b_kernel (eight waves, 16x16x4 MFMA tiles) */
+#define KFN_WINO_FORM_S2_EIGHT_WAVE 4  /* kfn_conv2d_winograd_s2: wino_s2b_kernel (eight waves, 16x16x4 MFMA tiles; fp32 operands) */
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1
@@ -231,7 +232,10 @@ int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const v
  * no workspace (csrc/kfn_wino_s2.hip).  u2_packed = the 16 pre-transformed, pre-signed weight fragments
  * [Cin/8][16][cout_pad][8] (fragments 0-8: G g00 G^T of the taps w[2a][2b]; 9-11: G (w[0][1], w[2][1]);
  * 12-14: G (w[1][0], w[1][2]); 15: w[1][1]; the fragments of Winograd index 2 negated) -- kfnet_amd.graph.
- * pack_winograd_s2_kernel.  Needs Cin % 16 == 0, H and W even, H >= 14, cout_pad % 32 == 0, no fused head
+ * pack_winograd_s2_kernel.  kfn_conv_desc.wino_form = KFN_WINO_FORM_S2_EIGHT_WAVE launches wino_s2b_kernel instead (two waves
+ * per SIMD on 16x16x4 MFMA tiles, fp32 operands only, 1.5-2.5 % faster: what the default graph does); its weights are packed
+ * per PAIR of fragments: u2b[((ci/8)*8 + f/2)*cout_pad + co][4*((ci%8)/2) + 2*(f%2) + ci%2]
+ * (kfnet_amd.graph.pack_winograd_s2_kernel_b).  Needs Cin % 16 == 0, H and W even, H >= 14, cout_pad % 32 == 0, no fused head
  * epilogue (kfn_winograd_s2_supported() == 1); KFN_ERR_UNSUPPORTED otherwise.  operand_dtype KFN_OPERAND_F16
  * (BASELINE config 5): u2_packed holds IEEE halfs in the same layout, the input transform runs in fp32 and is
  * rounded to fp16 when it is shared, fp16 MFMAs with fp32 accumulation. */

@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _lib
 from ..graph import (Conv64RowsF16Op, ConvOp, CopyChannelsOp, FirstConvOp, pack_conv64_rows_kernel, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
-                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel, pack_winograd_f43_kernel_b,
+                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_s2_kernel_b,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
                      pack_winograd_s2_kernel, current_scope, pack_conv_kernel_chunked)
@@ -294,8 +294,9 @@ class Network(object):
         # 3x3 stride-2 layers (SCoordNet conv2a / conv3a / conv4a): polyphase + F(2,2), 25/36 of the direct MFMAs
         if (k == 3 and strides == 2 and smin and cin >= smin and filters >= 128
                 and WinogradS2ConvOp.supported(input.shape, cin, filters)):
-            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel)
-            self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu))
+            e8 = bool(g.winograd_s2_eight_wave)
+            kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel_b if e8 else pack_winograd_s2_kernel)
+            self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
             return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):

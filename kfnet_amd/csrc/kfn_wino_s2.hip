@@ -425,6 +425,269 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
   }
 }
 
+
+// =====================================================================================================================
+// The EIGHT-WAVE form (two waves per SIMD), fp32 operands: wino_s2b_kernel.  Same tile block (8 x 4 tiles x 128 channels), same
+// positions / accumulator folding; on v_mfma_f32_16x16x4_f32 a wave owns 25 positions x 32 tiles x SIXTEEN channels = 9
+// accumulators x 2 tile halves x 4 registers = 72 -- two waves per SIMD fit, one wave's loads / transform / LDS traffic issue
+// under the other's MFMAs (what this bought the F(4x4,3x3) kernel: kfn_wino4.hip, wino4b_kernel).
+//   * V of a chunk: [26 slots][4 k][16 rows][2 tile halves][2 k-steps] floats (+16: the two chunks of a super-step 16 banks
+//     apart): lane (row r, k) of the A operand reads ONE ds_read_b128 per (chunk, position); input channel of (k, k-step s) =
+//     2 k + s.  Rows are stored at r ^ k (conflict-free reads, cf. wino4b_kernel).
+//   * producer: every wave; wave w = tile row w & 3 x tile columns 4 (w >> 2) .. + 3; lane = (phase set, tile column, channel
+//     PAIR of the super-step's 16): 13 loads of 8 bytes, 8 lanes on 64 contiguous bytes of a pixel; the transform is 12 / 8
+//     packed subtractions per half-wave (one register per pixel).
+//   * weights per PAIR of fragments (graph.pack_winograd_s2_kernel_b: [Cin/8][8 pairs][cout_pad][4 k][2 fragments][2 k-steps]):
+//     one 16-byte load per lane, chunk and pair.
+//   * epilogue: lane (channel, k) holds tiles 16 th + 4 k + e; per wave an 8 KiB staging image [8 rows][16 px][16 ch], 16-byte
+//     stores of 64-byte runs.
+constexpr int SB_VPOS = 256;                        // floats per slot
+constexpr int SB_VBUF = NSLOT * SB_VPOS + 16;       // floats per chunk buffer
+constexpr int SB_LDS_V = NVBUF * SB_VBUF * 4;       // 106 752 B
+constexpr int SB_LDS = SB_LDS_V > 65536 ? SB_LDS_V : 65536;   // the epilogue stages 8 x 8 KiB
+constexpr int pair_last_user_pos(int q) {           // the last position of a chunk that uses fragment 2q or 2q + 1
+  int last = -1;
+  for (int pp = 0; pp < NPOS; ++pp)
+    if (POS_FRAG[pp] / 2 == q) last = pp;
+  return last;
+}
+
+__global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_s2[];
+  float* const smf = reinterpret_cast<float*>(smem_s2);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap_s2(blockIdx.x, nwg);
+  const int per = p.tiles_m * p.n_group;
+  const int gset = tile / per, rem_ = tile - gset * per;
+  const int tm = rem_ / p.n_group;
+  const int tn = gset * p.n_group + (rem_ - tm * p.n_group);
+  const int cb = tm % p.bw, rb = tm / p.bw;
+  const int n0 = tn * NT + wave * 16;
+
+  const int vr0 = rb * BH;
+  const int img0 = vr0 / p.Th;
+  const int ty0 = vr0 - img0 * p.Th;
+  const int brk = (p.Th - ty0 < BH) ? (p.Th - ty0) : BH;
+  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_rest = p.x_bytes - a_base;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
+      (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u2), 0, p.u_bytes, 0x00020000);
+
+  // ---- PRODUCER: tile (row tr = wave & 3, column tc = 4 (wave >> 2) + ((lane >> 3) & 3)), phase set ps = lane >> 5, channel pair
+  // pq8 = lane & 7 of the super-step's 16 (chunk pq8 >> 2, k = pq8 & 3) ----
+  const int ps = lane >> 5, pq8 = lane & 7;
+  const int ptr_ = wave & 3, ptc = 4 * (wave >> 2) + ((lane >> 3) & 3);
+  unsigned goff[13];
+  {
+    const int img_rel = ptr_ < brk ? 0 : 1;
+    const int ty = ptr_ < brk ? ty0 + ptr_ : ptr_ - brk;
+    const int tx = cb * BW + ptc;
+    const bool tile_ok = (vr0 + ptr_ < p.vrows) && tx < p.Tw;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      const int ua = i < 9 ? 2 * (i / 3) : 2 * ((i - 9) >> 1) + 1, va = i < 9 ? 2 * (i % 3) : 2 * ((i - 9) & 1) + 1;
+      const int ub = i < 6 ? 2 * (i >> 1) : 2 * ((i - 6) / 3) + 1, vb = i < 6 ? 2 * (i & 1) + 1 : 2 * ((i - 6) % 3);
+      const int u = ps ? ub : ua, v = ps ? vb : va;
+      const int yy = 4 * ty + u, xx = 4 * tx + v;
+      const bool ok = tile_ok && yy < p.H && xx < p.W && (i < 12 || ps == 0);
+      goff[i] = ok ? (unsigned)((((img_rel * p.H + yy) * p.W + xx) * p.ldx + pq8 * 2) * 4) : OOBV;
+    }
+  }
+  const int pt = 8 * ptr_ + ptc, pk = pq8 & 3;
+  const int v_st = (pq8 >> 2) * SB_VBUF + ps * 13 * SB_VPOS + pk * 64 + (((pt & 15) ^ pk) * 4) + (pt >> 4) * 2;   // floats
+  const int n_chunks = p.Cin / 8;
+  const int n_super = n_chunks / 2;
+  const int s_last = n_super - 1;
+
+  // ---- CONSUMER ----
+  const int rl = lane & 15, kl = lane >> 4;
+  const int v_lane = kl * 64 + ((rl ^ kl) * 4);                         // floats; + slot * SB_VPOS
+  const unsigned voff_b = (unsigned)(((n0 + rl) * 16 + kl * 4) * 4);
+  const unsigned b_step = (unsigned)p.cout_pad * 64u;                   // bytes between fragment PAIRS
+  const int q_last = n_chunks * (NFRAG / 2) - 1;
+  const int n = n0 + rl;
+  const bool n_ok = n < p.Cout;
+  const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+  f32x4 acc[NACC][2];
+#pragma unroll
+  for (int g = 0; g < NACC; ++g)
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      const float v0 = (g <= D11) ? bv : 0.f;       // the bias rides in the four one-output accumulators
+      acc[g][th] = f32x4{v0, v0, v0, v0};
+    }
+
+  f32x2 pv[13];          // producer: 13 patch pixels x 2 channels
+  f32x4 bq[NFRAG / 2];   // weight fragment pairs of the current chunk
+  f32x4 vq[2][5];        // V fragments: the group in flight and the next one
+
+  auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const int sc = ss < s_last ? ss : s_last;
+    pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, goff[i], (unsigned)(sc * (SS_CH * 4)), 0));
+  };
+  // (d0, d1, d2) -> (d0 - d1, d1, d1 - d2) along the transformed axes; the two half-waves differ (see wino_s2_kernel): lanes
+  // 0-31 the 3x3 (even,even) patch pv[3m+n] rows then columns, lanes 32-63 (even,odd) pv[2m+n] along m and (odd,even)
+  // pv[6+3m+n] along n.  One asm block narrowing EXEC, no control flow in the MFMA stream.
+  auto p_transform = [&]() __attribute__((always_inline)) {
+    asm volatile(
+      "s_mov_b32 exec_hi, 0\n\t"
+      "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %2, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %3, %3, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %8, %7, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %3, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %1, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %4, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %2, %2, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %8, %5, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_mov_b32 exec_lo, 0\n\t"
+      "s_mov_b32 exec_hi, -1\n\t"
+      "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %4, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %3, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %8, %7, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %9, %9, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %11, %10, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_mov_b32 exec_lo, -1\n\t"
+      : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]),
+        "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]));
+  };
+  auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    *reinterpret_cast<f32x2*>(smf + (ss & 1) * (2 * SB_VBUF) + v_st + g * SB_VPOS) = pv[g];
+  };
+  auto b_load = [&](auto qc_, int ch) __attribute__((always_inline)) {     // fragment pair q of chunk ch
+    constexpr int q = decltype(qc_)::value;
+    const int qi = ch * (NFRAG / 2) + q;
+    const int qc = qi < q_last ? qi : q_last;
+    bq[q] = bload(rsU, voff_b, (unsigned)qc * b_step);
+  };
+  auto v_read = [&](auto pc, auto hb, int ch) __attribute__((always_inline)) {
+    constexpr int pp = decltype(pc)::value;
+    constexpr int slot = POS_SLOT[pp];
+    vq[decltype(hb)::value][pp % 5] = *reinterpret_cast<const f32x4*>(smf + (ch & (NVBUF - 1)) * SB_VBUF + slot * SB_VPOS + v_lane);
+  };
+
+  // ---- prologue ----
+  sfor<13>([&](auto ic) { p_gather(ic, 0); });
+  sfor<NFRAG / 2>([&](auto qc_) { b_load(qc_, 0); });
+  p_transform();
+  sfor<13>([&](auto gc) { p_store(gc, 0); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // One super-step = chunks 2ks, 2ks+1: 2 x 100 MFMA slots (5 groups of 5 positions x 2 k-steps x 2 tile halves).
+  constexpr int SPC = 100;
+  constexpr int GSTEP = 8, XSLOT = 150, SSLOT = 160, SSTEP = 2;
+  for (int ks = 0; ks < n_super; ++ks) {
+    const int nxt = ks + 1;
+    sfor<5>([&](auto pc) { v_read(pc, std::integral_constant<int, 0>{}, 2 * ks); });
+    sfor<2>([&](auto cc_) {
+      constexpr int cc = decltype(cc_)::value;
+      const int ch = 2 * ks + cc;
+      sfor<SPC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int G = j / 20, t = (j % 20) / 5, k = j % 5;          // t = 2 s + th: (s, th) = (0,0) (0,1) (1,0) (1,1)
+        constexpr int sk = t / 2, th = t % 2;
+        constexpr int pp = G * 5 + k;
+        constexpr int ia = POS_ACC[pp], ifr = POS_FRAG[pp];
+        constexpr int gi = cc * 5 + G;
+        constexpr int hb = gi % 2;
+        acc[ia][th] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[hb][k][2 * th + sk], bq[ifr / 2][2 * (ifr % 2) + sk], acc[ia][th], 0, 0, 0);
+        // the next chunk's fragment pair, once this chunk is done with both of its fragments
+        if constexpr (t == 3 && pair_last_user_pos(ifr / 2) == pp) b_load(std::integral_constant<int, ifr / 2>{}, ch + 1);
+        // V of the next group during the second quarter of this one
+        if constexpr (t == 1) {
+          if constexpr (G < 4) v_read(std::integral_constant<int, (G + 1) * 5 + k>{}, std::integral_constant<int, hb ^ 1>{}, ch);
+          else if constexpr (cc == 0) v_read(std::integral_constant<int, k>{}, std::integral_constant<int, hb ^ 1>{}, ch + 1);
+        }
+        constexpr int sj = cc * SPC + j;
+        if constexpr (sj < 13 * GSTEP && sj % GSTEP == 0) p_gather(std::integral_constant<int, sj / GSTEP>{}, nxt);
+        if constexpr (sj == XSLOT) p_transform();
+        if constexpr (sj >= SSLOT && sj < SSLOT + 13 * SSTEP && (sj - SSLOT) % SSTEP == 0) p_store(std::integral_constant<int, (sj - SSLOT) / SSTEP>{}, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: 9 accumulators -> 2x2 outputs.  Lane (channel n0 + rl, k = kl), accumulator half th, element e: tile
+  // 16 th + 4 kl + e = (tile row 2 th + (kl >> 1), tile column 4 (kl & 1) + e). ----
+  const bool relu = p.relu != 0;
+  const unsigned long long y_base = (unsigned long long)img0 * p.Ho * p.Wo * p.ldy * 4ull;
+  const unsigned long long y_rest = p.y_bytes - y_base;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+  auto out_transform = [&](auto&& put) __attribute__((always_inline)) {
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int ep = 0; ep < 2; ++ep) {
+        const int e0 = 2 * ep;
+        auto pr = [&](int a) __attribute__((always_inline)) { return f32x2{acc[a][th][e0], acc[a][th][e0 + 1]}; };
+        const f32x2 z0 = pk_add(pr(R0), pr(ZZ)), z1 = pk_add(pr(R1), pr(ZZ));
+        const f32x2 c0 = pr(C0), c1 = pr(C1);
+        const f32x2 o0 = pk_add(pk_add(pr(D00), z0), c0), o1 = pk_add(pk_add(pr(D01), z0), c1);
+        const f32x2 o2 = pk_add(pk_add(pr(D10), z1), c0), o3 = pk_add(pk_add(pr(D11), z1), c1);
+        const int trow = 2 * th + (kl >> 1), ec = 4 * (kl & 1) + e0;      // tile row, tile column inside the block
+        put(o0.x, trow, ec, 0, 0); put(o1.x, trow, ec, 0, 1); put(o2.x, trow, ec, 1, 0); put(o3.x, trow, ec, 1, 1);
+        put(o0.y, trow, ec + 1, 0, 0); put(o1.y, trow, ec + 1, 0, 1); put(o2.y, trow, ec + 1, 1, 0); put(o3.y, trow, ec + 1, 1, 1);
+      }
+  };
+  if (p.wide_store) {
+    // every wave is behind the loop's last barrier: V is dead.  Per wave [8 block rows][16 px][16 ch] floats = 8 KiB.
+    float* const stg = smf + wave * 2048;
+    out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
+      stg[((2 * trow + a) * 16 + 2 * ec + b) * 16 + rl] = v;
+    });
+    __builtin_amdgcn_wave_barrier();
+    const int ox = lane >> 2, nq = lane & 3;             // store lane: block pixel column ox, channel quad nq
+    const int ox0 = 2 * cb * BW;
+    const bool q_ok = n0 + nq * 4 < p.Cout && ox0 + ox < p.Wo;
+    const unsigned voff_q = q_ok ? (unsigned)(((ox0 + ox) * p.ldy + n0 + nq * 4) * 4) : OOBV;
+    const int pix_bytes = p.ldy * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + (i * 16 + ox) * 16 + nq * 4);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int trow = i >> 1, a = i & 1;
+      const int img_rel = trow < brk ? 0 : 1;
+      const int ty = trow < brk ? ty0 + trow : trow - brk;
+      const int oy = 2 * ty + a;
+      const bool row_ok = vr0 + trow < p.vrows && oy < p.Ho;        // uniform
+      const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo) * pix_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             rsY, row_ok ? voff_q : OOBV, soff, KFN_NT_STORE_AUX);
+    }
+  } else {
+    const int pix_bytes = p.ldy * 4;
+    out_transform([&](float v, int trow, int ec, int a, int b) __attribute__((always_inline)) {
+      const int img_rel = trow < brk ? 0 : 1;
+      const int ty = trow < brk ? ty0 + trow : trow - brk;
+      const int oy = 2 * ty + a;
+      v = relu ? fmaxf(v, 0.f) : v;
+      const int tx = cb * BW + ec;
+      const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo + 2 * tx + b) * pix_bytes);
+      const bool ok = n_ok && tx < p.Tw && 2 * tx + b < p.Wo && vr0 + trow < p.vrows && oy < p.Ho;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, ok ? (unsigned)(n * 4) : OOBV, soff, 0);
+    });
+  }
+}
+
 }  // namespace
 
 // Can the polyphase kernel take this layer?  (host-side routing; no device access)
@@ -499,6 +762,16 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   a.y_bytes = (unsigned long long)(((out_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * (h16 ? 2L : 4L));
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(64 * NWAVE);
+  if (d->wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE) {
+    // the eight-wave form: fp32 operands only, weights packed per pair of fragments (graph.pack_winograd_s2_kernel_b)
+    if (h16) return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2: the eight-wave form takes fp32 operands only");
+    static std::atomic<uint64_t> attr_done_b{0};
+    int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2b_kernel), SB_LDS, attr_done_b);
+    if (rc != KFN_OK) return rc;
+    hipLaunchKernelGGL(wino_s2b_kernel, grid, dim3(512), SB_LDS, (hipStream_t)stream, a);
+    KFN_LAUNCH_CHECK("wino_s2b_kernel");
+    return KFN_OK;
+  }
   if (h16) {
     static std::atomic<uint64_t> attr_done16{0};
     int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2_kernel<true>), VLayoutS2<true>::LDS, attr_done16);

@@ -330,6 +330,17 @@ def pack_winograd_s2_kernel(w):
     return np.ascontiguousarray(out.reshape(16, cp, ci // 8, 8).transpose(2, 0, 1, 3))
 
 
+def pack_winograd_s2_kernel_b(w):
+    """The same 16 fragments for the EIGHT-WAVE form of kfn_conv2d_winograd_s2 (kfn_conv_desc.wino_form =
+    KFN_WINO_FORM_S2_EIGHT_WAVE, wino_s2b_kernel): [Cin/8][8 fragment pairs][cout_pad][4 k][2 fragments][2 k-steps] -- lane
+    (channel n, k) of a 16x16x4 B operand reads 16 contiguous bytes per (chunk, pair): fragments 2q and 2q + 1, input channels
+    2k and 2k + 1."""
+    u = pack_winograd_s2_kernel(w)                      # [Cin/8][16][cp][8]
+    nc, _, cp, _ = u.shape
+    v = u.reshape(nc, 8, 2, cp, 4, 2)                   # [chunk][pair][f][n][k][s]
+    return np.ascontiguousarray(v.transpose(0, 1, 3, 4, 2, 5).reshape(nc, 8, cp, 16))
+
+
 def as_f16(pack):
     """Wrap a weight packer so that the packed matrix is stored as IEEE halfs (fp16-operand convs)."""
     def f(w):
@@ -651,8 +662,17 @@ class WinogradS2ConvOp(ConvOp):
     """3x3 stride-2 SAME conv of an even-sized image through kfn_conv2d_winograd_s2 (polyphase + F(2,2):
     25 MFMA streams into 9 accumulators per 2x2 outputs instead of 36 direct taps)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32):
+    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32, eight_wave=False):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu, operand_dtype=operand_dtype)
+        # wino_s2b_kernel (two waves per SIMD on 16x16x4 MFMA tiles; fp32 operands; weights packed per pair of fragments,
+        # pack_winograd_s2_kernel_b) instead of wino_s2_kernel
+        self.eight_wave = bool(eight_wave) and operand_dtype == _lib.OPERAND_F32
+
+    def desc(self):
+        d = ConvOp.desc(self)
+        if self.eight_wave:
+            d.wino_form = _lib.WINO_FORM_S2_EIGHT_WAVE
+        return d
 
     @staticmethod
     def supported(x_shape, cin, cout):
@@ -660,6 +680,8 @@ class WinogradS2ConvOp(ConvOp):
         return cin % 16 == 0 and h % 2 == 0 and w % 2 == 0 and (h // 2 + 1) // 2 >= 4
 
     def kernel_name(self, lib):
+        if self.eight_wave:
+            return 'wino_s2b_kernel'
         return 'wino_s2_kernel<true>' if self.operand_dtype == _lib.OPERAND_F16 else 'wino_s2_kernel'
 
     def mfma_flops(self):
@@ -1177,6 +1199,9 @@ class Graph(object):
         # the eight-wave form of the F(4x4,3x3) kernel (wino4b_kernel; measured at batch 32 against the four-wave form, same
         # box: conv1b 2.66 -> 2.34 ms, conv2b 6.98 -> 6.54, conv3b 6.43 -> 6.13, conv4b 6.08 -> 5.85)
         self.winograd_f43_eight_wave = True
+        # ... and of the stride-2 polyphase kernel (wino_s2b_kernel; batch 32, same box: conv2a 4.65 -> 4.54 ms, conv3a 7.35 ->
+        # 7.22, conv4a 7.19 -> 7.09)
+        self.winograd_s2_eight_wave = True
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

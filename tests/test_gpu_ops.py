@@ -920,15 +920,17 @@ S2_CASES = [(1, 16, 16, 16, 128), (2, 14, 18, 32, 160), (1, 120, 160, 64, 128), 
             (5, 20, 24, 16, 8), (2, 60, 80, 256, 256), (17, 14, 16, 32, 136), (1, 64, 96, 512, 128)]
 
 
+@pytest.mark.parametrize('form', [0, 4])      # four waves (wino_s2_kernel), KFN_WINO_FORM_S2_EIGHT_WAVE (wino_s2b_kernel)
 @pytest.mark.parametrize('relu', [1, 0])
 @pytest.mark.parametrize('case', S2_CASES)
-def test_winograd_s2_vs_oracle(case, relu):
-    """kfn_conv2d_winograd_s2 (polyphase + F(2,2): 25 MFMA streams into 9 accumulators per 2x2 outputs) == the
-    oracle's stride-2 SAME convolution up to fp32 round-off; strided output window, guard rows untouched."""
+def test_winograd_s2_vs_oracle(case, relu, form):
+    """kfn_conv2d_winograd_s2 (polyphase + F(2,2): 25 MFMA streams into 9 accumulators per 2x2 outputs; four waves on 32x32x2
+    MFMA tiles or eight on 16x16x4) == the oracle's stride-2 SAME convolution up to fp32 round-off; strided output window
+    (ldy = Cout + 8: the 16-byte store path when Cout % 4 == 0, the dword path otherwise), guard rows untouched."""
     import torch
     from tests.gpu_util import dev, stream, sync
     from kfnet_amd import _lib
-    from kfnet_amd.graph import pack_winograd_s2_kernel
+    from kfnet_amd.graph import pack_winograd_s2_kernel, pack_winograd_s2_kernel_b
     lib = _lib.load()
     n, h, w, ci, co = case
     ho, wo = h // 2, w // 2
@@ -938,11 +940,11 @@ def test_winograd_s2_vs_oracle(case, relu):
     b = rng.normal(size=co).astype(np.float32)
     ldy = co + 8
     d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
-                      stride=2, relu=relu)
+                      stride=2, relu=relu, wino_form=form)
     assert lib.kfn_winograd_s2_supported(C.byref(d)) == 1
     GUARD = 64
     y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
-    dx, du, db = dev(x), dev(pack_winograd_s2_kernel(wt)), dev(b)
+    dx, du, db = dev(x), dev((pack_winograd_s2_kernel_b if form == 4 else pack_winograd_s2_kernel)(wt)), dev(b)
     _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
                                           stream()), 'wino_s2')
     sync()

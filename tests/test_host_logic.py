@@ -113,7 +113,16 @@ def test_default_routes_of_the_3x3_layers():
         assert ub[ci // 8, pp // 2, co, 4 * ((ci % 8) // 2) + 2 * (pp % 2) + ci % 2] == ua[ci // 8, pp, co, ci % 8]
     assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
     for n in ('conv2a', 'conv3a', 'conv4a', 'feat6'):
-        assert names[n] == 'wino_s2_kernel', (n, names[n])
+        assert names[n] == 'wino_s2b_kernel', (n, names[n])      # the eight-wave form (Graph.winograd_s2_eight_wave)
+    gs, _ = _build(4, winograd_s2_eight_wave=False)
+    ks = [op for op in gs.ops if op.name == 'conv3a'][0]
+    assert ks.kernel_name(lib) == 'wino_s2_kernel' and ks.kernel.pack.__name__ == 'pack_winograd_s2_kernel' and ks.desc().wino_form == 0
+    from kfnet_amd.graph import pack_winograd_s2_kernel, pack_winograd_s2_kernel_b
+    ws = np.random.default_rng(6).normal(size=(3, 3, 16, 40)).astype(np.float32)
+    sa, sb = pack_winograd_s2_kernel(ws), pack_winograd_s2_kernel_b(ws)
+    assert sa.shape == (2, 16, 64, 8) and sb.shape == (2, 8, 64, 16)
+    for (ci, co, f) in [(0, 0, 0), (13, 39, 15), (6, 17, 9), (9, 5, 4)]:
+        assert sb[ci // 8, f // 2, co, 4 * ((ci % 8) // 2) + 2 * (f % 2) + ci % 2] == sa[ci // 8, f, co, ci % 8]
     by_name = {}
     for op in g.ops:
         by_name.setdefault(op.name, op)

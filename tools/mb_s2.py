@@ -23,7 +23,8 @@ for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320,
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     y = torch.empty(N * (H // 2) * (W // 2) * co, device='cuda')
     F16 = os.environ.get('MB_F16', '') == '1'
-    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, wino_order=ORDER)
+    d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, wino_order=ORDER,
+                      wino_form=int(os.environ.get('MB_S2_FORM', '0')))   # 4 = the eight-wave form (wino_s2b_kernel)
     d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16, wino_order=ORDER)
     if F16:
         u = u.half(); w9 = w9.half()
