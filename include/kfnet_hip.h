@@ -41,7 +41,7 @@ extern "C" {
 /* 5 (round 4): kfn_conv_desc starts with `struct_size` (the struct had grown at its end -- weights_path -- without a
  * version bump); kfn_comm_rank asks RCCL; kfn_kalman_scan_ex no longer allocates.  A host checks
  * kfn_abi_version() == KFN_ABI_VERSION once after loading the library. */
-#define KFN_ABI_VERSION 5
+#define KFN_ABI_VERSION 6
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -260,6 +260,12 @@ int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void
  * below 1 GiB, fp32 operands and activations, no fused head epilogue (kfn_winograd_f43_supported() == 1);
  * KFN_ERR_UNSUPPORTED otherwise. */
 int kfn_winograd_f43_supported(const kfn_conv_desc* desc);
+/* Dynamic LDS (bytes per workgroup) of the kernel the matching Winograd entry point launches for `desc`: stride 2 ->
+ * kfn_conv2d_winograd_s2 (wino_form AUTO / KFN_WINO_FORM_S2_EIGHT_WAVE), stride 1 with wino_form KFN_WINO_FORM_F43_* ->
+ * kfn_conv2d_winograd_f43, any other stride-1 descriptor -> the form kfn_conv2d_winograd_fused routes it to.  A host
+ * compares it with kfn_device_info()'s lds_bytes_per_cu and routes around kernels the device cannot hold (147-157 KB for
+ * the F(4x4,3x3) and four-wave F(2x2,3x3) forms) instead of failing in the first launch.  No device access.  (ABI 6) */
+int kfn_winograd_lds_bytes(const kfn_conv_desc* desc, int* bytes);
 int kfn_conv2d_winograd_f43(const kfn_conv_desc* desc, const float* x, const float* u4_packed, const float* bias,
                             float* y, void* stream);
 

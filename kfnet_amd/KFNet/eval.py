@@ -113,9 +113,21 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         weights, image_size=image_size, batch=batch, transform=transform, reset_period=sequence_length,
         nis_gate=7.815 if nis else 0.0, max_chunk=chunk, emit_metrics=want_metrics, device=device)
     if engine is not None:
+        # a supplied engine carries its own settings; an argument that DISAGREES with them must not be dropped silently
+        # (eval(..., nis=True, engine=eng_without_gate) used to return ungated records)
         chunk = min(chunk, eng.max_chunk)
         if want_metrics and not eng.emit_metrics:
             raise ValueError('labels given, but the engine was built without emit_metrics')
+        if bool(nis) != (eng.nis_gate > 0.0):
+            raise ValueError('eval(nis=%r) disagrees with the engine (nis_gate=%g)' % (nis, eng.nis_gate))
+        if int(sequence_length) != int(eng.reset_period):
+            raise ValueError('eval(sequence_length=%d) disagrees with the engine (reset_period=%d)'
+                             % (sequence_length, eng.reset_period))
+        if tuple(image_size) != (eng.H, eng.W):
+            raise ValueError('eval(image_size=%r) disagrees with the engine (%dx%d)' % (tuple(image_size), eng.H, eng.W))
+        t_arg = None if transform is None else np.asarray(transform, dtype=np.float32)
+        if (t_arg is None) != (eng.transform is None) or (t_arg is not None and not np.array_equal(t_arg, eng.transform)):
+            raise ValueError('eval(transform=...) disagrees with the transform the engine was built with')
     records, all_metrics = [], []
     # coord_<i>.npy (KFNet/eval.py:121-126) written off the consumer thread: the next chunk's records can be
     # fetched while the previous chunk's 76.8 KB files are still going to disk
@@ -155,21 +167,23 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         plan[k] = (lo, n, pairs)
 
     k = 0
-    for lo, rec in StreamedSequence(eng, chunk).run(loader, after_process=after_process if want_metrics else None):
-        emit(lo, rec.copy())
-        if want_metrics:
-            first, n, pairs = plan.pop(k)
-            for m in dm.collect(k & 1, first, n, pairs):
-                all_metrics.append(m)
-                if verbose:
-                    print(M.format_line(m))
-        elif verbose:
-            print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
-        k += 1
-    for f in pending_saves:
-        f.result()          # re-raise write errors; every file is on disk when eval() returns
-    if saver is not None:
-        saver.shutdown()
+    try:
+        for lo, rec in StreamedSequence(eng, chunk).run(loader, after_process=after_process if want_metrics else None):
+            emit(lo, rec.copy())
+            if want_metrics:
+                first, n, pairs = plan.pop(k)
+                for m in dm.collect(k & 1, first, n, pairs):
+                    all_metrics.append(m)
+                    if verbose:
+                        print(M.format_line(m))
+            elif verbose:
+                print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
+            k += 1
+        for f in pending_saves:
+            f.result()          # re-raise write errors; every file is on disk when eval() returns
+    finally:
+        if saver is not None:   # also when the loop raised: no writer thread outlives the call
+            saver.shutdown()
     records = np.concatenate(records) if records else np.zeros((0, eng.h, eng.w, 4), np.float32)
     if not want_metrics:
         return records

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
@@ -80,6 +80,7 @@ SYMBOLS = {
     'kfn_winograd_s2_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_conv2d_winograd_f43': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_f43_supported': (_i, [C.POINTER(ConvDesc)]),
+    'kfn_winograd_lds_bytes': (_i, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     'kfn_conv3x3_c64_f16': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_conv3x3_c64_f16_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),

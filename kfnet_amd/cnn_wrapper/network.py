@@ -104,11 +104,20 @@ class Network(object):
     def load(self, data_path, session=None, ignore_missing=False):
         """Weights from the reference's numpy dict format {op_name: {param_name: array}}
         (network.py:60-75).  `session` is accepted for signature compatibility; the arrays go
-        to the graph's device buffers under the variable scope active at call time."""
+        to the graph's device buffers under the variable scope active at call time.  The reference's rule: every entry
+        of the file is assigned to the variable <scope>/<op_name>/<param_name>; an entry WITHOUT such a variable raises
+        unless `ignore_missing` -- variables the file does not mention keep what they hold (a per-scope file therefore
+        loads into a graph that also holds the other scope's networks, KFNet/eval.py:66-68)."""
         from ..graph import current_scope
         from ..weights import from_network_load_dict
         table = np.load(data_path, allow_pickle=True).item()
-        self.graph.load_weights(from_network_load_dict(table, current_scope()), strict=not ignore_missing)
+        flat = from_network_load_dict(table, current_scope())
+        g = self.graph
+        known = set(p.source for p in g.params.values())
+        unknown = sorted(k for k in flat if k not in known)
+        if unknown and not ignore_missing:
+            raise ValueError('Network.load: no variable for %s (ignore_missing=False)' % ', '.join(unknown[:4]))
+        g.load_weights(dict((k, v) for k, v in flat.items() if k in known), strict=False)
 
     def feed(self, *args):
         """Select the input(s) of the next layer call: layer names or tensors."""
@@ -157,14 +166,22 @@ class Network(object):
         if len(hits) != 1:
             raise KeyError('set_epilogue: %d convolution launches are named %r' % (len(hits), layer_name))
         op = hits[0]
-        if isinstance(op, (WinogradConvOp, WinogradFusedConvOp, WinogradS2ConvOp)):
+        if isinstance(op, (WinogradConvOp, WinogradFusedConvOp, WinogradS2ConvOp, WinogradF43ConvOp, Conv64RowsF16Op)):
             if op.kernel.storage is not None:
-                raise RuntimeError('set_epilogue(%r): weights are already packed for the Winograd kernel' % layer_name)
+                raise RuntimeError('set_epilogue(%r): weights are already packed for the %s kernel'
+                                   % (layer_name, type(op).__name__))
             # in place (the op object may already sit in other launch lists): same tensors and
-            # variables, direct-kernel weight layout
-            op.kernel.pack = _direct_pack
+            # variables, direct-kernel weight layout.  The fp16-operand forms keep their operand type: the direct
+            # kernel reads fp16 activations with chunk-major weights (Network.conv's own rule for that case).
+            if op.operand_dtype == _lib.OPERAND_F16:
+                chunked = op.x.dtype == 'f16' or op.y.dtype == 'f16'
+                op.kernel.pack = as_f16(pack_conv_kernel_chunked if chunked else _direct_pack)
+            else:
+                op.kernel.pack = _direct_pack
             op.__class__ = ConvOp
             op.workspace = None
+            for attr in ('eight_wave',):        # routing state of the class the op just left (desc() no longer reads it)
+                op.__dict__.pop(attr, None)
             op.epilogue = epilogue
             return op
         if op.operand_dtype == _lib.OPERAND_F32 and op.y.shape[3] > 32 and epilogue == _lib.EPI_L2NORM:
@@ -271,16 +288,18 @@ class Network(object):
         fmin = g.winograd_fused_min_channels
         fused_ok = (k == 3 and strides == 1 and g.winograd_fused and fmin and cin >= fmin and filters >= fmin
                     and cin <= g.winograd_fused_max_channels
-                    and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters))
+                    and min(h, w) >= 8 and WinogradFusedConvOp.supported(input.shape, cin, filters)
+                    and g.winograd_lds_fits(1, cin, filters))
         # A launch of fewer than winograd_f43_min_workgroups workgroups (of 32 tiles x 64 channels, one per CU) leaves
         # most of the 256 CUs idle and the smaller F(2x2,3x3) workgroups win -- single frames only (batch 1, F(4x4) ->
         # F(2x2): conv5 80 workgroups 0.287 -> 0.238 ms, conv6 40: 0.151 -> 0.123, feat5 40: 0.031 -> 0.022; from 160
         # workgroups up F(4x4) is ahead: conv4b at batch 1 0.288 against 0.479; profiles/r04_wino4_microbench.log, r4z)
         f43_fills = (not fused_ok
                      or WinogradF43ConvOp.workgroups(input.shape, filters) >= g.winograd_f43_min_workgroups)
+        e8 = bool(g.winograd_f43_eight_wave)
         if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43 and f43_fills
-                and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld)):
-            e8 = bool(g.winograd_f43_eight_wave)
+                and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld, y.ld, y.ch_off)
+                and g.winograd_lds_fits(1, cin, filters, _lib.WINO_FORM_F43_EIGHT_WAVE if e8 else _lib.WINO_FORM_F43_FOUR_WAVE)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel_b if e8 else pack_winograd_f43_kernel)
             self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
             return y
@@ -292,9 +311,10 @@ class Network(object):
             return y
         smin = g.winograd_s2_min_channels
         # 3x3 stride-2 layers (SCoordNet conv2a / conv3a / conv4a): polyphase + F(2,2), 25/36 of the direct MFMAs
+        e8 = bool(g.winograd_s2_eight_wave)
         if (k == 3 and strides == 2 and smin and cin >= smin and filters >= 128
-                and WinogradS2ConvOp.supported(input.shape, cin, filters)):
-            e8 = bool(g.winograd_s2_eight_wave)
+                and WinogradS2ConvOp.supported(input.shape, cin, filters)
+                and g.winograd_lds_fits(2, cin, filters, _lib.WINO_FORM_S2_EIGHT_WAVE if e8 else 0)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel_b if e8 else pack_winograd_s2_kernel)
             self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
             return y

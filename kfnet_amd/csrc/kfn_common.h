@@ -59,6 +59,13 @@ inline int set_max_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Dynamic LDS (bytes per workgroup) of the kernels behind the Winograd entry points -- what kfn_winograd_lds_bytes()
+// answers; each is defined beside the kernel it describes.  < 0: no such form in that file.
+int wino_f43_lds_bytes(int wino_form);     // kfn_wino4.hip: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE
+int wino_s2_lds_bytes(int wino_form, int operand_dtype);   // kfn_wino_s2.hip: AUTO (four waves) / KFN_WINO_FORM_S2_EIGHT_WAVE
+int wino_fused_lds_bytes(const kfn_conv_desc* d);   // kfn_wino3.hip: the form kfn_conv2d_winograd_fused routes `d` to
+constexpr int WINO2_LDS_BYTES = 2 * 16384;          // wino2_kernel's two raw-patch buffers (kfn_wino2.hip asserts it)
+
 // kfn_conv_desc crosses the ABI by pointer and grows at its end; `struct_size` (first member) says how many bytes the
 // CALLER's object has.  Every entry point works on a full-size copy whose missing tail is zero (= AUTO / fp32
 // defaults) and never touches the caller's memory beyond struct_size.

@@ -58,6 +58,7 @@ constexpr int BUF_BYTES = 16384;        // >= RH * RPITCH, a power of two: the o
 constexpr int NB = 8;                   // depth of the B register ring (transform positions ahead); must divide 16
 
 static_assert(BUF_BYTES >= RH * RPITCH + 32 * 16 && (BUF_BYTES & (BUF_BYTES - 1)) == 0, "buffer toggle by XOR");
+static_assert(2 * BUF_BYTES == kfn::WINO2_LDS_BYTES, "kfn_winograd_lds_bytes() quotes this size");
 static_assert(16 % NB == 0, "the ring slot of a position is (position % 16) % NB");
 
 struct Wino2Args {

@@ -512,6 +512,15 @@ unsigned long long* g_wino3_prof = nullptr;
 
 namespace kfn {
 
+// (the routing rule of kfn_conv2d_winograd_fused, kfn_wino2.hip, without its byte-range conditions)
+int wino_fused_lds_bytes(const kfn_conv_desc* d) {
+  const bool h16 = d->operand_dtype == KFN_OPERAND_F16;
+  const bool one = d->wino_form == KFN_WINO_FORM_ONE_WAVE;
+  if ((!one || h16) && d->Cout >= 128 && d->Cin % 32 == 0) return 8 * (h16 ? VLayout<true>::VBUF : VLayout<false>::VBUF);
+  if (!one && !h16 && d->cout_pad == 64 && d->Cin % 16 == 0) return 4 * VLayout<false>::VBUF;
+  return h16 ? -1 : WINO2_LDS_BYTES;
+}
+
 // Launch of the 4-wave form (Cin % 32 == 0, Cout >= 128) or the two-wave form (cout_pad == 64, Cin % 16 == 0) for
 // a descriptor kfn_conv2d_winograd_fused has already validated.  Called from kfn_wino2.hip.
 int launch_wino3(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias, float* y,

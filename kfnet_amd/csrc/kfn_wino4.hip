@@ -57,7 +57,7 @@ constexpr int CPS = 2;                     // chunks of 8 input channels per sup
 constexpr int VHALF = 32 * 16 + 32;        // one k-half of a position: [32 tiles][4 floats] + pad (8 dwords: see below)
 constexpr int VPOS = 2 * VHALF;
 constexpr int VBUF = NPOS * VPOS + 16;     // one chunk; the pad puts the two chunks of a super-step 4 dwords apart mod 32
-constexpr int LDS_V = 2 * CPS * VBUF;      // 156 928 B
+constexpr int LDS_V = 2 * CPS * VBUF;      // 156 736 B
 constexpr int LDS_OUT = 32 * 16 * 64 * 4;  // 131 072 B: the output image of the epilogue (overlays the V buffers)
 #ifndef KFN_W4_NB
 #define KFN_W4_NB 9
@@ -1089,7 +1089,32 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
 unsigned long long* g_wino4_prof = nullptr;
 #endif
 
-// Can the F(4x4,3x3) kernel take this layer?  (host-side routing; no device access)
+int kfn::wino_f43_lds_bytes(int wino_form) {
+  if (wino_form == KFN_WINO_FORM_F43_FOUR_WAVE) return LDS_V;
+  if (wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE) return B_LDS;
+  return -1;
+}
+
+// Dynamic LDS per workgroup of the kernel a Winograd entry point launches for `desc` (stride 1: kfn_conv2d_winograd_f43
+// when wino_form names one of its two forms, else kfn_conv2d_winograd_fused's routing; stride 2: kfn_conv2d_winograd_s2),
+// so that a host can route around kernels a device's LDS cannot hold (kfn_device_info's lds_bytes_per_cu) instead of
+// failing in the first launch.  No device access.
+extern "C" int kfn_winograd_lds_bytes(const kfn_conv_desc* d, int* bytes) {
+  KFN_REQUIRE(d && bytes, "kfn_winograd_lds_bytes: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_winograd_lds_bytes");
+  KFN_REQUIRE(d->kh == 3 && d->kw == 3 && (d->stride == 1 || d->stride == 2) && !d->transposed,
+              "kfn_winograd_lds_bytes: the Winograd kernels take 3x3 stride-1 / stride-2 convolutions only");
+  int b;
+  if (d->stride == 2) b = kfn::wino_s2_lds_bytes(d->wino_form, d->operand_dtype);
+  else if (d->wino_form == KFN_WINO_FORM_F43_FOUR_WAVE || d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE) b = kfn::wino_f43_lds_bytes(d->wino_form);
+  else b = kfn::wino_fused_lds_bytes(d);
+  if (b < 0) return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_winograd_lds_bytes: no kernel for wino_form %d at stride %d", d->wino_form, d->stride);
+  *bytes = b;
+  return KFN_OK;
+}
+
+// Can the F(4x4,3x3) kernel take this layer?  (host-side routing; no device access.  Mirrors every check of the launcher
+// that does not need the pointers: what remains there is the 16-byte alignment of y / u4_packed / bias and 8-byte of x.)
 extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
   kfn_conv_desc d_full;
   if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_f43_supported") != KFN_OK) return 0;
@@ -1099,8 +1124,13 @@ extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
   if (d->Cin <= 0 || d->Cin % 16 != 0) return 0;
   if ((d->H + 3) / 4 < BH4) return 0;               // an 8-row tile block may straddle at most two images
   if (d->epilogue != KFN_EPI_NONE) return 0;
-  if (d->cout_pad % 32 != 0 || d->Cout % 4 != 0 || d->ldy % 4 != 0 || d->ldx % 2 != 0) return 0;
-  if (2L * d->H * d->W * d->ldx * 4L >= (1L << 30)) return 0;
+  if (d->N <= 0 || d->W <= 0 || d->Cout <= 0) return 0;
+  if (d->cout_pad % 32 != 0 || d->cout_pad < d->Cout || d->Cout % 4 != 0 || d->ldy % 4 != 0 || d->ldx % 2 != 0) return 0;
+  if (d->ldx < d->Cin || d->ldy < d->Cout) return 0;
+  if (2L * d->H * d->W * d->ldx * 4L >= (1L << 30)) return 0;            // two images of the input below 1 GiB
+  if (2L * d->H * d->W * d->ldy * 4L >= (1L << 31)) return 0;            // ... of the output below 2 GiB
+  if (36L * d->cout_pad * d->Cin * 4L >= (1L << 31)) return 0;           // the transformed kernel below 2 GiB
+  if ((long)d->N * ((d->H + 3) / 4) >= (1L << 30)) return 0;
   return 1;
 }
 

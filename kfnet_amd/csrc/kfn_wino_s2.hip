@@ -691,6 +691,12 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
 }  // namespace
 
 // Can the polyphase kernel take this layer?  (host-side routing; no device access)
+int kfn::wino_s2_lds_bytes(int wino_form, int operand_dtype) {
+  if (wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE) return operand_dtype == KFN_OPERAND_F32 ? SB_LDS : -1;
+  if (wino_form != KFN_WINO_FORM_AUTO) return -1;
+  return operand_dtype == KFN_OPERAND_F16 ? VLayoutS2<true>::LDS : VLayoutS2<false>::LDS;
+}
+
 extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
   kfn_conv_desc d_full;
   if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_s2_supported") != KFN_OK) return 0;

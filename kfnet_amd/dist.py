@@ -138,8 +138,19 @@ def _all_ranks_ok(dist, ok, device_index):
     """MIN over ranks of a success flag (collective: every rank of the group must call it)."""
     import torch
     on_gpu = dist.get_backend() == 'nccl' and torch.cuda.is_available()
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                        device=torch.device('cuda', int(device_index)) if on_gpu else 'cpu')
+    dev = 'cpu'
+    if on_gpu:
+        # The flag must reach the all_reduce on EVERY rank, above all on the rank whose device index is the thing that
+        # failed: an index that is no integer or out of range falls back to the process's current device (where the
+        # nccl process group lives anyway) instead of raising here and leaving the peers blocked in the reduction.
+        try:
+            idx = int(device_index)
+        except (TypeError, ValueError):
+            idx = -1
+        if not (0 <= idx < torch.cuda.device_count()):
+            idx = torch.cuda.current_device()
+        dev = torch.device('cuda', idx)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(int(flag.item()))
 
@@ -183,7 +194,7 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
             buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
             _lib.check(lib.kfn_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'kfn_comm_unique_id')
             uid = bytes(buf.raw)
-    except (_lib.KfnError, OSError) as e:
+    except (_lib.KfnError, OSError, TypeError, ValueError) as e:     # (int(None) / int('x'): a bad index is a local failure too)
         why = e
     link = None
     if _all_ranks_ok(dist, why is None, device_index):

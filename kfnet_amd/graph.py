@@ -583,10 +583,34 @@ class WinogradF43ConvOp(ConvOp):
         return d
 
     @staticmethod
-    def supported(x_shape, cin, cout, ldx=None):
+    def supported(x_shape, cin, cout, ldx=None, ldy=None, y_ch_off=0):
+        """Mirror of kfn_winograd_f43_supported (+ the launcher's 16-byte alignment of y, which for a tensor is "pixel
+        stride and channel offset multiples of 4": a concat slice at an odd offset must take another route -- the fused
+        F(2x2) and stride-2 kernels have a dword-store path for it, this kernel has not)."""
         n, h, w, _ = x_shape
         ldx = cin if ldx is None else ldx
-        return cin % 16 == 0 and (h + 3) // 4 >= 8 and cout % 4 == 0 and 2 * h * w * ldx * 4 < (1 << 30)
+        ldy = cout if ldy is None else ldy
+        return (cin % 16 == 0 and (h + 3) // 4 >= 8 and cout % 4 == 0 and ldx % 2 == 0 and ldx >= cin and ldy >= cout
+                and ldy % 4 == 0 and y_ch_off % 4 == 0
+                and 2 * h * w * ldx * 4 < (1 << 30) and 2 * h * w * ldy * 4 < (1 << 31)
+                and 36 * (-(-cout // 32) * 32) * cin * 4 < (1 << 31))
+
+    def resolve(self):
+        """Graph.finalize: a later concat may have re-bound the output into a wider buffer; if the F(4x4,3x3) launcher
+        would now reject it, fall back to the fused F(2x2,3x3) kernel (dword stores for unaligned outputs) or the direct
+        one -- the weights are not packed yet."""
+        n, h, w, cin = self.x.shape
+        if self.supported(self.x.shape, cin, self.y.shape[3], self.x.ld, self.y.ld, self.y.ch_off):
+            return
+        if self.kernel.storage is not None:
+            raise _lib.KfnError('%s: weights already packed for the F(4x4,3x3) kernel' % self.name)
+        self.__dict__.pop('eight_wave', None)
+        if WinogradFusedConvOp.supported(self.x.shape, cin, self.y.shape[3]) and min(h, w) >= 8:
+            self.kernel.pack = pack_winograd_fused_kernel
+            self.__class__ = WinogradFusedConvOp
+        else:
+            self.kernel.pack = pack_conv_kernel
+            self.__class__ = ConvOp
 
     @staticmethod
     def workgroups(x_shape, cout):
@@ -1224,6 +1248,17 @@ class Graph(object):
         self.f16_activation_scopes = ('ScoreNet',)
         self.f16x3_min_channels = 64
         self.active = (1, 1)  # (frames in this launch, frames the graph was built for)
+
+    def winograd_lds_fits(self, stride, cin, cout, wino_form=0, operand_dtype=_lib.OPERAND_F32):
+        """Does the Winograd kernel that would be launched for this 3x3 layer fit this device's LDS?  (kfn_winograd_lds_bytes
+        against lds_bytes_per_cu: the F(4x4,3x3) and four-wave forms need 144-157 KB of the 160 KiB a gfx950 CU has; on a
+        part with less Network.conv falls through to the next route instead of failing in the first launch.)"""
+        d = _lib.ConvDesc(N=1, H=64, W=64, Cin=cin, ldx=cin, Cout=cout, cout_pad=-(-cout // 32) * 32, ldy=cout, kh=3, kw=3,
+                          stride=stride, operand_dtype=operand_dtype, wino_form=wino_form)
+        nb = C.c_int(0)
+        if _lib.load().kfn_winograd_lds_bytes(C.byref(d), C.byref(nb)) != _lib.KFN_OK:
+            return False
+        return nb.value <= self.lds_bytes_per_cu
 
     # -- construction -------------------------------------------------------------------
     def placeholder(self, shape, dtype='f32', name=None):

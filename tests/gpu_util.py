@@ -72,3 +72,57 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     mask[y_off:y_off + cout] = False
     assert np.all(yh[:, mask] == -123.0), 'conv wrote outside its channel window'
     return out
+
+
+def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, config=0):
+    """One launch of a minimal-filtering entry point on x [N,H,W,Cin] fp32 with the TF-layout 3x3 kernel wt:
+      kind 'wino'  kfn_conv2d_winograd        (two kernels + workspace; F(2x2,3x3))
+           'fused' kfn_conv2d_winograd_fused  (form 0 = the library's routing, 1 = KFN_WINO_FORM_ONE_WAVE)
+           'f43'   kfn_conv2d_winograd_f43    (form 2 = four waves, 3 = eight waves)
+           's2'    kfn_conv2d_winograd_s2     (stride 2; form 0 = four waves, 4 = eight waves)
+    Input and output live in wider buffers (ldx = Cin + ldx_pad filled with 9.0 behind Cin, ldy = Cout + ldy_pad); guard
+    rows behind the output and the columns behind Cout must come back untouched.  Returns y [N,Ho,Wo,Cout] np fp32."""
+    import torch
+    from kfnet_amd.graph import (pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_fused_kernel,
+                                 pack_winograd_kernel, pack_winograd_s2_kernel, pack_winograd_s2_kernel_b)
+    lib = _lib.load()
+    n, h, w, ci = x.shape
+    co = wt.shape[3]
+    stride = 2 if kind == 's2' else 1
+    ho, wo = -(-h // stride), -(-w // stride)
+    ldx, ldy = ci + ldx_pad, co + ldy_pad
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=stride, relu=int(relu), wino_form=form, config=config)
+    xb = np.full((n * h * w, ldx), 9.0, dtype=np.float32)
+    xb[:, :ci] = x.reshape(-1, ci)
+    GUARD = 64
+    y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
+    dx = dev(xb)
+    db = dev(np.concatenate([b, np.zeros((-co) % 4, np.float32)]).astype(np.float32)) if b is not None else None
+    bp = db.data_ptr() if db is not None else None
+    if kind == 'wino':
+        nb = C.c_size_t()
+        _lib.check(lib.kfn_winograd_workspace_bytes(C.byref(d), C.byref(nb)), 'ws')
+        ws = torch.empty((nb.value // 4 + 64,), device='cuda')
+        du = dev(pack_winograd_kernel(wt))
+        _lib.check(lib.kfn_conv2d_winograd(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), ws.data_ptr(), 3,
+                                           stream()), 'kfn_conv2d_winograd')
+    elif kind == 'fused':
+        du = dev(pack_winograd_fused_kernel(wt))
+        _lib.check(lib.kfn_conv2d_winograd_fused(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), stream()),
+                   'kfn_conv2d_winograd_fused')
+    elif kind == 'f43':
+        du = dev((pack_winograd_f43_kernel_b if form == 3 else pack_winograd_f43_kernel)(wt))
+        _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), stream()),
+                   'kfn_conv2d_winograd_f43')
+    elif kind == 's2':
+        du = dev((pack_winograd_s2_kernel_b if form == 4 else pack_winograd_s2_kernel)(wt))
+        _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), stream()),
+                   'kfn_conv2d_winograd_s2')
+    else:
+        raise ValueError(kind)
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[n * ho * wo:] == -5.0), '%s wrote past the last output pixel' % kind
+    assert np.all(got[:, co:] == -5.0), '%s wrote outside its channel window' % kind
+    return got[:n * ho * wo, :co].reshape(n, ho, wo, co)

@@ -128,17 +128,20 @@ class _NcclLookalike(object):
         return getattr(self._d, name)
 
 
-def _link_worker(rank, world, port, fail_rank, prefer, out_dir):
+def _link_worker(rank, world, port, fail_rank, prefer, out_dir, bad_index=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from kfnet_amd import _lib, dist as kd
-    if rank == fail_rank:
+    if rank == fail_rank and not bad_index:
         def broken():
             raise _lib.KfnError('simulated: librccl cannot be bound on this rank')
         _lib.load = broken
     try:
-        link = kd.make_link(_NcclLookalike(dist), rank, world, 0, prefer=prefer)
+        # (bad_index: the failing rank's device index is not even an integer -- ADVICE r4: that must fail like any
+        #  other local precondition, collectively, not raise TypeError past make_link's except clause)
+        link = kd.make_link(_NcclLookalike(dist), rank, world, None if (bad_index and rank == fail_rank) else 0,
+                            prefer=prefer)
         name = type(link).__name__
         # the fallback link must be usable at once: one hand-off 0 -> 1
         buf = torch.full((2, 3, 4), float(rank + 1))
@@ -164,5 +167,16 @@ def test_make_link_fallback_is_collective(tmp_path, fail_rank, prefer):
     broadcast or on a different transport.  Whichever rank fails, BOTH ranks take TorchLink
     ('auto') or BOTH raise ('cabi'), and nobody hangs."""
     mp.spawn(_link_worker, args=(2, _free_port(), fail_rank, prefer, str(tmp_path)), nprocs=2, join=True)
+    names = [open(tmp_path / ('link_%d.txt' % r)).read() for r in range(2)]
+    assert names == (['TorchLink'] * 2 if prefer == 'auto' else ['raised'] * 2), names
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('prefer', ['auto', 'cabi'])
+def test_make_link_bad_device_index_fails_collectively(tmp_path, prefer):
+    """ADVICE r4 (dist.py:179): a device index that is None / out of range on ONE rank is a local precondition
+    failure: the flag reduction still runs on that rank (it falls back to the current device / the CPU), so both
+    ranks end on TorchLink ('auto') or both raise KfnError ('cabi') -- nobody hangs, nothing escapes as TypeError."""
+    mp.spawn(_link_worker, args=(2, _free_port(), 1, prefer, str(tmp_path), True), nprocs=2, join=True)
     names = [open(tmp_path / ('link_%d.txt' % r)).read() for r in range(2)]
     assert names == (['TorchLink'] * 2 if prefer == 'auto' else ['raised'] * 2), names

@@ -508,6 +508,46 @@ def test_epilogue_on_a_winograd_routed_layer_reroutes_to_the_direct_kernel():
         net.feat_tower.set_epilogue('no_such_layer', _lib.EPI_L2NORM)
 
 
+def test_epilogue_on_f43_and_conv64_routed_layers_reroutes_to_the_direct_kernel():
+    """a 3x3 layer with >= 64 channels is routed to WinogradF43ConvOp (fp32) / Conv64RowsF16Op (fp16
+    activations); neither kernel carries head epilogues, so set_epilogue must put the layer back on the direct kernel
+    with the direct kernel's weight packing (and, for fp16, keep the operand type)."""
+    from kfnet_amd import _lib
+    from kfnet_amd.cnn_wrapper.network import Network
+    from kfnet_amd.graph import (Conv64RowsF16Op, ConvOp, Graph, WinogradF43ConvOp, pack_conv_kernel, variable_scope)
+
+    class Two(Network):
+        def setup(self):
+            (self.feed('input').conv(3, 64, 1, name='a').conv(3, 64, 1, name='b'))
+
+    g = Graph()
+    x = g.placeholder((32, 64, 96, 64), name='input')
+    net = Two({'input': x}, is_training=False)
+    b = [op for op in net.ops if op.name == 'b'][0]
+    assert isinstance(b, WinogradF43ConvOp) and b.eight_wave
+    net.set_epilogue('b', _lib.EPI_EXP_CH3)
+    assert type(b) is ConvOp and b.epilogue == _lib.EPI_EXP_CH3 and b.kernel.pack is pack_conv_kernel
+    assert not hasattr(b, 'eight_wave') and b.desc().wino_form == 0
+    # packed weights have the direct kernel's [cout_pad][9 Cin] shape
+    w = np.arange(3 * 3 * 64 * 64, dtype=np.float32).reshape(3, 3, 64, 64)
+    assert b.kernel.pack(w).shape == (64, 576)
+    a = [op for op in net.ops if op.name == 'a'][0]
+    assert isinstance(a, WinogradF43ConvOp)          # untouched neighbour
+
+    g16 = Graph()
+    g16.conv_operands = 'f16'
+    g16.f16_activation_scopes = ('S',)
+    x16 = g16.placeholder((2, 64, 96, 64), dtype='f16', name='input')
+    with variable_scope('S'):
+        net16 = Two({'input': x16}, is_training=False)
+    b16 = [op for op in net16.ops if op.name == 'b'][0]
+    assert isinstance(b16, Conv64RowsF16Op)
+    net16.set_epilogue('b', _lib.EPI_EXP_CH3)
+    assert type(b16) is ConvOp and b16.operand_dtype == _lib.OPERAND_F16 and b16.epilogue == _lib.EPI_EXP_CH3
+    p = b16.kernel.pack(w)
+    assert p.dtype == np.float16 and p.size == 64 * 576          # chunk-major fp16 weights of the direct kernel
+
+
 def test_bench_telemetry_picks_the_busy_card_and_parses_sysfs(tmp_path):
     """bench.py's clock / power sampler on a fake sysfs tree: partition nodes (no pp_dpm_sclk) are ignored;
     when the PCI address cannot be matched (no GPU here) every card is watched and the busiest reported."""
