@@ -443,6 +443,17 @@ class ConvOp(Op):
         return 'conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d>' % (t + (bk.value, 1 if self.transposed else 0,
                                                                       3 if cfg.value in (10, 11) else 0))
 
+    def workgroups(self, lib=None):
+        """Workgroups of this op's launch (tiles of the implicit GEMM: kfn_conv2d_plan)."""
+        d = self.desc()
+        cfg, bk, tiles = C.c_int(), C.c_int(), C.c_int()
+        _lib.check((lib or _lib.load()).kfn_conv2d_plan(C.byref(d), C.byref(cfg), C.byref(bk), C.byref(tiles)), 'kfn_conv2d_plan')
+        return tiles.value
+
+    def mfma_flops(self):
+        """FLOPs the MFMAs execute; for the direct kernel the nominal count (tile padding not counted)."""
+        return self.flops()
+
     def launch(self, lib, stream):
         d = self.desc()
         rc = lib.kfn_conv2d_nhwc(C.byref(d), self.x.ptr, self.kernel.ptr,
@@ -560,6 +571,17 @@ class WinogradFusedConvOp(ConvOp):
             cpad = -(-cpad // 128) * 128
         return 2.0 * 16 * tiles * cpad * self.x.shape[3]
 
+    def workgroups(self, lib=None):
+        """Blocks of 8 x 4 tiles of 2x2 pixels (the tile rows of the batch packed) x column blocks of 128 (four waves), 64
+        (two waves: the whole layer) or 32 (one wave) output channels."""
+        n, ho, wo, cout = self.y.shape
+        n = _scaled(n, self.x.graph)
+        th, tw = (ho + 1) // 2, (wo + 1) // 2
+        blocks = (-(-tw // 8)) * (-(-(n * th) // 4))
+        cpad = -(-cout // 32) * 32
+        per = 128 if (self.four_wave() or self.operand_dtype == _lib.OPERAND_F16) else (64 if self.two_wave() else 32)
+        return blocks * (-(-cpad // per))
+
     def launch(self, lib, stream, phases=3):
         d = self.desc()
         rc = lib.kfn_conv2d_winograd_fused(C.byref(d), self.x.ptr, self.kernel.ptr,
@@ -618,6 +640,10 @@ class WinogradF43ConvOp(ConvOp):
         n, h, w, _ = x_shape
         th, tw = (h + 3) // 4, (w + 3) // 4
         return (-(-tw // 4)) * (-(-(n * th) // 8)) * (-(-cout // 64))
+
+    def launch_workgroups(self):
+        n, h, w, _ = self.x.shape
+        return self.workgroups((_scaled(n, self.x.graph), h, w, 0), self.y.shape[3])
 
     def kernel_name(self, lib):
         return 'wino4b_kernel' if self.eight_wave else 'wino4_kernel'
@@ -716,6 +742,13 @@ class WinogradS2ConvOp(ConvOp):
         th, tw = (ho + 1) // 2, (wo + 1) // 2
         tiles = (-(-tw // 8) * 8) * (-(-(n * th) // 4) * 4)
         return 2.0 * 25 * tiles * (-(-cout // 128) * 128) * self.x.shape[3]
+
+    def workgroups(self, lib=None):
+        """Blocks of 8 x 4 tiles of 2x2 OUTPUT pixels (batch rows packed) x column blocks of 128 output channels."""
+        n, ho, wo, cout = self.y.shape
+        n = _scaled(n, self.x.graph)
+        th, tw = (ho + 1) // 2, (wo + 1) // 2
+        return (-(-tw // 8)) * (-(-(n * th) // 4)) * (-(-cout // 128))
 
     def launch(self, lib, stream, phases=3):
         d = self.desc()

@@ -836,7 +836,9 @@ def test_winograd_fused_vs_oracle(case, relu):
 # (N, H, W, Cin, Cout): whole blocks, blocks straddling two images (Th % 8 != 0), ragged tile columns / rows (H, W not
 # multiples of 4 or 16), channel counts that leave waves past Cout (Cout % 64 != 0), one and many super-steps
 F43_CASES = [(2, 32, 16, 16, 64), (3, 60, 80, 32, 64), (2, 30, 40, 64, 128), (5, 36, 20, 16, 96), (1, 68, 120, 48, 72),
-             (3, 29, 35, 32, 100), (2, 120, 160, 16, 64), (9, 32, 16, 512, 64), (2, 60, 80, 1024, 128)]
+             (3, 29, 35, 32, 100), (2, 120, 160, 16, 64), (9, 32, 16, 512, 64), (2, 60, 80, 1024, 128),
+             # narrow images: fewer tile columns than a block holds (Tw = 2 / 3 < 4) -- ADVICE r4
+             (2, 32, 8, 16, 64), (1, 29, 12, 32, 72)]
 
 
 @pytest.mark.parametrize('form', [2, 3])      # KFN_WINO_FORM_F43_FOUR_WAVE (wino4_kernel), _EIGHT_WAVE (wino4b_kernel)
@@ -883,7 +885,9 @@ def test_winograd_f43_rejects_what_it_cannot_do():
     ok = dict(N=1, H=32, W=32, Cin=32, ldx=32, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1)
     assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**ok))) == 1
     for bad in (dict(H=28), dict(Cin=24, ldx=24), dict(stride=2), dict(Cout=62, ldy=62), dict(ldy=66), dict(x_dtype=1),
-                dict(operand_dtype=1), dict(epilogue=2), dict(kh=1, kw=1)):
+                dict(operand_dtype=1), dict(epilogue=2), dict(kh=1, kw=1),
+                # ... and everything else the launcher would refuse without seeing the pointers
+                dict(ldx=16), dict(ldy=60), dict(ldx=33), dict(cout_pad=32), dict(N=0), dict(H=8192, W=8192, Cin=16, ldx=16)):
         assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**dict(ok, **bad)))) == 0, bad
 
 

@@ -16,6 +16,12 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 if __name__ == '__main__':
+    # `--T 256`: SURVEY 8(d)'s default shape (S = 256 x T = 256) alone, for its own PMC passes (the kernel name is the same, so
+    # the two shapes cannot share a pass: tools/pmc_traffic.py averages per kernel name)
+    T = int(sys.argv[sys.argv.index('--T') + 1]) if '--T' in sys.argv else 64
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    print(json.dumps({'scan': bench.kalman_roofline(dev), 'fuse': bench.kalman_fuse_roofline(dev)}))
+    out = {'scan': bench.kalman_roofline(dev, T=T)}
+    if T == 64:
+        out['fuse'] = bench.kalman_fuse_roofline(dev)
+    print(json.dumps(out))

@@ -2,7 +2,7 @@
 # Regenerates the judged profile summaries of a round on the GPU box:
 #   bash tools/profile_round.sh r01        (writes gpurun_out/prof/<tag>_*; copy into profiles/)
 # Kernel trace and every PMC group are separate rocprofv3 runs (never combined with sys traces).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -28,6 +28,12 @@ python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_S
     --only kalman_scan_kernel --suffix '@S=256,T=64' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
 python tools/pmc_traffic.py "$(finddb $OUT/kFETCH_SIZE)" "$(finddb $OUT/kWRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json \
     --only kalman_fuse_kernel --suffix '@P=78643200' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
+# ... and SURVEY 8(d)'s default shape S=256 x T=256 in two more passes (same kernel name: it needs its own)
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/k256$C -- python $R/tools/kalman_roofline.py --T 256 > $OUT/${TAG}_kalman_roofline_T256_under_pmc_$C.json 2> $OUT/k256$C.err )
+done
+python tools/pmc_traffic.py "$(finddb $OUT/k256FETCH_SIZE)" "$(finddb $OUT/k256WRITE_SIZE)" $OUT/${TAG}_pmc_traffic.json \
+    --only kalman_scan_kernel --suffix '@S=256,T=256' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # the bench line below quotes these numbers (newest rNN file)
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
@@ -38,11 +44,18 @@ python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(
 # the un-profiled bench lines (they quote the fresh PMC traffic copied to profiles/ above): the 256-frame default and,
 # after the config-5 passes below, the driver's own command
 python bench.py --no-extra-configs > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
-rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
+rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/k256FETCH_SIZE $OUT/k256WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
 # ---- BASELINE config 5 (960x540, fp16 convs + fp16 activations, fp32 Kalman): kernel trace + the same PMC passes ----
 C5="--config c5 --no-cpu-baseline --min-seconds 0"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/c5kt -- python $R/bench.py $C5 > $OUT/${TAG}_c5_bench_under_rocprof.json 2> $OUT/c5kt.err )
 python tools/rocpd_stats.py "$(finddb $OUT/c5kt)" $OUT/${TAG}_c5_kernel_stats.csv > /dev/null
+# the same trace with the two towers serialised on one stream (VERDICT r4 Next #1a): per-kernel averages without the other
+# stream's kernels sharing the CUs -- the file the c5 line's roofline.frac (isolated launches, HIP events) is recomputed from
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/c5kt1 -- python $R/bench.py $C5 --one-stream > $OUT/${TAG}_c5_bench_under_rocprof_one_stream.json 2> $OUT/c5kt1.err )
+python tools/rocpd_stats.py "$(finddb $OUT/c5kt1)" $OUT/${TAG}_c5_kernel_stats_one_stream.csv > /dev/null
+# config 2 (single frame): kernel trace of the latency bench -- the per-layer batch-1 table of the line is recomputed from it
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/c2kt -- python $R/bench.py --config c2 --min-seconds 0.5 > $OUT/${TAG}_c2_bench_under_rocprof.json 2> $OUT/c2kt.err )
+python tools/rocpd_stats.py "$(finddb $OUT/c2kt)" $OUT/${TAG}_c2_kernel_stats.csv > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT/c5$C -- python $R/bench.py $C5 > /dev/null 2> $OUT/c5$C.err )
 done
@@ -57,5 +70,5 @@ cp $OUT/${TAG}_c5_pmc_traffic.json $R/profiles/${TAG}_c5_pmc_traffic.json    # q
 python bench.py --config c5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
 python bench.py --config c2 > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_command.json 2> $OUT/bench_driver.err
-rm -rf $OUT/c5kt $OUT/c5FETCH_SIZE $OUT/c5WRITE_SIZE $OUT/c5sq1 $OUT/c5sq2 $OUT/c5sq3
+rm -rf $OUT/c5kt $OUT/c5kt1 $OUT/c2kt $OUT/c5FETCH_SIZE $OUT/c5WRITE_SIZE $OUT/c5sq1 $OUT/c5sq2 $OUT/c5sq3
 ls -la $OUT
