@@ -266,6 +266,17 @@ int kfn_winograd_f43_supported(const kfn_conv_desc* desc);
  * compares it with kfn_device_info()'s lds_bytes_per_cu and routes around kernels the device cannot hold (147-157 KB for
  * the F(4x4,3x3) and four-wave F(2x2,3x3) forms) instead of failing in the first launch.  No device access.  (ABI 6) */
 int kfn_winograd_lds_bytes(const kfn_conv_desc* desc, int* bytes);
+/* Split-K form of the eight-wave kernel for launches that would leave the chip idle (BASELINE configs[1], one 480x640 frame:
+ * SCoordNet conv4b / conv5 / conv6 at batch 1 are 160 / 80 / 40 workgroups on 256 CUs, cnn_wrapper/SCoordNet.py:27-30): the
+ * input channels are cut into k_split runs of ceil(Cin / 16 / k_split) super-steps, k_split copies of the tile grid write raw
+ * partial sums into the planes of `workspace` ([k_split][N*H*W][Cout] floats, kfn_winograd_f43_splitk_workspace_bytes), a
+ * second kernel adds the planes in the fixed order 0 .. k_split-1, then bias and ReLU, into y -- two stream-ordered launches,
+ * no atomics, bit-stable from run to run.  u4b_packed = the eight-wave packing (kfnet_amd.graph.pack_winograd_f43_kernel_b);
+ * 1 <= k_split <= Cin / 16 with no empty run; k_split == 1 is kfn_conv2d_winograd_f43's eight-wave launch (workspace unused).
+ * The result differs from the unsplit launch by the summation order over the input channels only. */
+int kfn_winograd_f43_splitk_workspace_bytes(const kfn_conv_desc* desc, int k_split, size_t* bytes);
+int kfn_conv2d_winograd_f43_splitk(const kfn_conv_desc* desc, const float* x, const float* u4b_packed, const float* bias,
+                                   float* y, float* workspace, int k_split, void* stream);
 int kfn_conv2d_winograd_f43(const kfn_conv_desc* desc, const float* x, const float* u4_packed, const float* bias,
                             float* y, void* stream);
 

@@ -81,6 +81,8 @@ SYMBOLS = {
     'kfn_conv2d_winograd_f43': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_f43_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_winograd_lds_bytes': (_i, [C.POINTER(ConvDesc), C.POINTER(_i)]),
+    'kfn_winograd_f43_splitk_workspace_bytes': (_i, [C.POINTER(ConvDesc), _i, C.POINTER(_sz)]),
+    'kfn_conv2d_winograd_f43_splitk': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_conv3x3_c64_f16': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_conv3x3_c64_f16_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_first_conv_u8': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),

@@ -68,6 +68,12 @@ def _same_out(n, s):
     return -(-n // s)
 
 
+def _scaled_batch(n, graph):
+    """Frames a launch really processes (the graph's `active` share of the batch it was built for) -- at build time the
+    whole batch."""
+    return n
+
+
 def _off_path(name):
     def fn(self, *a, **k):
         raise NotImplementedError(
@@ -294,14 +300,23 @@ class Network(object):
         # most of the 256 CUs idle and the smaller F(2x2,3x3) workgroups win -- single frames only (batch 1, F(4x4) ->
         # F(2x2): conv5 80 workgroups 0.287 -> 0.238 ms, conv6 40: 0.151 -> 0.123, feat5 40: 0.031 -> 0.022; from 160
         # workgroups up F(4x4) is ahead: conv4b at batch 1 0.288 against 0.479; profiles/r04_wino4_microbench.log, r4z)
-        f43_fills = (not fused_ok
-                     or WinogradF43ConvOp.workgroups(input.shape, filters) >= g.winograd_f43_min_workgroups)
         e8 = bool(g.winograd_f43_eight_wave)
+        wgs = WinogradF43ConvOp.workgroups((_scaled_batch(n, g), h, w, cin), filters)
+        ksplit = 1
+        if e8 and g.winograd_f43_max_k_split > 1:
+            ksplit = WinogradF43ConvOp.best_k_split(wgs, cin, _scaled_batch(n, g) * h * w * filters * 4, g.winograd_f43_max_k_split)
+        f43_fills = (not fused_ok or wgs * ksplit >= g.winograd_f43_min_workgroups)
         if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43 and f43_fills
                 and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld, y.ld, y.ch_off)
                 and g.winograd_lds_fits(1, cin, filters, _lib.WINO_FORM_F43_EIGHT_WAVE if e8 else _lib.WINO_FORM_F43_FOUR_WAVE)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_f43_kernel_b if e8 else pack_winograd_f43_kernel)
-            self._emit(WinogradF43ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
+            op = WinogradF43ConvOp(name, input, y, kern, bias, relu, eight_wave=e8, k_split=ksplit)
+            if ksplit > 1:
+                # a PRIVATE workspace: the two towers run on two streams, a shared one would race (single frames only:
+                # 29-59 MB per split layer at batch 1)
+                op.workspace = Storage((op.workspace_bytes() + 3) // 4, 'f32')
+                g.storages.append(op.workspace)
+            self._emit(op)
             return y
         # (measured, 16-frame batch, single-kernel vs two-kernel form: conv1b 2.3 ms vs 3.3 direct, conv2b 5.60 vs
         #  7.10, conv3b 5.05 vs 5.99, conv4b 4.93 vs 5.42, conv5 2.49 vs 2.73, conv6 0.63 vs 0.77)

@@ -70,10 +70,12 @@ __device__ __forceinline__ void st_stream(V* p, const V& v) {
 // branch the compiler's s_waitcnt insertion must assume the branch not taken and degrades every wait to vmcnt(0), which
 // serialises the rolling prefetch (seen in the listing: vmcnt(0) in front of every pixel).  `valid`: this thread's pixel
 // exists (p < HW); invalid lanes compute on a clamped duplicate and store nothing.
+// (x, y) = the pixel's grid position (p = y W + x); rec_out != nullptr: the record is handed back instead of stored
+// (the scan kernel stores it through a buffer descriptor with scalar frame / slot offsets).
 template <bool NT = false, bool DBG = true>
-__device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4* st, const PixIn& in, int p,
+__device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4* st, const PixIn& in, int p, int x, int y,
                                             size_t off, bool reset, int W, float xmax, float ymax,
-                                            float eps2, bool want_nis, bool valid = true) {
+                                            float eps2, bool want_nis, bool valid = true, f32x4* rec_out = nullptr) {
   KalmanArgs a = a_in;
   if constexpr (!DBG) { a.opt_temp = nullptr; a.opt_nis = nullptr; a.opt_kf = nullptr; }
   const f32x4 z = in.z;  // (zx, zy, zz, sigma_z)
@@ -94,7 +96,6 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
     }
   }
   if (graph_path) {
-    const int y = p / W, x = p - y * W;
     // pixel_map = GetPixelMap + flow (KFNet.py:386, util.py:42-63: (x, y))
     const float px = (float)x + in.flow.x;
     const float py = (float)y + in.flow.y;
@@ -166,7 +167,8 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
     r.x = outv.x; r.y = outv.y; r.z = outv.z;
   }
   r.w = 1.0f / outv.w;
-  if (valid) st_stream<NT>(a.rec + off + p, r);
+  if (rec_out != nullptr) *rec_out = r;
+  else if (valid) st_stream<NT>(a.rec + off + p, r);
   return nv;
 }
 
@@ -194,39 +196,67 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   // state -> LDS
   for (int p = tid; p < HW; p += KT) st_base[p] = a.state[(size_t)s * HW + p];
 
-  const size_t seq_off = (size_t)s * T * HW;
+  // ---- addressing: ONE buffer descriptor per stream, based at this sequence and exactly its T frames long.  Pixel slot k
+  // of frame t sits at  voffset = tid * size  (per thread)  +  soffset = (t HW + k KT) * size  (wave-uniform: scalar
+  // registers and scalar arithmetic).  The per-pixel 64-bit pointers of the first version cost eight loop-invariant VGPRs
+  // per slot (the compiler hoists them out of the frame loop): 56-224 spilled registers in the single-buffer forms.  The
+  // hardware range-checks voffset (NOT the scalar offset) against num_records: a thread whose slot lies past the grid
+  // (tid + k KT >= HW) gets a voffset beyond every sequence -- its loads return zeros, its stores are dropped -- so every
+  // load and store is unconditional, the number of vector-memory operations between a load and its use is a compile-time
+  // constant and the s_waitcnt in front of the use leaves the younger loads in flight.  (The look-ahead's frame index is
+  // clamped to T - 1: the scalar offset is not range-checked.  T HW 16 < 2^31 -- checked by the launcher -- keeps the
+  // poison 0x08000000 elements beyond num_records for all three element sizes.)
+  const size_t seq_px = (size_t)s * T * HW;
+  const unsigned aux = NT ? 2u : 0u;          // the non-temporal bit: streamed once, not re-read by this launch
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x2*>(a.flow + seq_px), 0, T * HW * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sigma_t + seq_px), 0, T * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.meas + seq_px), 0, T * HW * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rec + seq_px, 0, T * HW * 16, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned POISON = 0x08000000u;    // element index: x 4 / 8 / 16 >= num_records of the three element sizes
   PixIn ring[D];
-  // pixel index of slot k, clamped for the LOADS (threads past the grid re-read the last pixel and store nothing): every
-  // load is unconditional, so the number of vector-memory operations between a load and its use is a compile-time
-  // constant and the s_waitcnt in front of the use can leave the younger loads in flight.  (Recomputed where it is
-  // used -- one add + one min -- instead of held in PPT registers.)
-  auto pl = [&](int k) { return min(tid + k * KT, HW - 1); };
-  auto load_pixel = [&](size_t off, int p, PixIn& dst) {
-    dst.flow = ld_stream<NT>(a.flow + off + p);
-    dst.st = ld_stream<NT>(a.sigma_t + off + p);
-    dst.z = ld_stream<NT>(a.meas + off + p);
+  // `tv` = this thread's index, opaque per frame (see below); slot k's element index for the range check
+  auto slot_index = [&](int tv, int k) { return (tv + k * KT < HW) ? (unsigned)tv : POISON; };
+  auto load_pixel = [&](int tv, int t, int k, PixIn& dst) __attribute__((always_inline)) {
+    const int tc = t < T - 1 ? t : T - 1;
+    const unsigned e = (unsigned)(tc * HW + k * KT);             // uniform element offset of the slot
+    const unsigned vi = slot_index(tv, k);
+    dst.flow = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsF, vi * 8u, e * 8u, aux));
+    dst.st = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsS, vi * 4u, e * 4u, aux));
+    dst.z = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsM, vi * 16u, e * 16u, aux));
   };
+  // grid position of slot k: (y0, x0) of pixel `tid` plus the wave-uniform (k KT) / W, (k KT) % W with one carry
+  const int y0 = tid / W, x0 = tid - y0 * W;
 #pragma unroll
-  for (int k = 0; k < D; ++k) load_pixel(seq_off, pl(k), ring[k]);
+  for (int k = 0; k < D; ++k) load_pixel(tid, 0, k, ring[k]);
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     const int gi = a.d.t0 + t;
     const bool reset = a.d.reset_period > 0 && (gi % a.d.reset_period) == 0;
-    const size_t off = seq_off + (size_t)t * HW;
-    const size_t off_next = seq_off + (size_t)min(t + 1, T - 1) * HW;   // (the last frame re-reads itself: no branch around loads)
+    const size_t off = seq_px + (size_t)t * HW;
     const f32x4* st = DBL ? st_base + (t & 1) * HW : st_base;
     f32x4* st_new = DBL ? st_base + ((t + 1) & 1) * HW : st_base;
     f32x4 newst[DBL ? 1 : PPT];
+    // (opaque per frame: keeps the per-slot positions / offsets / predicates from being hoisted out of the frame loop
+    //  into several live registers per slot)
+    int x0f = x0, y0f = y0, tv = tid;
+    asm volatile("" : "+v"(x0f), "+v"(y0f), "+v"(tv));
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      const int p = tid + k * KT;
+      const int p = tv + k * KT;
       const bool valid = p < HW;
-      const f32x4 nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], pl(k), off, reset, W, xmax, ymax, eps2, want_nis, valid);
+      const int qk = (k * KT) / W, rk = (k * KT) - qk * W;     // uniform
+      int xk = x0f + rk, yk = y0f + qk;
+      if (xk >= W) { xk -= W; yk += 1; }
+      f32x4 rec;
+      const f32x4 nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), rsR, slot_index(tv, k) * 16u,
+                                             (unsigned)(t * HW + k * KT) * 16u, aux);      // (threads past the grid: dropped)
       if (DBL) { if (valid) st_new[p] = nv; } else newst[DBL ? 0 : k] = nv;
       // this slot's inputs are consumed: fetch the pixel that uses the slot next
-      if (k + D < PPT) load_pixel(off, pl(k + D), ring[k % D]);
-      else load_pixel(off_next, pl(k + D - PPT), ring[k % D]);
+      if (k + D < PPT) load_pixel(tv, t, k + D, ring[k % D]);
+      else load_pixel(tv, t + 1, k + D - PPT, ring[k % D]);
       // keep the unrolled pixels sequential: interleaving them only multiplies live
       // temporaries (the 128-VGPR budget of a 1024-thread workgroup is tight)
       __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +293,8 @@ __global__ __launch_bounds__(256) void kalman_step_kernel(KalmanArgs a, const f3
   const bool reset = a.d.reset_period > 0 && (gi % a.d.reset_period) == 0;
   const float eps2 = a.d.min_uncertainty * a.d.min_uncertainty;
   const bool want_nis = (a.opt_nis != nullptr) || (a.d.nis_gate > 0.f);
-  next[(size_t)s * HW + p] = fuse_pixel(a, prev + (size_t)s * HW, in, p, off, reset, W, (float)(W - 1),
+  const int py = p / W, px = p - py * W;
+  next[(size_t)s * HW + p] = fuse_pixel(a, prev + (size_t)s * HW, in, p, px, py, off, reset, W, (float)(W - 1),
                                         (float)(H - 1), eps2, want_nis);
 }
 
@@ -356,13 +387,16 @@ __global__ __launch_bounds__(256) void kalman_fuse2_kernel(const f32x4* __restri
 #define KFN_SCAN_DEPTH KFN_SCAN_PPT
 #endif
 #ifndef KFN_SCAN_BIG_DEPTH
-#define KFN_SCAN_BIG_DEPTH 4
+#define KFN_SCAN_BIG_DEPTH 2
 #endif
 #ifndef KFN_SCAN_NT
 #define KFN_SCAN_NT 1
 #endif
+// fuse kernel: 256 threads x 4 pixels, non-temporal, ONE trip per thread (measured, tools/mb/kalman_mb, P = 78.6 M / 314.6 M
+// pixels: rounds 1-4's 256 x 1 grid-stride form 0.623 / 0.622 of 8 TB/s; 256 x 4 nt capped at 4096 blocks 0.773 / 0.703;
+// 512 x 4 nt 0.738 / 0.680; 256 x 4 nt one trip 0.786 / 0.750)
 #ifndef KFN_FUSE_BLOCK
-#define KFN_FUSE_BLOCK 512
+#define KFN_FUSE_BLOCK 256
 #define KFN_FUSE_U 4
 #define KFN_FUSE_NT 1
 #endif
@@ -445,6 +479,9 @@ extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy
       rc = kfn::check_hip(hipMemcpyAsync(a.state, scratch, bytes, hipMemcpyDeviceToDevice, s), "state copy-back");
     return rc;
   }
+  KFN_REQUIRE((long)d->T * HW * 16L < (1L << 31),
+              "kfn_kalman_scan: T * H * W = %ld pixel-frames per sequence exceed the 32-bit offsets of one launch (at most %ld frames "
+              "of this grid): scan the sequence in chunks", (long)d->T * HW, ((1L << 31) - 1) / (16L * HW));
   // 768 threads (12 wavefronts, 170-VGPR budget) x 7 pixels cover the 60x80 grid without
   // register spills; larger grids fall back to 1024 threads and the single-buffer form.
   const bool dbl = (size_t)HW * 32 <= 160 * 1024;  // two LDS copies of the state fit
@@ -452,10 +489,12 @@ extern "C" int kfn_kalman_scan_ex(const kfn_kalman_desc* d, const float* flow_xy
   if (dbl && HW <= KFN_SCAN_KT * KFN_SCAN_PPT)
     return launch_scan<KFN_SCAN_KT, KFN_SCAN_PPT, true, KFN_SCAN_DEPTH, NT, 768, 7, 1>(a, s);
   // single LDS copy (config 5's 68x120 = 8160-pixel grid takes the second line): the new states of a frame wait in
-  // registers for the mid-frame barrier -- 1024 threads keep that to PPT <= 10 float4 per thread beside a short input ring
-  if (HW <= 1024 * 6) return launch_scan<1024, 6, false, 3, NT, 512, 12, 1>(a, s);
+  // registers for the mid-frame barrier -- 1024 threads keep that to PPT <= 10 float4 per thread beside a two-deep input
+  // ring.  Measured (tools/mb/kalman_mb, 68x120, S = 256 x T = 32 / S = 4 x T = 64): rounds 1-4's 512 x 16 with the loads at
+  // the frame start 0.867 / 1.011 ms; 1024 x 8 with D = 2 0.793 / 0.914; D = 4 0.796 / 0.968; 768 x 11 D = 1 0.787 / 1.064.
+  if (HW <= 1024 * 6) return launch_scan<1024, 6, false, 2, NT, 512, 12, 1>(a, s);
   if (HW <= 1024 * 8) return launch_scan<1024, 8, false, KFN_SCAN_BIG_DEPTH, NT, 512, 16, 1>(a, s);
-  return launch_scan<1024, 10, false, 5, NT, 512, 20, 1>(a, s);
+  return launch_scan<1024, 10, false, 1, NT, 512, 20, 1>(a, s);
 }
 
 extern "C" int kfn_kalman_scan(const kfn_kalman_desc* d, const float* flow_xy,
@@ -470,8 +509,8 @@ extern "C" int kfn_kalman_fuse(const float* pred, const float* meas, float* out,
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(meas) |
                 reinterpret_cast<uintptr_t>(out)) & 15) == 0, "kfn_kalman_fuse: misaligned buffer");
   constexpr int PER = KFN_FUSE_BLOCK * KFN_FUSE_U;
-  long blocks = (P + PER - 1) / PER;
-  if (blocks > 256L * 16) blocks = 256L * 16;
+  const long blocks = (P + PER - 1) / PER;      // one trip per thread (the kernel's loop runs once)
+  KFN_REQUIRE(blocks < (1L << 31), "kfn_kalman_fuse: P=%ld too large for one launch", P);
   hipLaunchKernelGGL((kalman_fuse_kernel<KFN_FUSE_BLOCK, KFN_FUSE_U, KFN_FUSE_NT != 0>), dim3((unsigned)blocks), dim3(KFN_FUSE_BLOCK), 0,
                      (hipStream_t)stream, reinterpret_cast<const f32x4*>(pred), reinterpret_cast<const f32x4*>(meas),
                      reinterpret_cast<f32x4*>(out), opt_nis, P);

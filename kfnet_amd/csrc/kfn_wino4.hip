@@ -126,6 +126,11 @@ struct Wino4Args {
   unsigned long long x_bytes;
   unsigned long long y_bytes;
   unsigned u_bytes;
+  // split-K (wino4b_kernel only; kfn_conv2d_winograd_f43_splitk): the grid is k_split copies of the tile grid, copy s
+  // accumulates super-steps [s * ss_per_split, (s + 1) * ss_per_split) and writes its RAW partial sums (no bias, no ReLU)
+  // into plane s of the workspace (y / ldy / y_bytes describe ONE plane, y_split_bytes the distance between planes)
+  int k_split, ss_per_split;
+  unsigned long long y_split_bytes;
 #ifdef KFN_WINO4_PROF
   unsigned long long* prof;   // tools/mb/wino4_prof.hip: [block][wave][8] phase stamps, then [block][wave][11] timeline of one super-step
 #endif
@@ -769,7 +774,8 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wx = wave & 1, wq = wave >> 1;      // position half, 16-channel quarter
   const int nwg = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap4(blockIdx.x, nwg);
+  const int split = p.k_split > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;   // K split slowest: a split's workgroups keep the tile order
+  const int tile = xcd_remap4((int)blockIdx.x - split * nwg, nwg);
   const int per = p.tiles_m * p.n_group;
   const int gset = tile / per, rem = tile - gset * per;
   const int tm = rem / p.n_group;
@@ -819,8 +825,11 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   const int pt = 4 * ptr + tc;
   const int v_st = pch * B_VBUF + (c8 >> 1) * 64 + (((pt & 15) ^ (c8 >> 1)) * 4) + (pt >> 4) * 2 + (c8 & 1);
   const int n_chunks = p.Cin / 8;
-  const int n_super = n_chunks / CPS;
+  const int ks0 = split * p.ss_per_split;                                   // first super-step of this split (0 without split-K)
+  const int n_super = p.k_split > 1 ? ((n_chunks / CPS - ks0) < p.ss_per_split ? (n_chunks / CPS - ks0) : p.ss_per_split)
+                                    : n_chunks / CPS;
   const int s_last = n_super - 1;
+  const int c_base = ks0 * CPS;                                             // ... its first chunk
 
   // ---- CONSUMER: A row rl = lane & 15 (tiles rl, 16 + rl), k = kl = lane >> 4; B column nl = lane & 15 (channel n0 + nl) -------
   const int rl = lane & 15, kl = lane >> 4;
@@ -847,7 +856,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const int sc = ss < s_last ? ss : s_last;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
-    pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)(sc * 64), 0));
+    pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
   };
   auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
@@ -855,7 +864,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   };
   auto b_load = [&](auto sl_, int ch, int pr) __attribute__((always_inline)) {      // pair pr (0..8) of this wave's positions
     constexpr int sl = decltype(sl_)::value;
-    const int q = ch * (NPOS / 2) + (WPOS / 2) * wx + pr;
+    const int q = (c_base + ch) * (NPOS / 2) + (WPOS / 2) * wx + pr;
     const int qc = q < q_last ? q : q_last;
     bq[sl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)qc * b_step, 0));
   };
@@ -1055,7 +1064,8 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const unsigned long long y_base = (unsigned long long)img0 * p.H * p.W * p.ldy * 4ull;
     const unsigned long long y_rest = p.y_bytes - y_base;
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+        reinterpret_cast<char*>(p.y) + y_base + (unsigned long long)split * p.y_split_bytes, 0,
+        (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
     const int j = lane >> 4, nq = nbase + 4 * (lane & 15);
     const int pi = wave & 3, tsel = wave >> 2;
     const bool q_ok = nq < p.Cout;
@@ -1080,6 +1090,23 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
                                              rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
     }
+  }
+}
+
+// y[pix][c] = relu(bias[c] + sum_s ws[s][pix][c]), s = 0 .. k_split-1 in THAT order (one fixed order: deterministic, and the
+// same for every launch geometry).  ws planes are dense [pixels][Cout]; one float4 per thread.
+__global__ __launch_bounds__(256) void wino4_splitk_reduce_kernel(const f32x4* __restrict__ ws, int k_split, long plane_quads,
+                                                                  const float* __restrict__ bias, int relu, float* __restrict__ y,
+                                                                  int Cout, int ldy, long pixels) {
+  const int cq = Cout >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < plane_quads; i += (long)gridDim.x * 256) {
+    const long pix = i / cq;
+    const int c = (int)(i - pix * cq) * 4;
+    f32x4 acc = __builtin_nontemporal_load(ws + i);
+    for (int s2 = 1; s2 < k_split; ++s2) acc += __builtin_nontemporal_load(ws + (long)s2 * plane_quads + i);
+    if (bias != nullptr) acc += *reinterpret_cast<const f32x4*>(bias + c);
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<f32x4*>(y + pix * ldy + c) = acc;
   }
 }
 
@@ -1134,44 +1161,45 @@ extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
   return 1;
 }
 
-extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, const float* u4_packed, const float* bias,
-                                       float* y, void* stream) {
-  KFN_REQUIRE(d && x && u4_packed && y, "kfn_conv2d_winograd_f43: null argument");
-  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_f43");
-  KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed,
-              "kfn_conv2d_winograd_f43: only 3x3 stride-1 SAME convolutions");
-  KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "kfn_conv2d_winograd_f43: bad shape %dx%dx%d", d->N, d->H, d->W);
+namespace {
+
+// Argument checks + geometry shared by kfn_conv2d_winograd_f43 and its split-K form.  `y` / `ldy` = where the kernel writes
+// (the output tensor, or one dense plane of the split-K workspace).
+int wino4_setup(const kfn_conv_desc* d, const float* x, const float* u4_packed, const float* bias, float* y, int ldy,
+                const char* who, Wino4Args* out) {
+  KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed, "%s: only 3x3 stride-1 SAME convolutions", who);
+  KFN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "%s: bad shape %dx%dx%d", who, d->N, d->H, d->W);
   KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32 && d->operand_dtype == KFN_OPERAND_F32 &&
                   d->epilogue == KFN_EPI_NONE,
-              "kfn_conv2d_winograd_f43: fp32 operands and activations, no fused head epilogue");
+              "%s: fp32 operands and activations, no fused head epilogue", who);
   if (d->Cin <= 0 || d->Cin % 16 != 0)
-    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: Cin=%d must be a multiple of 16", d->Cin);
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: Cin=%d must be a multiple of 16", who, d->Cin);
   if ((d->H + 3) / 4 < BH4)
-    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: H=%d is below %d rows", d->H, 4 * BH4 - 3);
-  KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 2 == 0 && d->Cout > 0 && d->ldy >= d->Cout && d->cout_pad >= d->Cout &&
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: H=%d is below %d rows", who, d->H, 4 * BH4 - 3);
+  KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 2 == 0 && d->Cout > 0 && ldy >= d->Cout && d->cout_pad >= d->Cout &&
                   d->cout_pad % 32 == 0,
-              "kfn_conv2d_winograd_f43: bad strides / channel counts");
-  if (d->Cout % 4 != 0 || d->ldy % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)
-    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: Cout and ldy must be multiples of 4 and y 16-byte aligned");
+              "%s: bad strides / channel counts", who);
+  if (d->Cout % 4 != 0 || ldy % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: Cout and ldy must be multiples of 4 and y 16-byte aligned", who);
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) & 7) | (reinterpret_cast<uintptr_t>(u4_packed) & 15) |
                (bias ? (reinterpret_cast<uintptr_t>(bias) & 15) : 0)) == 0,
-              "kfn_conv2d_winograd_f43: x must be 8-byte, u4_packed and bias 16-byte aligned");
+              "%s: x must be 8-byte, u4_packed and bias 16-byte aligned", who);
   const long img_b = (long)d->H * d->W * d->ldx * 4L;
-  const long out_b = (long)d->H * d->W * d->ldy * 4L;
+  const long out_b = (long)d->H * d->W * ldy * 4L;
   if (2 * img_b >= (1L << 30) || 2 * out_b >= (1L << 31) || 36L * d->cout_pad * d->Cin * 4L >= (1L << 31))
-    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: image or kernel beyond the 32-bit offsets of this form");
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: image or kernel beyond the 32-bit offsets of this form", who);
   Wino4Args a;
   a.x = x; a.u4 = u4_packed; a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
+  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = ldy;
   a.Th = (d->H + 3) / 4; a.Tw = (d->W + 3) / 4;
   const long vrows = (long)d->N * a.Th;
-  KFN_REQUIRE(vrows < (1L << 30), "kfn_conv2d_winograd_f43: N*ceil(H/4) = %ld tile rows exceed 32-bit addressing", vrows);
+  KFN_REQUIRE(vrows < (1L << 30), "%s: N*ceil(H/4) = %ld tile rows exceed 32-bit addressing", who, vrows);
   a.vrows = (int)vrows;
   a.bw = kfn::ceil_div(a.Tw, BW4);
   const long tiles_m = (long)a.bw * kfn::ceil_div(a.vrows, BH4);
   a.tiles_n = kfn::ceil_div(d->cout_pad, 64);
-  KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_f43: grid too large");
+  KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "%s: grid too large", who);
   a.tiles_m = (int)tiles_m;
   a.relu = d->relu;
   // workgroup order: M fastest (1 group), all channel groups of a block adjacent (N fastest), or KFN_WINO_ORDER_GROUPS(n).
@@ -1186,28 +1214,98 @@ extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, c
   a.n_group = ng;
   const long in_pix = (long)d->N * d->H * d->W;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
-  a.y_bytes = (unsigned long long)(((in_pix - 1) * d->ldy + d->Cout) * 4L);
+  a.y_bytes = (unsigned long long)(((in_pix - 1) * ldy + d->Cout) * 4L);
   // the B ring prefetches whole 1 KiB fragments of 32 output channels: the last column block of a 32-but-not-64-multiple
   // cout_pad reads 32 channels past the matrix -- the range check returns zeros for them (their accumulators are never stored)
   a.u_bytes = (unsigned)(36L * d->cout_pad * d->Cin * 4L);
+  a.k_split = 1;
+  a.ss_per_split = d->Cin / (8 * CPS);
+  a.y_split_bytes = 0;
 #ifdef KFN_WINO4_PROF
   a.prof = g_wino4_prof;
 #endif
+  *out = a;
+  return KFN_OK;
+}
+
+int wino4b_launch(const Wino4Args& a, hipStream_t stream) {
+  static std::atomic<uint64_t> attr_done_b{0};
+  int rcb = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4b_kernel), B_LDS, attr_done_b);
+  if (rcb != KFN_OK) return rcb;
+  hipLaunchKernelGGL(wino4b_kernel, dim3((unsigned)((long)a.tiles_m * a.tiles_n * a.k_split)), dim3(512), B_LDS, stream, a);
+  KFN_LAUNCH_CHECK("wino4b_kernel");
+  return KFN_OK;
+}
+
+}  // namespace
+
+extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, const float* u4_packed, const float* bias,
+                                       float* y, void* stream) {
+  KFN_REQUIRE(d && x && u4_packed && y, "kfn_conv2d_winograd_f43: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_f43");
+  Wino4Args a;
+  int rc = wino4_setup(d, x, u4_packed, bias, y, d->ldy, "kfn_conv2d_winograd_f43", &a);
+  if (rc != KFN_OK) return rc;
   // kfn_conv_desc.wino_form: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE pick the kernel (A/B measurements); AUTO = the default below
   const bool eight = d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE ||
                      (d->wino_form != KFN_WINO_FORM_F43_FOUR_WAVE && KFN_W4_DEFAULT_EIGHT_WAVE);
-  if (eight) {
-    static std::atomic<uint64_t> attr_done_b{0};
-    int rcb = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4b_kernel), B_LDS, attr_done_b);
-    if (rcb != KFN_OK) return rcb;
-    hipLaunchKernelGGL(wino4b_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), B_LDS, (hipStream_t)stream, a);
-    KFN_LAUNCH_CHECK("wino4b_kernel");
-    return KFN_OK;
-  }
+  if (eight) return wino4b_launch(a, (hipStream_t)stream);
   static std::atomic<uint64_t> attr_done{0};
-  int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);
+  rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);
   if (rc != KFN_OK) return rc;
   hipLaunchKernelGGL(wino4_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), LDS_V, (hipStream_t)stream, a);
   KFN_LAUNCH_CHECK("wino4_kernel");
+  return KFN_OK;
+}
+
+// ---- split-K form (round 5: BASELINE configs[1], one 480x640 frame): the layers whose launch has fewer workgroups than
+// the chip has CUs (conv4b 160, conv5 80, conv6 40 at batch 1) split their input channels over k_split copies of the tile
+// grid.  Copy s writes raw partial sums into plane s of `workspace` ([k_split][N*H*W][Cout] floats, dense); a second kernel
+// adds the planes in the order 0, 1, .., k_split-1, the bias, the ReLU and writes y: two launches, no atomics, bit-stable.
+extern "C" int kfn_winograd_f43_splitk_workspace_bytes(const kfn_conv_desc* d, int k_split, size_t* bytes) {
+  KFN_REQUIRE(d && bytes, "kfn_winograd_f43_splitk_workspace_bytes: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_winograd_f43_splitk_workspace_bytes");
+  KFN_REQUIRE(k_split >= 1 && d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "kfn_winograd_f43_splitk_workspace_bytes: bad argument");
+  *bytes = k_split > 1 ? (size_t)k_split * d->N * d->H * d->W * d->Cout * sizeof(float) : 0;
+  return KFN_OK;
+}
+
+extern "C" int kfn_conv2d_winograd_f43_splitk(const kfn_conv_desc* d, const float* x, const float* u4b_packed, const float* bias,
+                                              float* y, float* workspace, int k_split, void* stream) {
+  KFN_REQUIRE(d && x && u4b_packed && y, "kfn_conv2d_winograd_f43_splitk: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_f43_splitk");
+  KFN_REQUIRE(d->wino_form == KFN_WINO_FORM_AUTO || d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE,
+              "kfn_conv2d_winograd_f43_splitk: the eight-wave form only (weights packed per pair of positions)");
+  const int n_super = d->Cin > 0 ? d->Cin / (8 * CPS) : 0;
+  KFN_REQUIRE(k_split >= 1 && k_split <= (n_super > 0 ? n_super : 1), "kfn_conv2d_winograd_f43_splitk: k_split=%d outside 1..%d (Cin/16)",
+              k_split, n_super);
+  Wino4Args a;
+  if (k_split == 1) {
+    int rc = wino4_setup(d, x, u4b_packed, bias, y, d->ldy, "kfn_conv2d_winograd_f43_splitk", &a);
+    if (rc != KFN_OK) return rc;
+    return wino4b_launch(a, (hipStream_t)stream);
+  }
+  KFN_REQUIRE(workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && d->ldy >= d->Cout && d->ldy % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+              "kfn_conv2d_winograd_f43_splitk: k_split > 1 needs a 16-byte aligned workspace of kfn_winograd_f43_splitk_workspace_bytes() "
+              "and a 16-byte aligned output with ldy %% 4 == 0");
+  int rc = wino4_setup(d, x, u4b_packed, nullptr, workspace, d->Cout, "kfn_conv2d_winograd_f43_splitk", &a);
+  if (rc != KFN_OK) return rc;
+  const long pixels = (long)d->N * d->H * d->W;
+  a.relu = 0;
+  a.k_split = k_split;
+  a.ss_per_split = kfn::ceil_div(n_super, k_split);
+  KFN_REQUIRE((long)(k_split - 1) * a.ss_per_split < n_super, "kfn_conv2d_winograd_f43_splitk: k_split=%d leaves an empty split of %d super-steps",
+              k_split, n_super);
+  a.y_split_bytes = (unsigned long long)pixels * d->Cout * 4ull;
+  KFN_REQUIRE((long)a.tiles_m * a.tiles_n * k_split < (1L << 31), "kfn_conv2d_winograd_f43_splitk: grid too large");
+  rc = wino4b_launch(a, (hipStream_t)stream);
+  if (rc != KFN_OK) return rc;
+  const long quads = pixels * (d->Cout / 4);
+  long blocks = (quads + 255) / 256;
+  if (blocks > 256L * 8) blocks = 256L * 8;
+  hipLaunchKernelGGL(wino4_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(workspace), k_split, quads, bias, d->relu, y, d->Cout, d->ldy, pixels);
+  KFN_LAUNCH_CHECK("wino4_splitk_reduce_kernel");
   return KFN_OK;
 }

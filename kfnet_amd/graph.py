@@ -595,9 +595,40 @@ class WinogradF43ConvOp(ConvOp):
     accumulators of 4 registers per wave, weights packed per pair of positions (pack_winograd_f43_kernel_b); else
     wino4_kernel -- four waves on 32x32x2 tiles, 18 accumulators of 16 registers (pack_winograd_f43_kernel)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu, eight_wave=True):
+    def __init__(self, name, x, y, kernel, bias, relu, eight_wave=True, k_split=1, workspace=None):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 1, relu)
         self.eight_wave = eight_wave
+        self.k_split = int(k_split)      # > 1: kfn_conv2d_winograd_f43_splitk (eight-wave form only) with the graph's shared workspace
+        self.workspace = workspace
+
+    # cost model of a launch on `cus` CUs, in microseconds (measured at batch 1 and 32, profiles/r05_*): a super-step of 16
+    # input channels 3.8, prologue + epilogue of a workgroup 10, the reduce launch 4 + its traffic at 4 TB/s
+    SS_US, FIXED_US, REDUCE_US, REDUCE_BPS = 3.8, 10.0, 4.0, 4.0e12
+
+    @classmethod
+    def launch_us(cls, workgroups, n_super, k_split, out_bytes, cus=256):
+        rounds = -(-(workgroups * k_split) // cus)
+        t = rounds * (-(-n_super // k_split) * cls.SS_US + cls.FIXED_US)
+        if k_split > 1:
+            t += cls.REDUCE_US + (k_split + 1) * out_bytes / cls.REDUCE_BPS * 1e6
+        return t
+
+    @classmethod
+    def best_k_split(cls, workgroups, cin, out_bytes, max_split=8, cus=256):
+        """Split of the input channels that minimises launch_us; 1 unless the unsplit launch leaves CUs idle (fewer workgroups
+        than CUs) and splitting wins by more than 10 % (a split launch is two launches and a workspace round trip)."""
+        n_super = cin // 16
+        if workgroups >= cus or n_super < 2:
+            return 1
+        base = cls.launch_us(workgroups, n_super, 1, out_bytes, cus)
+        best, best_t = 1, base
+        for ks in range(2, min(max_split, n_super) + 1):
+            if (ks - 1) * (-(-n_super // ks)) >= n_super:     # an empty last run
+                continue
+            t = cls.launch_us(workgroups, n_super, ks, out_bytes, cus)
+            if t < best_t:
+                best, best_t = ks, t
+        return best if best_t < 0.9 * base else 1
 
     def desc(self):
         d = ConvOp.desc(self)
@@ -627,6 +658,8 @@ class WinogradF43ConvOp(ConvOp):
         if self.kernel.storage is not None:
             raise _lib.KfnError('%s: weights already packed for the F(4x4,3x3) kernel' % self.name)
         self.__dict__.pop('eight_wave', None)
+        self.__dict__.pop('k_split', None)
+        self.workspace = None
         if WinogradFusedConvOp.supported(self.x.shape, cin, self.y.shape[3]) and min(h, w) >= 8:
             self.kernel.pack = pack_winograd_fused_kernel
             self.__class__ = WinogradFusedConvOp
@@ -643,9 +676,11 @@ class WinogradF43ConvOp(ConvOp):
 
     def launch_workgroups(self):
         n, h, w, _ = self.x.shape
-        return self.workgroups((_scaled(n, self.x.graph), h, w, 0), self.y.shape[3])
+        return self.workgroups((_scaled(n, self.x.graph), h, w, 0), self.y.shape[3]) * max(1, self.k_split)
 
     def kernel_name(self, lib):
+        if self.k_split > 1:
+            return 'wino4b_kernel[split-K %d] + wino4_splitk_reduce_kernel' % self.k_split
         return 'wino4b_kernel' if self.eight_wave else 'wino4_kernel'
 
     def mfma_flops(self):
@@ -658,10 +693,19 @@ class WinogradF43ConvOp(ConvOp):
         cpad = -(-cout // 64) * 64
         return 2.0 * 36 * tiles * cpad * self.x.shape[3]
 
+    def workspace_bytes(self):
+        n, ho, wo, cout = self.y.shape
+        return self.k_split * _scaled(n, self.x.graph) * ho * wo * cout * 4 if self.k_split > 1 else 0
+
     def launch(self, lib, stream, phases=3):
         d = self.desc()
-        rc = lib.kfn_conv2d_winograd_f43(C.byref(d), self.x.ptr, self.kernel.ptr,
-                                         self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        bias = self.bias.ptr if self.bias is not None else None
+        if self.k_split > 1:
+            rc = lib.kfn_conv2d_winograd_f43_splitk(C.byref(d), self.x.ptr, self.kernel.ptr, bias, self.y.ptr,
+                                                    self.workspace.ptr, self.k_split, stream)
+            _lib.check(rc, 'kfn_conv2d_winograd_f43_splitk[%s]' % self.name)
+            return
+        rc = lib.kfn_conv2d_winograd_f43(C.byref(d), self.x.ptr, self.kernel.ptr, bias, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_winograd_f43[%s]' % self.name)
 
 
@@ -1253,6 +1297,9 @@ class Graph(object):
         # the K loop must amortise the 36-position transforms and the cross-wave output reduction
         self.winograd_f43_min_channels = 64
         self.winograd_f43_min_workgroups = 128   # below this the launch leaves the chip idle: F(2x2,3x3) (Network.conv)
+        # split-K for F(4x4,3x3) launches of fewer workgroups than CUs (single frames: conv4b 160, conv5 80, conv6 40): the
+        # split WinogradF43ConvOp.best_k_split picks (eight-wave form; 0 / 1 = never split)
+        self.winograd_f43_max_k_split = 8
         # the eight-wave form of the F(4x4,3x3) kernel (wino4b_kernel; measured at batch 32 against the four-wave form, same
         # box: conv1b 2.66 -> 2.34 ms, conv2b 6.98 -> 6.54, conv3b 6.43 -> 6.13, conv4b 6.08 -> 5.85)
         self.winograd_f43_eight_wave = True

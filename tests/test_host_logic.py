@@ -571,3 +571,44 @@ def test_bench_telemetry_picks_the_busy_card_and_parses_sysfs(tmp_path):
     assert s['samples_during_timed_region'] >= 3 and 'card1' in s['source'] and 'busiest of 2' in s['source']
     assert s['sclk_mhz']['mean'] == 2104.0 and s['power_w']['max'] == 912.0 and s['busy_pct']['min'] == 97
     assert s['after']['sclk_mhz'] == 2104.0
+
+
+def test_f43_split_k_is_chosen_for_single_frames_only():
+    """BASELINE configs[1] (one 480x640 frame): SCoordNet's conv4b / conv5 / conv6 launch 160 / 80 / 40 F(4x4,3x3) workgroups on
+    256 CUs -- Network.conv splits their input channels (WinogradF43ConvOp.best_k_split) so that the launch fills the chip; every
+    split layer owns a private workspace (the two towers run on two streams).  At the bench batch nothing is split."""
+    from kfnet_amd.cnn_wrapper.SCoordNet import SCoordNet
+    from kfnet_amd.graph import Graph, WinogradF43ConvOp, variable_scope
+
+    def build(batch):
+        g = Graph()
+        img = g.placeholder((batch, 480, 640, 3), 'u8', name='images')
+        with variable_scope('ScoreNet'):
+            net = SCoordNet({'input': img}, is_training=False, focal_x=525., focal_y=525., u=320., v=240.)
+        return g, {op.name: op for op in net.ops if isinstance(op, WinogradF43ConvOp)}
+
+    g1, f1 = build(1)
+    assert {k: v.k_split for k, v in f1.items()} == {'conv1b': 1, 'conv2b': 1, 'conv3b': 1, 'conv4b': 3, 'conv5': 3, 'conv6': 6}
+    for name in ('conv4b', 'conv5', 'conv6'):
+        op = f1[name]
+        assert op.eight_wave and op.workspace in g1.storages and op.workspace.numel * 4 >= op.workspace_bytes() > 0
+        assert op.launch_workgroups() >= 240 and 'split-K' in op.kernel_name(None)
+    assert len({id(f1[n].workspace) for n in ('conv4b', 'conv5', 'conv6')}) == 3
+    assert f1['conv2b'].workspace is None
+    g32, f32 = build(32)
+    assert set(f32) == set(f1) and all(v.k_split == 1 and v.workspace is None for v in f32.values())
+    # the switch: Graph.winograd_f43_max_k_split = 1 restores round 4's routing (conv5 / conv6 on the F(2x2,3x3) kernel at batch 1)
+    g = Graph()
+    g.winograd_f43_max_k_split = 1
+    img = g.placeholder((1, 480, 640, 3), 'u8', name='images')
+    with variable_scope('ScoreNet'):
+        net = SCoordNet({'input': img}, is_training=False, focal_x=525., focal_y=525., u=320., v=240.)
+    kinds = {op.name: type(op).__name__ for op in net.ops}
+    assert kinds['conv4b'] == 'WinogradF43ConvOp' and kinds['conv5'] == 'WinogradFusedConvOp' and kinds['conv6'] == 'WinogradFusedConvOp'
+    # the cost model itself: never an empty last run, never a split when the launch already fills the chip
+    assert WinogradF43ConvOp.best_k_split(320, 512, 1 << 20) == 1 and WinogradF43ConvOp.best_k_split(40, 16, 1 << 20) == 1
+    for wg in (10, 40, 80, 160, 250):
+        for cin in (32, 64, 512, 1024):
+            ks = WinogradF43ConvOp.best_k_split(wg, cin, 10 << 20)
+            n_super = cin // 16
+            assert 1 <= ks <= max(1, n_super) and (ks == 1 or (ks - 1) * (-(-n_super // ks)) < n_super)

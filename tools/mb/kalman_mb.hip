@@ -65,7 +65,7 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel_r4(KalmanArgs a) {
     for (int k = 0; k < PPT; ++k) {
       const int p = tid + k * KT;
       if (p < HW) {
-        const f32x4 nv = fuse_pixel<false, true>(a, st, cur[k], p, off, reset, W, xmax, ymax, eps2, want_nis);
+        const f32x4 nv = fuse_pixel<false, true>(a, st, cur[k], p, p % W, p / W, off, reset, W, xmax, ymax, eps2, want_nis);
         if (DBL) st_new[p] = nv; else newst[DBL ? 0 : k] = nv;
       }
       // keep the unrolled pixels sequential: interleaving them only multiplies live
