@@ -148,7 +148,7 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239);
     # uploads / compute / downloads overlapped on three streams -- with or without labels
     loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
-                         workers=decode_workers)
+                         workers=decode_workers, first_chunk=min(chunk, max(eng.B, 16)))
     dm = M.DeviceMetrics(eng) if want_metrics else None
     plan = {}     # chunk index -> (first, n, global pairs)
 

@@ -49,12 +49,16 @@ class ChunkLoader(object):
     of input take the same path).  `depth` staging buffers rotate: a chunk handed out stays
     valid until `depth - 1` further chunks have been requested."""
 
-    def __init__(self, source, image_size, chunk, workers=8, depth=3, pinned=True, decode=decode_image):
+    def __init__(self, source, image_size, chunk, workers=8, depth=3, pinned=True, decode=decode_image, first_chunk=None):
+        """`first_chunk` (< chunk): length of the FIRST chunk only -- its decode is the one nothing overlaps, so a short
+        one (a tower batch) gets the GPU going while the first full chunk is still decoding; every later chunk is `chunk`
+        frames (deep launch queues: the consumer thread shares the interpreter with the decode and writer threads)."""
         import torch
         self.image_size = tuple(image_size)
         self.chunk = int(chunk)
         if self.chunk <= 0:
             raise ValueError('chunk must be positive')
+        self.first_chunk = self.chunk if not first_chunk else max(1, min(int(first_chunk), self.chunk))
         self.source = source
         self.T = len(source)
         self.workers = max(1, int(workers))
@@ -73,8 +77,17 @@ class ChunkLoader(object):
         self._held = []
         self._pool = None
 
+    def bounds(self):
+        """[(lo, hi)] of the chunks, in order."""
+        out, lo = [], 0
+        while lo < self.T:
+            hi = min(self.T, lo + (self.first_chunk if lo == 0 else self.chunk))
+            out.append((lo, hi))
+            lo = hi
+        return out
+
     def __len__(self):
-        return (self.T + self.chunk - 1) // self.chunk
+        return len(self.bounds())
 
     def _fill(self, buf, lo, hi):
         dst = buf.numpy()
@@ -94,8 +107,7 @@ class ChunkLoader(object):
 
     def _produce(self):
         try:
-            for lo in range(0, self.T, self.chunk):
-                hi = min(self.T, lo + self.chunk)
+            for lo, hi in self.bounds():
                 b = self.free.get()
                 if b is None:
                     return

@@ -125,3 +125,15 @@ def test_confident_points_reads_records_like_the_vis_tools(tmp_path):
     np.save(p, rec[..., :3])
     with pytest.raises(ValueError):
         confident_points(p)
+
+
+def test_chunk_loader_short_first_chunk(tmp_path):
+    """first_chunk: only the first chunk is short (its decode is exposed: get the GPU going early), the rest are `chunk`."""
+    from kfnet_amd.pipeline import ChunkLoader
+    frames, paths = _png_sequence(tmp_path, 11)
+    loader = ChunkLoader(paths, (6, 8), chunk=4, workers=2, pinned=False, first_chunk=2)
+    assert loader.bounds() == [(0, 2), (2, 6), (6, 10), (10, 11)] and len(loader) == 4
+    got = [(lo, host.numpy().copy()) for lo, host in loader]
+    assert [g[0] for g in got] == [0, 2, 6, 10] and [g[1].shape[0] for g in got] == [2, 4, 4, 1]
+    assert np.array_equal(np.concatenate([g[1] for g in got]), frames)
+    assert ChunkLoader(frames, (6, 8), chunk=4, pinned=False, first_chunk=9).bounds()[0] == (0, 4)     # never longer than a chunk

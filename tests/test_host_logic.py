@@ -144,8 +144,10 @@ def test_default_routes_of_the_3x3_layers():
     g0, net0 = _build(2, winograd_f43_min_channels=0)
     assert all(type(op).__name__ != 'WinogradF43ConvOp' for op in g0.ops)
     # a single frame: launches of fewer than 128 F(4x4) workgroups (conv5: 10 tile blocks x 8 channel groups, conv6: 10 x 4,
-    # feat5: 40 x 1) would leave most CUs idle and go to the F(2x2,3x3) kernels; conv4b (10 x 16 = 160) stays
-    g1, net1 = _build(1)
+    # feat5: 40 x 1) would leave most CUs idle and go to the F(2x2,3x3) kernels; conv4b (10 x 16 = 160) stays -- round 4's
+    # routing, which is what Graph.winograd_f43_max_k_split = 1 restores (round 5 splits their input channels instead:
+    # test_f43_split_k_is_chosen_for_single_frames_only)
+    g1, net1 = _build(1, winograd_f43_max_k_split=1)
     by1 = {}
     for op in g1.ops:
         by1.setdefault(op.name, op)
@@ -153,7 +155,7 @@ def test_default_routes_of_the_3x3_layers():
     assert WinogradF43ConvOp.workgroups(by1['conv5'].x.shape, 512) == 80
     assert [type(by1[n]).__name__ for n in ('conv4b', 'conv5', 'conv6', 'feat5')] == \
         ['WinogradF43ConvOp', 'WinogradFusedConvOp', 'WinogradFusedConvOp', 'WinogradFusedConvOp']
-    g1b, _ = _build(1, winograd_f43_min_workgroups=0)
+    g1b, _ = _build(1, winograd_f43_min_workgroups=0, winograd_f43_max_k_split=1)
     assert sum(type(op).__name__ == 'WinogradF43ConvOp' for op in g1b.ops) == 7
     # executed MFMA FLOPs of the two-wave form: all 64 channels in one column block (no padding to 128)
     op = by2['conv1b']
