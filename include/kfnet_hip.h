@@ -242,6 +242,12 @@ int kfn_conv2d_winograd_fused(const kfn_conv_desc* desc, const float* x, const v
 int kfn_winograd_s2_supported(const kfn_conv_desc* desc);
 int kfn_conv2d_winograd_s2(const kfn_conv_desc* desc, const float* x, const void* u2_packed, const float* bias,
                            float* y, void* stream);
+/* Split-K form of the eight-wave stride-2 kernel (fp32 operands, u2b_packed = the pair packing; Cout % 4 == 0, ldy % 4 == 0,
+ * y 16-byte aligned) for launches that leave the chip partly idle: semantics, workspace layout ([k_split][N*Ho*Wo][Cout]
+ * floats) and determinism exactly as kfn_conv2d_winograd_f43_splitk below; the planes are reduced by the same second kernel. */
+int kfn_winograd_s2_splitk_workspace_bytes(const kfn_conv_desc* desc, int k_split, size_t* bytes);
+int kfn_conv2d_winograd_s2_splitk(const kfn_conv_desc* desc, const float* x, const void* u2b_packed, const float* bias,
+                                  float* y, float* workspace, int k_split, void* stream);
 
 /* Winograd F(4x4,3x3) for the same 3x3 stride-1 'same' convolutions (csrc/kfn_wino4.hip, round 4): 36 products per
  * 4x4 outputs -- 2.25 multiplies per output instead of 4 (F(2x2,3x3)) or 9 (direct) -- interpolation points

@@ -78,6 +78,8 @@ SYMBOLS = {
     'kfn_winograd_fused_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_conv2d_winograd_s2': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_s2_supported': (_i, [C.POINTER(ConvDesc)]),
+    'kfn_winograd_s2_splitk_workspace_bytes': (_i, [C.POINTER(ConvDesc), _i, C.POINTER(_sz)]),
+    'kfn_conv2d_winograd_s2_splitk': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'kfn_conv2d_winograd_f43': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'kfn_winograd_f43_supported': (_i, [C.POINTER(ConvDesc)]),
     'kfn_winograd_lds_bytes': (_i, [C.POINTER(ConvDesc), C.POINTER(_i)]),

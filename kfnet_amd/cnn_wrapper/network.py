@@ -331,7 +331,15 @@ class Network(object):
                 and WinogradS2ConvOp.supported(input.shape, cin, filters)
                 and g.winograd_lds_fits(2, cin, filters, _lib.WINO_FORM_S2_EIGHT_WAVE if e8 else 0)):
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel_b if e8 else pack_winograd_s2_kernel)
-            self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, eight_wave=e8))
+            ksplit = 1
+            if e8 and g.winograd_s2_max_k_split > 1 and filters % 4 == 0:
+                ksplit = WinogradS2ConvOp.best_k_split(WinogradS2ConvOp.base_workgroups(y.shape), cin,
+                                                       y.shape[0] * y.shape[1] * y.shape[2] * filters * 4, g.winograd_s2_max_k_split)
+            op = WinogradS2ConvOp(name, input, y, kern, bias, relu, eight_wave=e8, k_split=ksplit)
+            if ksplit > 1:
+                op.workspace = Storage((op.workspace_bytes() + 3) // 4, 'f32')     # private: see the F(4x4) split above
+                g.storages.append(op.workspace)
+            self._emit(op)
             return y
         if (k == 3 and strides == 1 and wmin and cin >= wmin and filters >= wmin and filters % 4 == 0
                 and min(h, w) >= 8):

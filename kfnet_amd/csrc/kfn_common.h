@@ -64,6 +64,9 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int wino_f43_lds_bytes(int wino_form);     // kfn_wino4.hip: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE
 int wino_s2_lds_bytes(int wino_form, int operand_dtype);   // kfn_wino_s2.hip: AUTO (four waves) / KFN_WINO_FORM_S2_EIGHT_WAVE
 int wino_fused_lds_bytes(const kfn_conv_desc* d);   // kfn_wino3.hip: the form kfn_conv2d_winograd_fused routes `d` to
+// y[pix][c] = relu(bias[c] + sum_s ws[s][pix][c]), s ascending (kfn_wino4.hip): the second launch of the split-K forms
+int launch_splitk_reduce(const float* ws, int k_split, long pixels, const float* bias, int relu, float* y, int Cout, int ldy,
+                         hipStream_t stream);
 constexpr int WINO2_LDS_BYTES = 2 * 16384;          // wino2_kernel's two raw-patch buffers (kfn_wino2.hip asserts it)
 
 // kfn_conv_desc crosses the ABI by pointer and grows at its end; `struct_size` (first member) says how many bytes the

@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
 
 // y[pix][c] = relu(bias[c] + sum_s ws[s][pix][c]), s = 0 .. k_split-1 in THAT order (one fixed order: deterministic, and the
 // same for every launch geometry).  ws planes are dense [pixels][Cout]; one float4 per thread.
-__global__ __launch_bounds__(256) void wino4_splitk_reduce_kernel(const f32x4* __restrict__ ws, int k_split, long plane_quads,
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ ws, int k_split, long plane_quads,
                                                                   const float* __restrict__ bias, int relu, float* __restrict__ y,
                                                                   int Cout, int ldy, long pixels) {
   const int cq = Cout >> 2;
@@ -1301,11 +1301,16 @@ extern "C" int kfn_conv2d_winograd_f43_splitk(const kfn_conv_desc* d, const floa
   KFN_REQUIRE((long)a.tiles_m * a.tiles_n * k_split < (1L << 31), "kfn_conv2d_winograd_f43_splitk: grid too large");
   rc = wino4b_launch(a, (hipStream_t)stream);
   if (rc != KFN_OK) return rc;
-  const long quads = pixels * (d->Cout / 4);
+  return kfn::launch_splitk_reduce(workspace, k_split, pixels, bias, d->relu, y, d->Cout, d->ldy, (hipStream_t)stream);
+}
+
+int kfn::launch_splitk_reduce(const float* ws, int k_split, long pixels, const float* bias, int relu, float* y, int Cout, int ldy,
+                              hipStream_t stream) {
+  const long quads = pixels * (Cout / 4);
   long blocks = (quads + 255) / 256;
   if (blocks > 256L * 8) blocks = 256L * 8;
-  hipLaunchKernelGGL(wino4_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const f32x4*>(workspace), k_split, quads, bias, d->relu, y, d->Cout, d->ldy, pixels);
-  KFN_LAUNCH_CHECK("wino4_splitk_reduce_kernel");
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const f32x4*>(ws), k_split, quads, bias, relu, y, Cout, ldy, pixels);
+  KFN_LAUNCH_CHECK("splitk_reduce_kernel");
   return KFN_OK;
 }

@@ -103,6 +103,10 @@ struct WinoS2Args {
   unsigned long long x_bytes;
   unsigned long long y_bytes;
   unsigned u_bytes;
+  // split-K (wino_s2b_kernel only; kfn_conv2d_winograd_s2_splitk): k_split copies of the tile grid, copy s accumulates
+  // super-steps [s * ss_per_split, ..) and writes RAW partial sums into plane s of the workspace (cf. kfn_wino4.hip)
+  int k_split, ss_per_split;
+  unsigned long long y_split_bytes;
 };
 
 template <int I, int N, class F>
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nwg = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap_s2(blockIdx.x, nwg);
+  const int split = p.k_split > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;      // K split slowest
+  const int tile = xcd_remap_s2((int)blockIdx.x - split * nwg, nwg);
   const int per = p.tiles_m * p.n_group;
   const int gset = tile / per, rem_ = tile - gset * per;
   const int tm = rem_ / p.n_group;
@@ -501,8 +506,10 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
   const int pt = 8 * ptr_ + ptc, pk = pq8 & 3;
   const int v_st = (pq8 >> 2) * SB_VBUF + ps * 13 * SB_VPOS + pk * 64 + (((pt & 15) ^ pk) * 4) + (pt >> 4) * 2;   // floats
   const int n_chunks = p.Cin / 8;
-  const int n_super = n_chunks / 2;
+  const int ks0 = split * p.ss_per_split;                                   // first super-step of this split (0 without split-K)
+  const int n_super = p.k_split > 1 ? ((n_chunks / 2 - ks0) < p.ss_per_split ? (n_chunks / 2 - ks0) : p.ss_per_split) : n_chunks / 2;
   const int s_last = n_super - 1;
+  const int c_base = 2 * ks0;
 
   // ---- CONSUMER ----
   const int rl = lane & 15, kl = lane >> 4;
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
   auto p_gather = [&](auto ic, int ss) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const int sc = ss < s_last ? ss : s_last;
-    pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, goff[i], (unsigned)(sc * (SS_CH * 4)), 0));
+    pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, goff[i], (unsigned)((ks0 + sc) * (SS_CH * 4)), 0));
   };
   // (d0, d1, d2) -> (d0 - d1, d1, d1 - d2) along the transformed axes; the two half-waves differ (see wino_s2_kernel): lanes
   // 0-31 the 3x3 (even,even) patch pv[3m+n] rows then columns, lanes 32-63 (even,odd) pv[2m+n] along m and (odd,even)
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
   };
   auto b_load = [&](auto qc_, int ch) __attribute__((always_inline)) {     // fragment pair q of chunk ch
     constexpr int q = decltype(qc_)::value;
-    const int qi = ch * (NFRAG / 2) + q;
+    const int qi = (c_base + ch) * (NFRAG / 2) + q;
     const int qc = qi < q_last ? qi : q_last;
     bq[q] = bload(rsU, voff_b, (unsigned)qc * b_step);
   };
@@ -631,7 +638,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
   const unsigned long long y_base = (unsigned long long)img0 * p.Ho * p.Wo * p.ldy * 4ull;
   const unsigned long long y_rest = p.y_bytes - y_base;
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+      reinterpret_cast<char*>(p.y) + y_base + (unsigned long long)split * p.y_split_bytes, 0,
+      (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
   auto out_transform = [&](auto&& put) __attribute__((always_inline)) {
 #pragma unroll
     for (int th = 0; th < 2; ++th)
@@ -711,10 +719,11 @@ extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
   return 1;
 }
 
-extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias,
-                                      float* y, void* stream) {
-  KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
-  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2");
+namespace {
+// `d` normalised; y / ldy = where the kernel writes (the output tensor, or plane 0 of the split-K workspace); k_split > 1:
+// the eight-wave kernel on k_split copies of the tile grid, raw partial sums (the caller passes bias = nullptr, relu = 0)
+int s2_launch(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias, float* y, int ldy, int relu,
+              int k_split, void* stream) {
   KFN_REQUIRE(d->x_dtype == KFN_ACT_F32 && d->y_dtype == KFN_ACT_F32,
               "kfn_conv2d_winograd_s2: fp32 activations in memory only (x_dtype / y_dtype = KFN_ACT_F16 is implemented by kfn_conv2d_nhwc)");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 2 && !d->transposed,
@@ -726,7 +735,7 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
     return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2: Cin=%d must be a multiple of %d", d->Cin, SS_CH);
   if ((d->H / 2 + 1) / 2 < BH)
     return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2: H=%d is below %d rows", d->H, 4 * BH - 2);
-  KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0 && d->Cout > 0 && d->ldy >= d->Cout &&
+  KFN_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0 && d->Cout > 0 && ldy >= d->Cout &&
                   d->cout_pad >= d->Cout && d->cout_pad % 32 == 0,
               "kfn_conv2d_winograd_s2: bad strides / channel counts");
   KFN_REQUIRE(d->epilogue == KFN_EPI_NONE && (d->operand_dtype == KFN_OPERAND_F32 || d->operand_dtype == KFN_OPERAND_F16),
@@ -735,13 +744,13 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u2_packed)) & 15) == 0,
               "kfn_conv2d_winograd_s2: buffers must be 16-byte aligned");
   const long img_b = (long)d->H * d->W * d->ldx * 4L;
-  const long out_b = (long)(d->H / 2) * (d->W / 2) * d->ldy * 4L;
+  const long out_b = (long)(d->H / 2) * (d->W / 2) * ldy * 4L;
   KFN_REQUIRE(2 * img_b < (1L << 31) && 2 * out_b < (1L << 31) && 16L * d->cout_pad * d->Cin * 4L < (1L << 31),
               "kfn_conv2d_winograd_s2: image or kernel beyond 2 GiB of 32-bit offsets");
   WinoS2Args a;
   a.x = x; a.u2 = static_cast<const float*>(u2_packed); a.bias = bias; a.y = y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = d->ldy;
+  a.Cout = d->Cout; a.cout_pad = d->cout_pad; a.ldy = ldy;
   a.Ho = d->H / 2; a.Wo = d->W / 2;
   a.Th = (a.Ho + 1) / 2; a.Tw = (a.Wo + 1) / 2;
   const long vrows = (long)d->N * a.Th;
@@ -751,7 +760,7 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   a.tiles_n = kfn::ceil_div(d->cout_pad, NT);
   KFN_REQUIRE(tiles_m * a.tiles_n < (1L << 31), "kfn_conv2d_winograd_s2: grid too large");
   a.tiles_m = (int)tiles_m;
-  a.relu = d->relu;
+  a.relu = relu;
   {
     // AUTO: two channel groups of a tile block adjacent (round 4, profiles/r04_wino4_microbench.log: conv4a 7.19 ms against
     // 7.34 with all eight adjacent and 7.29 with the tile blocks fastest; conv3a / conv2a within 1 % of each other)
@@ -762,13 +771,25 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
     if (ng < 1 || ng > a.tiles_n || a.tiles_n % ng != 0) ng = KFN_WINO_DEFAULT_N_FAST ? a.tiles_n : 1;
     a.n_group = ng;
   }
-  a.wide_store = (d->Cout % 4 == 0 && d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
+  a.wide_store = (d->Cout % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 1 : 0;
   const long in_pix = (long)d->N * d->H * d->W, out_pix = (long)d->N * a.Ho * a.Wo;
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
-  a.y_bytes = (unsigned long long)(((out_pix - 1) * d->ldy + d->Cout) * 4L);
+  a.y_bytes = (unsigned long long)(((out_pix - 1) * ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)(16L * d->cout_pad * d->Cin * (h16 ? 2L : 4L));
-  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(64 * NWAVE);
-  if (d->wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE) {
+  a.k_split = 1;
+  a.ss_per_split = d->Cin / SS_CH;
+  a.y_split_bytes = 0;
+  if (k_split > 1) {
+    const int n_super = d->Cin / SS_CH;
+    a.k_split = k_split;
+    a.ss_per_split = kfn::ceil_div(n_super, k_split);
+    KFN_REQUIRE((long)(k_split - 1) * a.ss_per_split < n_super, "kfn_conv2d_winograd_s2_splitk: k_split=%d leaves an empty split of %d super-steps",
+                k_split, n_super);
+    a.y_split_bytes = (unsigned long long)out_pix * d->Cout * 4ull;
+    KFN_REQUIRE((long)a.tiles_m * a.tiles_n * k_split < (1L << 31), "kfn_conv2d_winograd_s2_splitk: grid too large");
+  }
+  const dim3 grid((unsigned)((long)a.tiles_m * a.tiles_n * a.k_split)), block(64 * NWAVE);
+  if (d->wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE || k_split > 1) {
     // the eight-wave form: fp32 operands only, weights packed per pair of fragments (graph.pack_winograd_s2_kernel_b)
     if (h16) return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2: the eight-wave form takes fp32 operands only");
     static std::atomic<uint64_t> attr_done_b{0};
@@ -791,4 +812,44 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
   }
   KFN_LAUNCH_CHECK("wino_s2_kernel");
   return KFN_OK;
+}
+}  // namespace
+
+extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias,
+                                      float* y, void* stream) {
+  KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2");
+  return s2_launch(d, x, u2_packed, bias, y, d->ldy, d->relu, 1, stream);
+}
+
+// ---- split-K form of the eight-wave kernel (round 5; cf. kfn_conv2d_winograd_f43_splitk): BASELINE configs[1]'s conv4a launches
+// 320 workgroups at batch 1 = two rounds on 256 CUs, the second a quarter full.
+extern "C" int kfn_winograd_s2_splitk_workspace_bytes(const kfn_conv_desc* d, int k_split, size_t* bytes) {
+  KFN_REQUIRE(d && bytes, "kfn_winograd_s2_splitk_workspace_bytes: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_winograd_s2_splitk_workspace_bytes");
+  KFN_REQUIRE(k_split >= 1 && d->N > 0 && d->H > 1 && d->W > 1 && d->Cout > 0, "kfn_winograd_s2_splitk_workspace_bytes: bad argument");
+  *bytes = k_split > 1 ? (size_t)k_split * d->N * (d->H / 2) * (d->W / 2) * d->Cout * sizeof(float) : 0;
+  return KFN_OK;
+}
+
+extern "C" int kfn_conv2d_winograd_s2_splitk(const kfn_conv_desc* d, const float* x, const void* u2b_packed, const float* bias,
+                                             float* y, float* workspace, int k_split, void* stream) {
+  KFN_REQUIRE(d && x && u2b_packed && y, "kfn_conv2d_winograd_s2_splitk: null argument");
+  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2_splitk");
+  KFN_REQUIRE((d->wino_form == KFN_WINO_FORM_AUTO || d->wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE) && d->operand_dtype == KFN_OPERAND_F32,
+              "kfn_conv2d_winograd_s2_splitk: the eight-wave form only (fp32 operands, weights packed per pair of fragments)");
+  const int n_super = d->Cin > 0 ? d->Cin / SS_CH : 0;
+  KFN_REQUIRE(k_split >= 1 && k_split <= (n_super > 0 ? n_super : 1), "kfn_conv2d_winograd_s2_splitk: k_split=%d outside 1..%d (Cin/16)",
+              k_split, n_super);
+  kfn_conv_desc d8 = *d;
+  d8.wino_form = KFN_WINO_FORM_S2_EIGHT_WAVE;
+  if (k_split == 1) return s2_launch(&d8, x, u2b_packed, bias, y, d->ldy, d->relu, 1, stream);
+  KFN_REQUIRE(workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && d->Cout % 4 == 0 && d->ldy >= d->Cout &&
+                  d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+              "kfn_conv2d_winograd_s2_splitk: k_split > 1 needs a 16-byte aligned workspace of kfn_winograd_s2_splitk_workspace_bytes(), "
+              "Cout %% 4 == 0 and a 16-byte aligned output with ldy %% 4 == 0");
+  int rc = s2_launch(&d8, x, u2b_packed, nullptr, workspace, d->Cout, 0, k_split, stream);
+  if (rc != KFN_OK) return rc;
+  const long pixels = (long)d->N * (d->H / 2) * (d->W / 2);
+  return kfn::launch_splitk_reduce(workspace, k_split, pixels, bias, d->relu, y, d->Cout, d->ldy, (hipStream_t)stream);
 }

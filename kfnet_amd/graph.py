@@ -383,6 +383,33 @@ def pack_bias(b):
     return np.ascontiguousarray(b.astype(np.float32))
 
 
+def split_k_launch_us(workgroups, n_super, k_split, out_bytes, ss_us, fixed_us=10.0, reduce_us=4.0, reduce_bps=4.0e12, cus=256):
+    """Cost model (microseconds) of a one-workgroup-per-CU Winograd launch whose input channels are cut into k_split runs:
+    rounds of `cus` workgroups x (super-steps of a run x ss_us + the workgroup's prologue / epilogue) + the reduce launch and
+    its workspace traffic.  Constants measured at batch 1 and 32 (profiles/r05_*)."""
+    rounds = -(-(workgroups * k_split) // cus)
+    t = rounds * (-(-n_super // k_split) * ss_us + fixed_us)
+    if k_split > 1:
+        t += reduce_us + (k_split + 1) * out_bytes / reduce_bps * 1e6
+    return t
+
+
+def best_split_k(workgroups, n_super, out_bytes, ss_us, max_split=8, cus=256, only_below_cus=True):
+    """The split that minimises split_k_launch_us; 1 unless splitting wins by more than 10 % (a split launch is two launches
+    and a workspace round trip).  only_below_cus: never split a launch that already has a workgroup for every CU."""
+    if n_super < 2 or max_split < 2 or (only_below_cus and workgroups >= cus):
+        return 1
+    base = split_k_launch_us(workgroups, n_super, 1, out_bytes, ss_us, cus=cus)
+    best, best_t = 1, base
+    for ks in range(2, min(max_split, n_super) + 1):
+        if (ks - 1) * (-(-n_super // ks)) >= n_super:     # an empty last run
+            continue
+        t = split_k_launch_us(workgroups, n_super, ks, out_bytes, ss_us, cus=cus)
+        if t < best_t:
+            best, best_t = ks, t
+    return best if best_t < 0.9 * base else 1
+
+
 class ConvOp(Op):
     def __init__(self, name, x, y, kernel, bias, kh, kw, stride, relu, transposed=False,
                  epilogue=_lib.EPI_NONE, config=_lib.CFG_AUTO, operand_dtype=_lib.OPERAND_F32):
@@ -601,34 +628,17 @@ class WinogradF43ConvOp(ConvOp):
         self.k_split = int(k_split)      # > 1: kfn_conv2d_winograd_f43_splitk (eight-wave form only) with the graph's shared workspace
         self.workspace = workspace
 
-    # cost model of a launch on `cus` CUs, in microseconds (measured at batch 1 and 32, profiles/r05_*): a super-step of 16
-    # input channels 3.8, prologue + epilogue of a workgroup 10, the reduce launch 4 + its traffic at 4 TB/s
-    SS_US, FIXED_US, REDUCE_US, REDUCE_BPS = 3.8, 10.0, 4.0, 4.0e12
+    SS_US = 3.8      # one super-step (16 input channels) of a workgroup: 144 MFMAs of 32 cycles on each of two waves per SIMD
 
     @classmethod
     def launch_us(cls, workgroups, n_super, k_split, out_bytes, cus=256):
-        rounds = -(-(workgroups * k_split) // cus)
-        t = rounds * (-(-n_super // k_split) * cls.SS_US + cls.FIXED_US)
-        if k_split > 1:
-            t += cls.REDUCE_US + (k_split + 1) * out_bytes / cls.REDUCE_BPS * 1e6
-        return t
+        return split_k_launch_us(workgroups, n_super, k_split, out_bytes, cls.SS_US, cus=cus)
 
     @classmethod
     def best_k_split(cls, workgroups, cin, out_bytes, max_split=8, cus=256):
-        """Split of the input channels that minimises launch_us; 1 unless the unsplit launch leaves CUs idle (fewer workgroups
-        than CUs) and splitting wins by more than 10 % (a split launch is two launches and a workspace round trip)."""
-        n_super = cin // 16
-        if workgroups >= cus or n_super < 2:
-            return 1
-        base = cls.launch_us(workgroups, n_super, 1, out_bytes, cus)
-        best, best_t = 1, base
-        for ks in range(2, min(max_split, n_super) + 1):
-            if (ks - 1) * (-(-n_super // ks)) >= n_super:     # an empty last run
-                continue
-            t = cls.launch_us(workgroups, n_super, ks, out_bytes, cus)
-            if t < best_t:
-                best, best_t = ks, t
-        return best if best_t < 0.9 * base else 1
+        """Split of the input channels for a launch of fewer workgroups than CUs (single frames: conv4b 160, conv5 80, conv6
+        40 workgroups on 256 CUs)."""
+        return best_split_k(workgroups, cin // 16, out_bytes, cls.SS_US, max_split, cus)
 
     def desc(self):
         d = ConvOp.desc(self)
@@ -756,8 +766,12 @@ class WinogradS2ConvOp(ConvOp):
     """3x3 stride-2 SAME conv of an even-sized image through kfn_conv2d_winograd_s2 (polyphase + F(2,2):
     25 MFMA streams into 9 accumulators per 2x2 outputs instead of 36 direct taps)."""
 
-    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32, eight_wave=False):
+    SS_US = 5.3      # one super-step of wino_s2b_kernel: 200 MFMAs of 32 cycles on each of two waves per SIMD
+
+    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32, eight_wave=False, k_split=1, workspace=None):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu, operand_dtype=operand_dtype)
+        self.k_split = int(k_split)      # > 1: kfn_conv2d_winograd_s2_splitk (eight-wave form, fp32) with a private workspace
+        self.workspace = workspace
         # wino_s2b_kernel (two waves per SIMD on 16x16x4 MFMA tiles; fp32 operands; weights packed per pair of fragments,
         # pack_winograd_s2_kernel_b) instead of wino_s2_kernel
         self.eight_wave = bool(eight_wave) and operand_dtype == _lib.OPERAND_F32
@@ -774,6 +788,8 @@ class WinogradS2ConvOp(ConvOp):
         return cin % 16 == 0 and h % 2 == 0 and w % 2 == 0 and (h // 2 + 1) // 2 >= 4
 
     def kernel_name(self, lib):
+        if self.k_split > 1:
+            return 'wino_s2b_kernel[split-K %d] + splitk_reduce_kernel' % self.k_split
         if self.eight_wave:
             return 'wino_s2b_kernel'
         return 'wino_s2_kernel<true>' if self.operand_dtype == _lib.OPERAND_F16 else 'wino_s2_kernel'
@@ -792,12 +808,35 @@ class WinogradS2ConvOp(ConvOp):
         n, ho, wo, cout = self.y.shape
         n = _scaled(n, self.x.graph)
         th, tw = (ho + 1) // 2, (wo + 1) // 2
+        return (-(-tw // 8)) * (-(-(n * th) // 4)) * (-(-cout // 128)) * max(1, self.k_split)
+
+    @staticmethod
+    def base_workgroups(y_shape):
+        n, ho, wo, cout = y_shape
+        th, tw = (ho + 1) // 2, (wo + 1) // 2
         return (-(-tw // 8)) * (-(-(n * th) // 4)) * (-(-cout // 128))
+
+    @classmethod
+    def best_k_split(cls, workgroups, cin, out_bytes, max_split=8, cus=256):
+        """Unlike the F(4x4) rule this one also splits launches a little ABOVE one round (conv4a at batch 1: 320 workgroups =
+        two rounds, the second a quarter full) -- up to two rounds."""
+        if workgroups >= 2 * cus:
+            return 1
+        return best_split_k(workgroups, cin // 16, out_bytes, cls.SS_US, max_split, cus, only_below_cus=False)
+
+    def workspace_bytes(self):
+        n, ho, wo, cout = self.y.shape
+        return self.k_split * _scaled(n, self.x.graph) * ho * wo * cout * 4 if self.k_split > 1 else 0
 
     def launch(self, lib, stream, phases=3):
         d = self.desc()
-        rc = lib.kfn_conv2d_winograd_s2(C.byref(d), self.x.ptr, self.kernel.ptr,
-                                        self.bias.ptr if self.bias is not None else None, self.y.ptr, stream)
+        bias = self.bias.ptr if self.bias is not None else None
+        if self.k_split > 1:
+            rc = lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), self.x.ptr, self.kernel.ptr, bias, self.y.ptr, self.workspace.ptr,
+                                                   self.k_split, stream)
+            _lib.check(rc, 'kfn_conv2d_winograd_s2_splitk[%s]' % self.name)
+            return
+        rc = lib.kfn_conv2d_winograd_s2(C.byref(d), self.x.ptr, self.kernel.ptr, bias, self.y.ptr, stream)
         _lib.check(rc, 'kfn_conv2d_winograd_s2[%s]' % self.name)
 
 
@@ -1300,6 +1339,7 @@ class Graph(object):
         # split-K for F(4x4,3x3) launches of fewer workgroups than CUs (single frames: conv4b 160, conv5 80, conv6 40): the
         # split WinogradF43ConvOp.best_k_split picks (eight-wave form; 0 / 1 = never split)
         self.winograd_f43_max_k_split = 8
+        self.winograd_s2_max_k_split = 8         # the same for the eight-wave stride-2 kernel (conv4a at batch 1: 320 workgroups)
         # the eight-wave form of the F(4x4,3x3) kernel (wino4b_kernel; measured at batch 32 against the four-wave form, same
         # box: conv1b 2.66 -> 2.34 ms, conv2b 6.98 -> 6.54, conv3b 6.43 -> 6.13, conv4b 6.08 -> 5.85)
         self.winograd_f43_eight_wave = True

@@ -1441,3 +1441,61 @@ def test_winograd_f43_splitk_rejects_bad_splits():
     assert lib.kfn_conv2d_winograd_f43_splitk(*args(2, None)) != 0 and b'workspace' in lib.kfn_last_error()
     d4 = _lib.ConvDesc(N=1, H=32, W=32, Cin=64, ldx=64, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1, wino_form=2)
     assert lib.kfn_conv2d_winograd_f43_splitk(C.byref(d4), buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), buf.data_ptr(), 2, None) != 0
+
+
+@pytest.mark.parametrize('case,k_split', [((1, 120, 160, 512, 1024), 4), ((2, 14, 18, 32, 160), 2), ((1, 64, 96, 64, 128), 3),
+                                          ((1, 30, 34, 48, 36), 3), ((2, 60, 80, 256, 256), 1)])
+def test_winograd_s2_splitk_vs_oracle(case, k_split):
+    """kfn_conv2d_winograd_s2_splitk (eight-wave polyphase kernel, input channels cut into k_split runs, planes reduced in a
+    fixed order): == the oracle's stride-2 SAME convolution within the polyphase bound, bit-identical from run to run, the
+    unsplit launch differs by summation order only; strided output, guards untouched.  (1,120,160,512,1024) = conv4a at
+    batch 1, the layer the split is for."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_s2_kernel_b
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    ho, wo = h // 2, w // 2
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 29)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy = co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3, stride=2, relu=1,
+                      wino_form=4)
+    nb = C.c_size_t()
+    _lib.check(lib.kfn_winograd_s2_splitk_workspace_bytes(C.byref(d), k_split, C.byref(nb)), 'ws bytes')
+    assert nb.value == (k_split * n * ho * wo * co * 4 if k_split > 1 else 0)
+    GUARD = 64
+    ws = torch.full((nb.value // 4 + GUARD,), -7.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_s2_kernel_b(wt)), dev(b)
+    outs = []
+    for rep in range(2):
+        y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
+        _lib.check(lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                                     ws.data_ptr(), k_split, stream()), 's2 split-K')
+        sync()
+        got = y.cpu().numpy()
+        assert np.all(got[:, co:] == -5.0) and np.all(got[n * ho * wo:] == -5.0)
+        outs.append(got[:n * ho * wo, :co].copy())
+    assert bool((ws[nb.value // 4:] == -7.0).all()), 'the partial sums went past the workspace'
+    assert np.array_equal(outs[0], outs[1]), 'split-K result changes from run to run'
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 2, True)
+    _check_err(np.abs(outs[0].reshape(ref.shape) - ref).max(), x, wt, 'f22s2', 'wino s2 split-K %d %s' % (k_split, case))
+    y1 = torch.full((n * ho * wo, ldy), -5.0, device='cuda')
+    _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y1.data_ptr(), stream()), 's2')
+    sync()
+    un = y1.cpu().numpy()[:, :co]
+    assert np.abs(un - outs[0]).max() <= 2 * _conv_tol(x, wt, kind='f22s2')
+    if k_split == 1:
+        assert np.array_equal(un, outs[0])
+    # what the entry point refuses: a split with an empty run, a null workspace, the fp16 / four-wave forms
+    if k_split > 1:
+        n_super = ci // 16
+        assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), ws.data_ptr(),
+                                                 n_super + 1, stream()) != 0
+        assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), None, k_split, stream()) != 0
+        d16 = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3, stride=2,
+                            operand_dtype=1)
+        assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d16), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), ws.data_ptr(), k_split, stream()) != 0

@@ -580,7 +580,7 @@ def test_f43_split_k_is_chosen_for_single_frames_only():
     256 CUs -- Network.conv splits their input channels (WinogradF43ConvOp.best_k_split) so that the launch fills the chip; every
     split layer owns a private workspace (the two towers run on two streams).  At the bench batch nothing is split."""
     from kfnet_amd.cnn_wrapper.SCoordNet import SCoordNet
-    from kfnet_amd.graph import Graph, WinogradF43ConvOp, variable_scope
+    from kfnet_amd.graph import Graph, WinogradF43ConvOp, WinogradS2ConvOp, variable_scope
 
     def build(batch):
         g = Graph()
@@ -599,6 +599,12 @@ def test_f43_split_k_is_chosen_for_single_frames_only():
     assert f1['conv2b'].workspace is None
     g32, f32 = build(32)
     assert set(f32) == set(f1) and all(v.k_split == 1 and v.workspace is None for v in f32.values())
+    # the stride-2 layers: conv4a at batch 1 is 320 workgroups = two rounds, the second a quarter full -> 4 runs (1280 = 5 rounds)
+    s1 = {op.name: op for op in g1.ops if isinstance(op, WinogradS2ConvOp)}
+    assert {k: v.k_split for k, v in s1.items()} == {'conv2a': 1, 'conv3a': 1, 'conv4a': 4}
+    assert s1['conv4a'].workspace in g1.storages and s1['conv4a'].launch_workgroups() == 1280 if hasattr(s1['conv4a'], 'launch_workgroups') \
+        else s1['conv4a'].workgroups() == 1280
+    assert all(op.k_split == 1 for op in g32.ops if isinstance(op, WinogradS2ConvOp))
     # the switch: Graph.winograd_f43_max_k_split = 1 restores round 4's routing (conv5 / conv6 on the F(2x2,3x3) kernel at batch 1)
     g = Graph()
     g.winograd_f43_max_k_split = 1
