@@ -90,6 +90,7 @@ def parse():
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='c3 on one GPU: skip the config5_960x540 / config2_single_frame blocks')
     ap.add_argument('--no-eval-png', action='store_true', help='skip the PNG -> coord_<i>.npy end-to-end block')
+    ap.add_argument('--eval-chunk', type=int, default=128, help='frames per host chunk of the PNG end-to-end block')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
@@ -590,7 +591,8 @@ def config3_literal(args, Wt, T4, transform_txt, device, dev_index, frames=256, 
         extra['host_streamed'] = host_streamed(eng, host, dev, chunk=128)
         if not args.no_eval_png:
             resident = eng.process(dev, t0=0).cpu().numpy()
-            extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index)
+            extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index,
+                                                               chunk=args.eval_chunk)
             hs = extra['host_streamed']['value']
             extra['eval_png_end_to_end']['fraction_of_host_streamed'] = round(extra['eval_png_end_to_end']['value'] / hs, 4)
     del eng, dev

@@ -68,7 +68,15 @@ class ChunkLoader(object):
             if source.dtype != np.uint8 or source.shape[1:] != (H, W, 3):
                 raise ValueError('frames must be uint8 [T,%d,%d,3]' % (H, W))
         self.depth = max(2, int(depth))
-        self.bufs = [_host_buffer((self.chunk, H, W, 3), torch.uint8, pinned) for _ in range(self.depth)]
+        # Page-locking costs ~0.3 ms per MB: three 128-frame buffers (354 MB) would add > 0.1 s in front of the first frame.
+        # Only the FIRST chunk's own small buffer is locked here; the rotating full-size buffers are allocated by the producer
+        # thread when it first needs them, i.e. beside the first chunk's compute.
+        self.pinned = bool(pinned)
+        self._torch = torch
+        self.bufs = [None] * self.depth
+        self.first_buf = None
+        if self.first_chunk < self.chunk and self.T > 0:
+            self.first_buf = _host_buffer((self.first_chunk, H, W, 3), torch.uint8, pinned)
         self.free = queue.Queue()
         for i in range(self.depth):
             self.free.put(i)
@@ -107,10 +115,17 @@ class ChunkLoader(object):
 
     def _produce(self):
         try:
+            H, W = self.image_size
             for lo, hi in self.bounds():
+                if lo == 0 and self.first_buf is not None:      # its own buffer, outside the rotation
+                    self._fill(self.first_buf, lo, hi)
+                    self.ready.put((lo, hi - lo, -1, None))
+                    continue
                 b = self.free.get()
                 if b is None:
                     return
+                if self.bufs[b] is None:
+                    self.bufs[b] = _host_buffer((self.chunk, H, W, 3), self._torch.uint8, self.pinned)
                 self._fill(self.bufs[b], lo, hi)
                 self.ready.put((lo, hi - lo, b, None))
             self.ready.put((None, 0, None, None))
@@ -133,6 +148,9 @@ class ChunkLoader(object):
                     raise err
                 if lo is None:
                     return
+                if b < 0:
+                    yield lo, self.first_buf[:n]
+                    continue
                 # recycle the buffer handed out depth-1 chunks ago
                 self._held.append(b)
                 if len(self._held) >= self.depth:
