@@ -90,6 +90,7 @@ def parse():
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='c3 on one GPU: skip the config5_960x540 / config2_single_frame blocks')
     ap.add_argument('--no-eval-png', action='store_true', help='skip the PNG -> coord_<i>.npy end-to-end block')
+    ap.add_argument('--block', type=int, default=32, help='multi-rank runs: frames per block of the block-cyclic sharding measured beside the contiguous one')
     ap.add_argument('--eval-chunk', type=int, default=128, help='frames per host chunk of the PNG end-to-end block')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
@@ -902,7 +903,8 @@ def chain_timing(run_with_timer, dist, device, world):
     t_abs = lambda r, name: allr[r]['t_origin_monotonic_s'] * 1e3 + allr[r]['ms_since_origin'][name]
     chain = t_abs(world - 1, 'scan_end') - t_abs(0, 'recv_end')
     scans = [a['scan_ms'] for a in allr]
-    return {'scan_chain_ms': round(chain, 4),
+    tail = max(t_abs(r, 'scan_end') for r in range(world)) - max(t_abs(r, 'heavy_end') for r in range(world))
+    return {'sharding': 'contiguous', 'scan_chain_ms': round(chain, 4), 'tail_ms': round(tail, 4),
             'scan_ms_per_rank': [round(x, 4) for x in scans],
             'heavy_ms_per_rank': [round(a['heavy_ms'], 3) for a in allr],
             'handoff_us': [{'recv_wait_us': None if a['recv_wait_us'] is None else round(a['recv_wait_us'], 1),
@@ -910,6 +912,64 @@ def chain_timing(run_with_timer, dist, device, world):
             'handoff_us_net': round((chain - sum(scans)) * 1e3 / max(world - 1, 1), 1),
             'note': 'one instrumented pass after the timed repetitions; HIP events on each rank\'s stream, origins '
                     'aligned through a barrier and time.monotonic()'}
+
+
+def cyclic_sharding_block(args, eng, rank, world, K, link, dist, device, backend):
+    """The same N*K-frame job with BLOCK-CYCLIC sharding (kfnet_amd.dist.run_cyclic: blocks of --block frames dealt round-robin,
+    the state hopping once per block) beside the contiguous chunks of the headline: timed the same way, plus one instrumented
+    pass whose `tail_ms` = last scan end over all ranks - last heavy-phase end over all ranks, i.e. the serial part nothing
+    hides (contiguous: world scans + world-1 hand-offs; cyclic: the start-up skew of one block's scan per rank).
+    Collective: every rank calls it."""
+    import torch
+    from kfnet_amd.dist import cyclic_blocks, needs_state, run_cyclic
+    from kfnet_amd.synth import synthetic_sequence
+    total = K * world
+    block = max(1, min(args.block, K, eng.max_chunk))
+    store = {}
+    for j, lo, hi in cyclic_blocks(total, block, rank, world):
+        need = 1 if needs_state(lo, 500) else 0
+        store[lo - need] = eng.upload_frames(synthetic_sequence(hi - lo + need, args.height, args.width, seed=1, start=lo - need))
+    frames_of = lambda lo, hi: store[lo][:hi - lo]
+    sink = lambda lo, rec: None
+    run = lambda stamp=None: run_cyclic(eng, frames_of, total, block, rank, world, link, on_block=sink, stamp=stamp)
+    run()
+    torch.cuda.synchronize()
+    times = timed_repetitions(run, dist, device, backend, args.min_seconds)
+    med = float(np.median(times))
+    # instrumented pass: HIP events on this rank's stream at every block's heavy end / scan start / scan end
+    ev = {}
+
+    def stamp(name, j):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(device))
+        ev[(name, j)] = e
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t_origin = time.monotonic()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(device))
+    run(stamp)
+    torch.cuda.synchronize()
+    rel = {k: float(e0.elapsed_time(e)) for k, e in ev.items()}
+    mine = {'t0': t_origin,
+            'last_heavy_end': max([v for (n_, _), v in rel.items() if n_ == 'heavy_end'], default=None),
+            'last_scan_end': max([v for (n_, _), v in rel.items() if n_ == 'scan_end'], default=None),
+            'recv_wait_ms': sum(rel[('scan_start', j)] - rel[('heavy_end', j)] for (n_, j) in rel if n_ == 'heavy_end'),
+            'scan_ms': sum(rel[('scan_end', j)] - rel[('scan_start', j)] for (n_, j) in rel if n_ == 'scan_end')}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    ab = lambda a, k: None if a[k] is None else a['t0'] * 1e3 + a[k]
+    ends = [ab(a, 'last_scan_end') for a in allr if a['last_scan_end'] is not None]
+    heavies = [ab(a, 'last_heavy_end') for a in allr if a['last_heavy_end'] is not None]
+    del store
+    return {'sharding': 'block-cyclic', 'block': block, 'blocks_total': -(-total // block),
+            'value': round(total / med, 3), 'unit': 'frames/s', 'ms_per_step': round(med * 1e3 / K, 4), 'repetitions': len(times),
+            'tail_ms': round(max(ends) - max(heavies), 4) if ends and heavies else None,
+            'recv_wait_ms_per_rank': [round(a['recv_wait_ms'], 3) for a in allr],
+            'scan_ms_per_rank': [round(a['scan_ms'], 3) for a in allr],
+            'note': 'same job, same timing protocol as the headline (contiguous chunks); tail_ms = serial part left exposed after the '
+                    'last heavy phase of any rank has ended'}
 
 
 def config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index, frames_per_rank=256, batch=32):
@@ -1071,6 +1131,8 @@ def main():
     if dist is not None:
         out['handoff'] = chain_timing(lambda timer: run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev, timer=timer),
                                       dist, device, world)
+        out['sharding'] = 'contiguous'       # of the headline `value`; the block-cyclic alternative is measured beside it
+        out['sharding_cyclic'] = cyclic_sharding_block(args, eng, rank, world, K, link, dist, device, backend)
         if world == 8 and K < 256 and not args.no_config3 and args.conv_operands == 'f32':
             out['config4_2048_frames'] = config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index)
     if rank == 0:
@@ -1226,7 +1288,8 @@ def main():
                 'parity_vs_fp32_path': pick(c5b.get('parity_vs_fp32_path'), 'unmasked_outside_tolerance', 'masked_fraction',
                                             'outside_tolerance_fraction', 'frames', 'sequences', 'crossings')},
             'config2_single_frame_ms': None if c2b is None else c2b['latency_ms'],
-            'handoff': pick(out.get('handoff'), 'scan_chain_ms', 'handoff_us_net'),
+            'handoff': pick(out.get('handoff'), 'scan_chain_ms', 'tail_ms', 'handoff_us_net'),
+            'sharding_cyclic': pick(out.get('sharding_cyclic'), 'value', 'block', 'tail_ms'),
             'config4_2048_frames': pick(out.get('config4_2048_frames'), 'value', 'ms_per_step'),
         }
         out['summary'] = {k: v for k, v in summ.items() if v is not None}

@@ -92,6 +92,39 @@ def eval_sharded(image_paths, transform, weights, output_folder, rank, world, li
     return lo, rec
 
 
+def eval_sharded_cyclic(image_paths, transform, weights, output_folder, rank, world, link, block, nis=False,
+                        image_size=(480, 640), batch=4, frames=None, sequence_length=RESET_PERIOD, verbose=True, device=None):
+    """Block-cyclic frame sharding (kfnet_amd.dist.run_cyclic): blocks of `block` frames dealt round-robin, block j on rank
+    j % world; the Kalman state hops rank -> rank+1 once per block, so a rank scans its block while the others are still in
+    the heavy phase of theirs.  Same records, bit for bit, as eval_sharded and as a single process.
+    Returns [(first_frame, records [n,h,w,4])] of this rank's blocks."""
+    import torch
+    from ..dist import run_cyclic
+    from ..engine import KFNetEngine
+    T = len(image_paths) if frames is None else frames.shape[0]
+    dev = device if device is not None else 'cuda:%d' % torch.cuda.current_device()
+    eng = KFNetEngine(weights, image_size=image_size, batch=batch, transform=transform, reset_period=sequence_length,
+                      nis_gate=7.815 if nis else 0.0, max_chunk=max(int(block), 1), device=dev)
+
+    def frames_of(lo, hi):       # only this rank's blocks (+ the frame in front of each) are ever decoded / uploaded
+        host = np.ascontiguousarray(frames[lo:hi]) if frames is not None else load_images(image_paths[lo:hi], image_size)
+        return eng.upload_frames(host)
+
+    out = []
+
+    def on_block(lo, rec):
+        r = rec.cpu().numpy().copy()
+        if output_folder and os.path.isdir(output_folder):
+            for k in range(r.shape[0]):
+                np.save(os.path.join(output_folder, 'coord_%d.npy' % (lo + k)), r[k].astype(np.float32))
+        out.append((lo, r))
+
+    run_cyclic(eng, frames_of, T, int(block), rank, world, link, on_block=on_block)
+    if verbose:
+        print('rank %d/%d: %d blocks of %d frames done (block-cyclic)' % (rank, world, len(out), block))
+    return out
+
+
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=RESET_PERIOD, chunk=256, verbose=True, label_paths=None, labels=None,
          decode_workers=8, device=None, metrics_sequence_length=1000, engine=None, save_workers=2):
@@ -207,6 +240,9 @@ def main(argv=None):
     ap.add_argument('--random_weights', action='store_true')
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--sharding', choices=['contiguous', 'cyclic'], default='contiguous',
+                    help='multi-process runs: contiguous chunks per rank, or blocks of --block frames dealt round-robin')
+    ap.add_argument('--block', type=int, default=32, help='--sharding cyclic: frames per block')
     a = ap.parse_args(argv)
     if a.scene not in SCENES:
         print('Invalid scene:', a.scene)   # KFNet/train.py:142-144
@@ -278,6 +314,14 @@ def _main_sharded(a, W, size, rank, world):
             part = synthetic_sequence(hi - first, a.height, a.width, start=first)
             frames = _ShiftedFrames(part, first, a.synthetic)
             transform = np.linalg.inv(synthetic_transform())
+            if a.sharding == 'cyclic':
+                # (the generator is a function of (seed, frame index): every rank synthesises only what its blocks need)
+                gen = _SyntheticFrames(a.synthetic, a.height, a.width)
+                eval_sharded_cyclic(None, transform, W, a.output_folder, rank, world, link, a.block, a.NIS, image_size=size,
+                                    batch=a.batch, frames=gen, sequence_length=RESET_PERIOD)
+                torch.cuda.synchronize()
+                dist.barrier()
+                return 0
             eval_sharded(None, transform, W, a.output_folder, rank, world, link, a.NIS, image_size=size,
                          batch=a.batch, frames=frames, sequence_length=RESET_PERIOD)
         else:
@@ -288,8 +332,12 @@ def _main_sharded(a, W, size, rank, world):
                       'no per-frame log line and no median summary will be printed.  Run single-process '
                       '(python -m kfnet_amd.KFNet.eval --gpu N ...) for the metrics.' % world, file=sys.stderr)
             image_paths = read_lines(os.path.join(a.input_folder, 'image_list.txt'))
-            eval_sharded(image_paths, get_transform(os.path.join(a.input_folder, 'transform.txt')), W,
-                         a.output_folder, rank, world, link, a.NIS, image_size=size, batch=a.batch)
+            if a.sharding == 'cyclic':
+                eval_sharded_cyclic(image_paths, get_transform(os.path.join(a.input_folder, 'transform.txt')), W,
+                                    a.output_folder, rank, world, link, a.block, a.NIS, image_size=size, batch=a.batch)
+            else:
+                eval_sharded(image_paths, get_transform(os.path.join(a.input_folder, 'transform.txt')), W,
+                             a.output_folder, rank, world, link, a.NIS, image_size=size, batch=a.batch)
         torch.cuda.synchronize()
         dist.barrier()
     finally:
@@ -297,6 +345,18 @@ def _main_sharded(a, W, size, rank, world):
             link.close()
         dist.destroy_process_group()
     return 0
+
+
+class _SyntheticFrames(object):
+    """The seeded synthetic sequence, generated slice by slice (frame t depends on (seed, t) alone)."""
+
+    def __init__(self, total, height, width):
+        self.shape = (total, height, width, 3)
+        self.h, self.w = height, width
+
+    def __getitem__(self, sl):
+        from ..synth import synthetic_sequence
+        return synthetic_sequence(sl.stop - sl.start, self.h, self.w, start=sl.start)
 
 
 class _ShiftedFrames(object):

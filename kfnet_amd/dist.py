@@ -216,6 +216,90 @@ def make_link(dist, rank, world, device_index, prefer='auto'):
     return TorchLink(dist)
 
 
+# ---- block-cyclic sharding (round 5) -----------------------------------------------------------------------------------------
+# Contiguous chunks put the whole serial part at the END of the job: every rank finishes its heavy phase at the same time and
+# then the `world` scans run one after another (each waits for its predecessor's state).  With blocks of `block` frames dealt
+# round-robin (block j -> rank j % world) the state hops once per block and a rank scans block j while the others are still
+# in the heavy phase of theirs: what is left exposed is the start-up skew, (world - 1) x (one block's scan + one hop), instead
+# of (world - 1) x (one chunk's scan + one hop).  Same arithmetic, same pairing rule -- evaluated per block -- so the records
+# are bit-identical to a single pass and to the contiguous sharding.
+def cyclic_blocks(total_frames, block, rank, world):
+    """[(j, lo, hi)] of the blocks rank `rank` owns, ascending."""
+    if block <= 0:
+        raise ValueError('block must be positive')
+    nblocks = -(-total_frames // block)
+    return [(j, j * block, min(total_frames, (j + 1) * block)) for j in range(rank, nblocks, world)]
+
+
+def cyclic_handoff_plan(lo, hi, total_frames, rank, world, reset_period):
+    """(rank to receive the state from | None, rank to send it to | None) for the block [lo, hi): the same predicate on the
+    same frame index on both sides of every boundary, as handoff_plan."""
+    recv = world > 1 and needs_state(lo, reset_period)
+    send = world > 1 and hi < total_frames and needs_state(hi, reset_period)
+    return ((rank - 1) % world if recv else None), ((rank + 1) % world if send else None)
+
+
+def iter_cyclic(eng, frames_of, total_frames, block, rank, world, link=None, stamp=None):
+    """Generator form of run_cyclic: yields (lo, records VIEW [n,h,w,4]) after each of this rank's blocks (the view is valid
+    until the generator is advanced).  In-process tests drive the generators of N "ranks" in global block order."""
+    if link is not None and hasattr(link, 'get_backend'):
+        link = TorchLink(link)
+    if block > eng.max_chunk:
+        raise ValueError('block %d exceeds the engine\'s max_chunk %d' % (block, eng.max_chunk))
+    w = world if link is not None else 1
+    for j, lo, hi in cyclic_blocks(total_frames, block, rank, w):
+        n = hi - lo
+        need = needs_state(lo, eng.reset_period)
+        frames = frames_of(lo - 1 if need else lo, hi)
+        if need:
+            eng.prime(frames[0])           # flow features of frame lo-1, recomputed locally (5.6 GFLOP instead of a 614 KB message)
+            frames = frames[1:]
+        eng.heavy(frames, n)
+        if stamp is not None:
+            stamp('heavy_end', j)
+        src, dst = cyclic_handoff_plan(lo, hi, total_frames, rank, w, eng.reset_period)
+        if src is not None:
+            link.recv(eng.get_state(), src, eng)
+        if stamp is not None:
+            stamp('scan_start', j)
+        eng.scan(n, lo)
+        if stamp is not None:
+            stamp('scan_end', j)
+        if dst is not None:
+            link.send(eng.get_state(), dst, eng)
+        yield lo, eng.records(n)
+
+
+def run_cyclic(eng, frames_of, total_frames, block, rank, world, link=None, on_block=None, stamp=None):
+    """Process this rank's blocks of a `total_frames`-frame sequence dealt round-robin in blocks of `block` frames.
+    `frames_of(lo, hi)` returns the device uint8 frames [lo, hi) (a rank only ever asks for its own blocks and the frame in
+    front of each).  Per block: heavy phase (state-independent) -> receive the Kalman state from rank-1 unless the block
+    starts on a reset frame -> scan -> send the state to rank+1 unless the next block starts on a reset frame.
+    Returns [(lo, records tensor [n,h,w,4])] (copies: the engine's record buffer is reused by the next block);
+    `on_block(lo, records_view)` instead consumes each block's records in place.  `stamp(name, j)`: phase hook of bench.py."""
+    out = []
+    for lo, rec in iter_cyclic(eng, frames_of, total_frames, block, rank, world, link, stamp):
+        if on_block is not None:
+            on_block(lo, rec)
+        else:
+            out.append((lo, rec.clone()))
+    return out
+
+
+def scan_cyclic_host(chunk_scan_fn, rank, world, dist, state_buf, total_frames, block, reset_period):
+    """Backend-agnostic skeleton of run_cyclic's hand-off for the gloo CPU tests: `chunk_scan_fn(state_buf, lo, hi)` advances
+    the state over frames [lo, hi) in place and returns that block's outputs.  Returns [(lo, outputs)]."""
+    out = []
+    for j, lo, hi in cyclic_blocks(total_frames, block, rank, world):
+        src, dst = cyclic_handoff_plan(lo, hi, total_frames, rank, world, reset_period)
+        if src is not None:
+            dist.recv(state_buf, src=src)
+        out.append((lo, chunk_scan_fn(state_buf, lo, hi)))
+        if dst is not None:
+            dist.send(state_buf, dst=dst)
+    return out
+
+
 class ChunkTimer(object):
     """HIP-event stamps of one `run_chunk` pass on the engine's stream, for the serial chain of the sharded
     configuration: heavy phase | recv (waits for the predecessor's scan) | scan | send.  `origin()` is called right

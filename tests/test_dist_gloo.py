@@ -180,3 +180,68 @@ def test_make_link_bad_device_index_fails_collectively(tmp_path, prefer):
     mp.spawn(_link_worker, args=(2, _free_port(), 1, prefer, str(tmp_path), True), nprocs=2, join=True)
     names = [open(tmp_path / ('link_%d.txt' % r)).read() for r in range(2)]
     assert names == (['TorchLink'] * 2 if prefer == 'auto' else ['raised'] * 2), names
+
+
+# ---- block-cyclic sharding (kfnet_amd/dist.py: cyclic_blocks / cyclic_handoff_plan / scan_cyclic_host) ---------------------------
+def _cyclic_worker(rank, world, port, T, H, W, reset_period, block, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from kfnet_amd.dist import scan_cyclic_host
+    flow, sig, meas = _inputs(T, H, W)
+    state = torch.zeros(H, W, 4)
+
+    def block_fn(buf, lo, hi):
+        r, s = _scan(flow[lo:hi], sig[lo:hi], meas[lo:hi], buf.numpy().copy(), lo, reset_period)
+        buf.copy_(torch.from_numpy(s))
+        return r
+
+    for lo, r in scan_cyclic_host(block_fn, rank, world, dist, state, T, block, reset_period):
+        np.save(os.path.join(out_dir, 'blk_%06d.npy' % lo), r)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('T,reset_period,world,block', [(23, 500, 2, 4), (24, 6, 2, 3), (24, 6, 4, 6), (5, 500, 4, 2), (7, 3, 3, 1),
+                                                        (2048, 500, 8, 64)])
+def test_cyclic_sharded_scan_equals_serial(tmp_path, T, reset_period, world, block):
+    """Blocks of `block` frames dealt round-robin over `world` gloo ranks, the state hopping rank -> rank+1 (wrapping from the
+    last rank to rank 0) once per block: bit-identical to the serial scan.  (24, 6, 4, 6): every block starts on a reset -> no
+    message at all; (24, 6, 2, 3): every second one; (5, 500, 4, 2): fewer blocks than ranks; (2048, 500, 8, 64) = BASELINE
+    config 4's sequence in 32 blocks, four revolutions of the ring, resets inside blocks 7, 15, 23 and 31."""
+    H, W = 6, 9
+    mp.spawn(_cyclic_worker, args=(world, _free_port(), T, H, W, reset_period, block, str(tmp_path)), nprocs=world, join=True)
+    flow, sig, meas = _inputs(T, H, W)
+    ref, _ = _scan(flow, sig, meas, np.zeros((H, W, 4), np.float32), 0, reset_period)
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith('blk_'))
+    assert len(files) == -(-T // block)
+    got = np.concatenate([np.load(tmp_path / f) for f in files])
+    assert np.array_equal(got, ref)
+
+
+def test_cyclic_plan_pairs_every_send_with_one_recv():
+    from kfnet_amd.dist import cyclic_blocks, cyclic_handoff_plan
+    for total, world, block, period in [(2048, 8, 32, 500), (2048, 8, 64, 500), (100, 3, 7, 10), (9, 4, 2, 0), (50, 2, 25, 25), (5, 8, 1, 500)]:
+        owned = {}
+        for r in range(world):
+            for j, lo, hi in cyclic_blocks(total, block, r, world):
+                assert j % world == r and j not in owned
+                owned[j] = (r, lo, hi)
+        assert sorted(owned) == list(range(-(-total // block)))
+        assert [owned[j][1] for j in sorted(owned)] == [j * block for j in sorted(owned)] and owned[max(owned)][2] == total
+        for j in sorted(owned):
+            r, lo, hi = owned[j]
+            src, dst = cyclic_handoff_plan(lo, hi, total, r, world, period)
+            if j == 0:
+                assert src is None
+            if dst is not None:                      # the next block exists, is owned by dst, and expects the state from r
+                r2, lo2, hi2 = owned[j + 1]
+                assert r2 == dst and lo2 == hi and cyclic_handoff_plan(lo2, hi2, total, r2, world, period)[0] == r
+            elif j + 1 in owned:                     # no send: the next block must not wait for one
+                r2, lo2, hi2 = owned[j + 1]
+                assert cyclic_handoff_plan(lo2, hi2, total, r2, world, period)[0] is None
+            if world == 1:
+                assert src is None and dst is None
+    # 50 frames, 2 ranks, blocks of 25, resets every 25: both blocks start on a reset -> nothing travels
+    assert cyclic_handoff_plan(0, 25, 50, 0, 2, 25) == (None, None) and cyclic_handoff_plan(25, 50, 50, 1, 2, 25) == (None, None)

@@ -116,3 +116,73 @@ def test_sharded_edge_cases_in_process(T, world, period):
     one = eng.process(dev).cpu().numpy().copy()
     got = _run_sharded_in_process(W, dev, world, None, 3, (64, 96), reset_period=period)
     assert np.array_equal(got, one)
+
+
+# ---- block-cyclic sharding (kfnet_amd.dist.run_cyclic / iter_cyclic; round 5) -----------------------------------------------------
+@pytest.mark.parametrize('T,world,block,period', [(300, 8, 16, 100), (70, 3, 8, 24), (50, 4, 7, 500), (9, 8, 2, 4)])
+def test_cyclic_sharding_in_process_equals_single_pass(T, world, block, period):
+    """N "ranks" = N engines in this process, their block generators advanced in GLOBAL block order (what the real transports
+    do in time), the state travelling through a LoopbackLink mailbox (rank -> rank+1, wrapping from the last rank to 0): the
+    records equal a single pass bit for bit.  (300, 8, 16, 100): 19 blocks over 8 ranks, resets inside blocks and -- at 96 =
+    6 x 16 -- none on a block boundary; (70, 3, 8, 24): resets at 24 / 48 ON block boundaries (no message there), ragged last
+    block; (9, 8, 2, 4): fewer blocks than ranks."""
+    from kfnet_amd.dist import LoopbackLink, cyclic_blocks, iter_cyclic
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(5)
+    T4 = np.linalg.inv(synthetic_transform())
+    imgs = synthetic_sequence(T, 64, 96, seed=4)
+    one_eng = KFNetEngine(W, image_size=(64, 96), batch=3, transform=T4, reset_period=period, max_chunk=T)
+    dev = one_eng.upload_frames(imgs)
+    one = one_eng.process(dev).cpu().numpy().copy()
+    mailbox = {}
+    gens, asked = [], [[] for _ in range(world)]
+    for r in range(world):
+        eng = KFNetEngine(W, image_size=(64, 96), batch=3, transform=T4, reset_period=period, max_chunk=block)
+
+        def frames_of(lo, hi, r=r):
+            asked[r].append((lo, hi))
+            return dev[lo:hi]
+        gens.append(iter_cyclic(eng, frames_of, T, block, r, world, LoopbackLink(mailbox, r)))
+    got = np.zeros_like(one)
+    nblocks = -(-T // block)
+    for j in range(nblocks):
+        lo, rec = next(gens[j % world])
+        assert lo == j * block
+        got[lo:lo + rec.shape[0]] = rec.cpu().numpy()
+    for g in gens:
+        with pytest.raises(StopIteration):
+            next(g)
+    assert not mailbox, 'unconsumed state messages: %s' % list(mailbox)
+    assert np.array_equal(got, one)
+    # a rank touches only its own blocks and the frame in front of each
+    for r in range(world):
+        own = [(lo, hi) for _, lo, hi in cyclic_blocks(T, block, r, world)]
+        assert [(hi) for _, hi in asked[r]] == [hi for _, hi in own]
+        assert all(a_lo in (lo, lo - 1) for (a_lo, _), (lo, _) in zip(asked[r], own))
+
+
+def test_cyclic_eval_cli_four_gloo_ranks_bit_identical_to_single_pass(tmp_path):
+    """python -m torch.distributed.run ... -m kfnet_amd.KFNet.eval --sharding cyclic --block 16: four processes sharing this
+    GPU over gloo, 13 blocks (three revolutions of the ring + one), every rank writes the coord_<i>.npy of its own blocks."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
+    from kfnet_amd.weights import synthetic_weights
+    T, world, block = 200, 4, 16
+    out = tmp_path / 'cyclic'
+    out.mkdir()
+    env = dict(os.environ, KFN_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), '-m', 'kfnet_amd.KFNet.eval',
+           '--scene', 'heads', '--synthetic', str(T), '--random_weights', '--batch', '8', '--sharding', 'cyclic', '--block', str(block),
+           '--height', '64', '--width', '96', '--output_folder', str(out)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'rank 0/4: 4 blocks of 16 frames done (block-cyclic)' in r.stdout and 'rank 3/4: 3 blocks' in r.stdout
+    imgs = synthetic_sequence(T, 64, 96)
+    T4 = np.linalg.inv(synthetic_transform())
+    eng = KFNetEngine(synthetic_weights(1234), image_size=(64, 96), batch=8, transform=T4, reset_period=500, max_chunk=T)
+    one = eng.process(eng.upload_frames(imgs)).cpu().numpy()
+    got = np.stack([np.load(out / ('coord_%d.npy' % i)) for i in range(T)])
+    assert np.array_equal(got, one)

@@ -168,7 +168,7 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'KFN_DIST_BACKEND')}
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2']
+           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2', '--block', '2']
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -182,6 +182,12 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     assert len(h['scan_ms_per_rank']) == 2 and h['scan_chain_ms'] >= max(h['scan_ms_per_rank'])
     assert h['handoff_us'][0]['send_us'] is not None and h['handoff_us'][1]['recv_wait_us'] is not None
     assert h['handoff_us'][0]['recv_wait_us'] is None and h['handoff_us'][1]['send_us'] is None
+    # ... and the block-cyclic sharding of the same 12-frame job measured beside it (Next #9): --block 2 -> six
+    # blocks over two ranks, the state hopping five times
+    assert out['sharding'] == 'contiguous' and h['sharding'] == 'contiguous' and h['tail_ms'] > 0
+    cy = out['sharding_cyclic']
+    assert cy['sharding'] == 'block-cyclic' and cy['block'] == 2 and cy['blocks_total'] == 6 and cy['value'] > 0
+    assert len(cy['recv_wait_ms_per_rank']) == 2 and cy['tail_ms'] is not None
     if torch.cuda.device_count() >= 2:
         assert out['dist_backend'] == 'nccl' and out['rank_devices'] == [0, 1]
         assert out['rccl_ranks'] == [[0, 2], [1, 2]], out['rccl_ranks']   # kfn_comm_rank on every rank
