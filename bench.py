@@ -91,7 +91,7 @@ def parse():
                     help='c3 on one GPU: skip the config5_960x540 / config2_single_frame blocks')
     ap.add_argument('--no-eval-png', action='store_true', help='skip the PNG -> coord_<i>.npy end-to-end block')
     ap.add_argument('--block', type=int, default=32, help='multi-rank runs: frames per block of the block-cyclic sharding measured beside the contiguous one')
-    ap.add_argument('--eval-chunk', type=int, default=128, help='frames per host chunk of the PNG end-to-end block')
+    ap.add_argument('--eval-chunk', type=int, default=32, help='frames per host chunk of the PNG end-to-end block')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
@@ -305,7 +305,7 @@ def host_streamed(eng, host_frames, dev_frames, chunk=None):
                     '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
 
 
-def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=128, repeat=4):
+def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4):
     """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
     (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
     package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the

@@ -181,7 +181,8 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
 // not depend on the state, so the ring rolls straight across the frame barrier).  D = PPT is the full rolling prefetch (a
 // whole frame of inputs in flight per thread); the single-buffer forms of the larger grids, which also hold PPT new states
 // in registers across their mid-frame barrier, take a short ring.  NT: non-temporal input loads / record stores.
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG>
+// ILP: pixels of a thread the scheduler may interleave (1 = strictly one after the other).
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, int ILP = 1>
 __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   static_assert(D >= 1 && D <= PPT && PPT % D == 0, "ring slots are compile-time constants");
   extern __shared__ __attribute__((aligned(16))) float smem_k[];
@@ -208,10 +209,19 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   // poison 0x08000000 elements beyond num_records for all three element sizes.)
   const size_t seq_px = (size_t)s * T * HW;
   const unsigned aux = NT ? 2u : 0u;          // the non-temporal bit: streamed once, not re-read by this launch
-  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x2*>(a.flow + seq_px), 0, T * HW * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sigma_t + seq_px), 0, T * HW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.meas + seq_px), 0, T * HW * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rec + seq_px, 0, T * HW * 16, 0x00020000);
+  // (readfirstlane on the descriptor words: the compiler must KNOW they are wave-uniform, or it keeps them in vector
+  //  registers and wraps every buffer instruction in a waterfall loop -- four v_readfirstlane + two compares + a branch per
+  //  load: the first build of this addressing was 4.5 % slower than the pointer form for exactly that reason)
+  auto uni = [](const void* q) __attribute__((always_inline)) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  };
+  const int n_el = __builtin_amdgcn_readfirstlane(T * HW);
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(uni(a.flow + seq_px), 0, n_el * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(uni(a.sigma_t + seq_px), 0, n_el * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(uni(a.meas + seq_px), 0, n_el * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(uni(a.rec + seq_px), 0, n_el * 16, 0x00020000);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned POISON = 0x08000000u;    // element index: x 4 / 8 / 16 >= num_records of the three element sizes
   PixIn ring[D];
@@ -257,9 +267,9 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
       // this slot's inputs are consumed: fetch the pixel that uses the slot next
       if (k + D < PPT) load_pixel(tv, t, k + D, ring[k % D]);
       else load_pixel(tv, t + 1, k + D - PPT, ring[k % D]);
-      // keep the unrolled pixels sequential: interleaving them only multiplies live
-      // temporaries (the 128-VGPR budget of a 1024-thread workgroup is tight)
-      __builtin_amdgcn_sched_barrier(0);
+      // keep the unrolled pixels (groups of ILP) sequential: interleaving all of them only multiplies live temporaries
+      // (the 128-VGPR budget of a 1024-thread workgroup)
+      if ((k + 1) % ILP == 0) __builtin_amdgcn_sched_barrier(0);
     }
     if (!DBL) {
       __syncthreads();  // every gather of frame t done
@@ -401,10 +411,10 @@ __global__ __launch_bounds__(256) void kalman_fuse2_kernel(const f32x4* __restri
 #define KFN_FUSE_NT 1
 #endif
 
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG>
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, int ILP = 1>
 int launch_scan_dbg(const KalmanArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
-  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG>;
+  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG, ILP>;
   static std::atomic<uint64_t> attr_done{0};   // per instantiation: bit per device
   {
     int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done);

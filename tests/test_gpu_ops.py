@@ -1443,7 +1443,7 @@ def test_winograd_f43_splitk_rejects_bad_splits():
     assert lib.kfn_conv2d_winograd_f43_splitk(C.byref(d4), buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), buf.data_ptr(), 2, None) != 0
 
 
-@pytest.mark.parametrize('case,k_split', [((1, 120, 160, 512, 1024), 4), ((2, 14, 18, 32, 160), 2), ((1, 64, 96, 64, 128), 3),
+@pytest.mark.parametrize('case,k_split', [((1, 120, 160, 512, 1024), 4), ((2, 14, 18, 32, 160), 2), ((1, 64, 96, 64, 128), 2),
                                           ((1, 30, 34, 48, 36), 3), ((2, 60, 80, 256, 256), 1)])
 def test_winograd_s2_splitk_vs_oracle(case, k_split):
     """kfn_conv2d_winograd_s2_splitk (eight-wave polyphase kernel, input channels cut into k_split runs, planes reduced in a
@@ -1495,6 +1495,9 @@ def test_winograd_s2_splitk_vs_oracle(case, k_split):
         n_super = ci // 16
         assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), ws.data_ptr(),
                                                  n_super + 1, stream()) != 0
+        if n_super == 4:      # runs of 2 super-steps: a third run would be empty
+            assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), ws.data_ptr(),
+                                                     3, stream()) != 0 and b'empty split' in lib.kfn_last_error()
         assert lib.kfn_conv2d_winograd_s2_splitk(C.byref(d), dx.data_ptr(), du.data_ptr(), None, y1.data_ptr(), None, k_split, stream()) != 0
         d16 = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3, stride=2,
                             operand_dtype=1)

@@ -155,6 +155,9 @@ int main(int argc, char** argv) {
     vs.push_back({"768x7  D=7 plain", launch_scan_dbg<768, 7, true, 7, false, false>});
     vs.push_back({"1024x5 D=5 nt (default)", launch_scan_dbg<1024, 5, true, 5, true, false>});
     vs.push_back({"1024x5 D=5 plain", launch_scan_dbg<1024, 5, true, 5, false, false>});
+    vs.push_back({"1024x5 D=5 nt, pixels interleaved in pairs", launch_scan_dbg<1024, 5, true, 5, true, false, 2>});
+    vs.push_back({"1024x5 D=5 nt, all five pixels interleaved", launch_scan_dbg<1024, 5, true, 5, true, false, 5>});
+    vs.push_back({"768x7  D=7 nt, pixels interleaved in pairs", launch_scan_dbg<768, 7, true, 7, true, false, 2>});
     vs.push_back({"1024x5 D=1 nt", launch_scan_dbg<1024, 5, true, 1, true, false>});
     vs.push_back({"512x10 D=10 nt", launch_scan_dbg<512, 10, true, 10, true, false>});
     vs.push_back({"512x10 D=5 nt", launch_scan_dbg<512, 10, true, 5, true, false>});

@@ -36,15 +36,17 @@ python tools/pmc_traffic.py "$(finddb $OUT/k256FETCH_SIZE)" "$(finddb $OUT/k256W
     --only kalman_scan_kernel --suffix '@S=256,T=256' --into $OUT/${TAG}_pmc_traffic.json > /dev/null
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # the bench line below quotes these numbers (newest rNN file)
 i=0
-for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+# (fourth group, round 5: the texture-addresser side -- TA_BUSY_avr = % of the kernel's time the address units are busy,
+#  vector-memory instructions issued, TA cycles stalled by the cache -- for the F(4x4,3x3) kernel's issue-rate analysis)
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "TA_BUSY_avr SQ_INSTS_VMEM_RD TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
   i=$((i+1))
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/sq$i -- python $R/bench.py $SHORT > /dev/null 2> $OUT/sq$i.err )
 done
-python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)"
+python tools/pmc_sq.py $OUT/${TAG}_pmc_sq_counters.json "$(finddb $OUT/sq1)" "$(finddb $OUT/sq2)" "$(finddb $OUT/sq3)" "$(finddb $OUT/sq4)"
 # the un-profiled bench lines (they quote the fresh PMC traffic copied to profiles/ above): the 256-frame default and,
 # after the config-5 passes below, the driver's own command
 python bench.py --no-extra-configs > $OUT/${TAG}_bench_final.json 2> $OUT/bench.err
-rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/k256FETCH_SIZE $OUT/k256WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3
+rm -rf $OUT/kt $OUT/kt1 $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/kFETCH_SIZE $OUT/kWRITE_SIZE $OUT/k256FETCH_SIZE $OUT/k256WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/sq4
 # ---- BASELINE config 5 (960x540, fp16 convs + fp16 activations, fp32 Kalman): kernel trace + the same PMC passes ----
 C5="--config c5 --no-cpu-baseline --min-seconds 0"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/c5kt -- python $R/bench.py $C5 > $OUT/${TAG}_c5_bench_under_rocprof.json 2> $OUT/c5kt.err )
