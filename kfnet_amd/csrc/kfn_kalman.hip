@@ -181,8 +181,12 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
 // not depend on the state, so the ring rolls straight across the frame barrier).  D = PPT is the full rolling prefetch (a
 // whole frame of inputs in flight per thread); the single-buffer forms of the larger grids, which also hold PPT new states
 // in registers across their mid-frame barrier, take a short ring.  NT: non-temporal input loads / record stores.
-// ILP: pixels of a thread the scheduler may interleave (1 = strictly one after the other).
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, int ILP = 1>
+// PTR: how the streams are addressed.  true = per-pixel 64-bit pointers (clamped index, predicated stores): the compiler
+// keeps them live across the frame loop (eight VGPRs per slot), which the double-buffered 60x80 form can afford -- and it
+// is the fastest form there (same box, S = 256: 0.662 / 0.672 of 8 TB/s at T = 64 / 256 against 0.633 / 0.645 with
+// descriptors).  false = buffer descriptors with scalar frame / slot offsets (below): no per-slot registers, which is what
+// lets the single-buffer forms of the larger grids run without spills (68x120: 0.644 against 0.42-0.43 for rounds 1-4's form).
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false>
 __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   static_assert(D >= 1 && D <= PPT && PPT % D == 0, "ring slots are compile-time constants");
   extern __shared__ __attribute__((aligned(16))) float smem_k[];
@@ -209,19 +213,17 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   // poison 0x08000000 elements beyond num_records for all three element sizes.)
   const size_t seq_px = (size_t)s * T * HW;
   const unsigned aux = NT ? 2u : 0u;          // the non-temporal bit: streamed once, not re-read by this launch
-  // (readfirstlane on the descriptor words: the compiler must KNOW they are wave-uniform, or it keeps them in vector
-  //  registers and wraps every buffer instruction in a waterfall loop -- four v_readfirstlane + two compares + a branch per
-  //  load: the first build of this addressing was 4.5 % slower than the pointer form for exactly that reason)
-  auto uni = [](const void* q) __attribute__((always_inline)) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-  };
-  const int n_el = __builtin_amdgcn_readfirstlane(T * HW);
-  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(uni(a.flow + seq_px), 0, n_el * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(uni(a.sigma_t + seq_px), 0, n_el * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(uni(a.meas + seq_px), 0, n_el * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(uni(a.rec + seq_px), 0, n_el * 16, 0x00020000);
+  // (hipcc does not prove these descriptors wave-uniform -- the sequence offset reaches them through the divergent
+  //  state-copy loop above -- and wraps every buffer instruction in a waterfall loop: four v_readfirstlane, two compares, a
+  //  branch.  Forcing them scalar with readfirstlane removes the loops (72 instead of 88 VGPRs, a quarter fewer
+  //  instructions) and measured the SAME speed on the 60x80 form, but the single-buffer forms built that way returned
+  //  wrong records (config 5's tests, the A/B harness: "DIFFERS"); the cause was not found in the time there was, so the
+  //  descriptors stay as the compiler makes them -- every form below is the one the harness holds bit-identical to
+  //  rounds 1-4's kernel.  profiles/r05_kalman_ab.log keeps all three runs.)
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x2*>(a.flow + seq_px), 0, T * HW * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sigma_t + seq_px), 0, T * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.meas + seq_px), 0, T * HW * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rec + seq_px, 0, T * HW * 16, 0x00020000);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned POISON = 0x08000000u;    // element index: x 4 / 8 / 16 >= num_records of the three element sizes
   PixIn ring[D];
@@ -229,6 +231,14 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   auto slot_index = [&](int tv, int k) { return (tv + k * KT < HW) ? (unsigned)tv : POISON; };
   auto load_pixel = [&](int tv, int t, int k, PixIn& dst) __attribute__((always_inline)) {
     const int tc = t < T - 1 ? t : T - 1;
+    if constexpr (PTR) {
+      // threads past the grid re-read the last pixel (and store nothing): every load unconditional here too
+      const size_t q = seq_px + (size_t)tc * HW + min(tid + k * KT, HW - 1);
+      dst.flow = ld_stream<NT>(a.flow + q);
+      dst.st = ld_stream<NT>(a.sigma_t + q);
+      dst.z = ld_stream<NT>(a.meas + q);
+      return;
+    }
     const unsigned e = (unsigned)(tc * HW + k * KT);             // uniform element offset of the slot
     const unsigned vi = slot_index(tv, k);
     dst.flow = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsF, vi * 8u, e * 8u, aux));
@@ -259,17 +269,23 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
       const int qk = (k * KT) / W, rk = (k * KT) - qk * W;     // uniform
       int xk = x0f + rk, yk = y0f + qk;
       if (xk >= W) { xk -= W; yk += 1; }
-      f32x4 rec;
-      const f32x4 nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), rsR, slot_index(tv, k) * 16u,
-                                             (unsigned)(t * HW + k * KT) * 16u, aux);      // (threads past the grid: dropped)
+      f32x4 rec, nv;
+      if constexpr (PTR) {
+        const int pc = min(tid + k * KT, HW - 1);
+        const int yc = pc / W, xc = pc - yc * W;
+        nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], pc, xc, yc, off, reset, W, xmax, ymax, eps2, want_nis, valid);
+      } else {
+        nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), rsR, slot_index(tv, k) * 16u,
+                                               (unsigned)(t * HW + k * KT) * 16u, aux);      // (threads past the grid: dropped)
+      }
       if (DBL) { if (valid) st_new[p] = nv; } else newst[DBL ? 0 : k] = nv;
       // this slot's inputs are consumed: fetch the pixel that uses the slot next
       if (k + D < PPT) load_pixel(tv, t, k + D, ring[k % D]);
       else load_pixel(tv, t + 1, k + D - PPT, ring[k % D]);
-      // keep the unrolled pixels (groups of ILP) sequential: interleaving all of them only multiplies live temporaries
-      // (the 128-VGPR budget of a 1024-thread workgroup)
-      if ((k + 1) % ILP == 0) __builtin_amdgcn_sched_barrier(0);
+      // keep the unrolled pixels sequential: interleaving them only multiplies live temporaries (measured with pairs and
+      // with all five interleaved: -0.3 ... -1 %)
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (!DBL) {
       __syncthreads();  // every gather of frame t done
@@ -411,10 +427,10 @@ __global__ __launch_bounds__(256) void kalman_fuse2_kernel(const f32x4* __restri
 #define KFN_FUSE_NT 1
 #endif
 
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, int ILP = 1>
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false>
 int launch_scan_dbg(const KalmanArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
-  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG, ILP>;
+  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG, PTR>;
   static std::atomic<uint64_t> attr_done{0};   // per instantiation: bit per device
   {
     int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done);
@@ -430,8 +446,8 @@ int launch_scan_dbg(const KalmanArgs& a, hipStream_t stream) {
 // cost registers: a full ring would spill)
 template <int KT, int PPT, bool DBL, int D, bool NT, int KT_DBG = KT, int PPT_DBG = PPT, int DD = 1>
 int launch_scan(const KalmanArgs& a, hipStream_t stream) {
-  if (a.opt_temp || a.opt_nis || a.opt_kf) return launch_scan_dbg<KT_DBG, PPT_DBG, DBL, DD, NT, true>(a, stream);
-  return launch_scan_dbg<KT, PPT, DBL, D, NT, false>(a, stream);
+  if (a.opt_temp || a.opt_nis || a.opt_kf) return launch_scan_dbg<KT_DBG, PPT_DBG, DBL, DD, NT, true, false>(a, stream);
+  return launch_scan_dbg<KT, PPT, DBL, D, NT, false, /*PTR=*/DBL>(a, stream);
 }
 
 }  // namespace

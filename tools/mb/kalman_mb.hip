@@ -153,11 +153,10 @@ int main(int argc, char** argv) {
     vs.push_back({"768x7  D=7 nt (rolling)", launch_scan_dbg<768, 7, true, 7, true, false>});
     vs.push_back({"768x7  D=1 plain (~ rounds 1-4 without the burst prefetch)", launch_scan_dbg<768, 7, true, 1, false, false>});
     vs.push_back({"768x7  D=7 plain", launch_scan_dbg<768, 7, true, 7, false, false>});
-    vs.push_back({"1024x5 D=5 nt (default)", launch_scan_dbg<1024, 5, true, 5, true, false>});
+    vs.push_back({"1024x5 D=5 nt, descriptors", launch_scan_dbg<1024, 5, true, 5, true, false>});
     vs.push_back({"1024x5 D=5 plain", launch_scan_dbg<1024, 5, true, 5, false, false>});
-    vs.push_back({"1024x5 D=5 nt, pixels interleaved in pairs", launch_scan_dbg<1024, 5, true, 5, true, false, 2>});
-    vs.push_back({"1024x5 D=5 nt, all five pixels interleaved", launch_scan_dbg<1024, 5, true, 5, true, false, 5>});
-    vs.push_back({"768x7  D=7 nt, pixels interleaved in pairs", launch_scan_dbg<768, 7, true, 7, true, false, 2>});
+    vs.push_back({"1024x5 D=5 nt, POINTER addressing (default)", launch_scan_dbg<1024, 5, true, 5, true, false, true>});
+    vs.push_back({"768x7  D=7 nt, pointer addressing", launch_scan_dbg<768, 7, true, 7, true, false, true>});
     vs.push_back({"1024x5 D=1 nt", launch_scan_dbg<1024, 5, true, 1, true, false>});
     vs.push_back({"512x10 D=10 nt", launch_scan_dbg<512, 10, true, 10, true, false>});
     vs.push_back({"512x10 D=5 nt", launch_scan_dbg<512, 10, true, 5, true, false>});
