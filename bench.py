@@ -91,6 +91,7 @@ def parse():
                     help='c3 on one GPU: skip the config5_960x540 / config2_single_frame blocks')
     ap.add_argument('--no-eval-png', action='store_true', help='skip the PNG -> coord_<i>.npy end-to-end block')
     ap.add_argument('--block', type=int, default=32, help='multi-rank runs: frames per block of the block-cyclic sharding measured beside the contiguous one')
+    ap.add_argument('--decode-workers', type=int, default=0, help='PNG decode threads of the end-to-end block (0 = min(32, cores / 2))')
     ap.add_argument('--eval-chunk', type=int, default=32, help='frames per host chunk of the PNG end-to-end block')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
@@ -283,7 +284,7 @@ def host_streamed(eng, host_frames, dev_frames, chunk=None):
     from kfnet_amd.pipeline import ChunkLoader, StreamedSequence
     K = int(host_frames.shape[0])
     chunk = int(chunk) if chunk else max(eng.B, min(4 * eng.B, eng.max_chunk))
-    runner = StreamedSequence(eng, chunk)
+    runner = StreamedSequence(eng, chunk, depth=2)      # (frames already pinned: nothing on the host can stall the queue)
     pinned = torch.from_numpy(np.ascontiguousarray(host_frames)).pin_memory()
     chunks = [(lo, pinned[lo:lo + chunk]) for lo in range(0, K, chunk)]
     for _ in runner.run(chunks[:2]):       # warm the copy streams
@@ -305,7 +306,7 @@ def host_streamed(eng, host_frames, dev_frames, chunk=None):
                     '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
 
 
-def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4):
+def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4, workers=0):
     """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
     (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
     package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the
@@ -321,7 +322,7 @@ def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_record
     from kfnet_amd.tools.io import read_lines
     T = int(host_frames.shape[0])
     cores = os.cpu_count() or 8
-    workers = max(4, min(32, cores // 2))
+    workers = int(workers) if workers else max(4, min(32, cores // 2))
     root = tempfile.mkdtemp(prefix='kfn_png_')
     try:
         inp, outd = os.path.join(root, 'in'), os.path.join(root, 'out')
@@ -593,7 +594,7 @@ def config3_literal(args, Wt, T4, transform_txt, device, dev_index, frames=256, 
         if not args.no_eval_png:
             resident = eng.process(dev, t0=0).cpu().numpy()
             extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index,
-                                                               chunk=args.eval_chunk)
+                                                               chunk=args.eval_chunk, workers=args.decode_workers)
             hs = extra['host_streamed']['value']
             extra['eval_png_end_to_end']['fraction_of_host_streamed'] = round(extra['eval_png_end_to_end']['value'] / hs, 4)
     del eng, dev

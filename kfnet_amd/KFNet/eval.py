@@ -180,8 +180,12 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
 
     # decode thread + pinned staging (the reference's queue runners, KFNet/train.py:195-239);
     # uploads / compute / downloads overlapped on three streams -- with or without labels
+    # chunks in flight on the GPU: 3 (a second chunk queued behind the running one); the metrics reduction double-buffers
+    # its results, so it keeps 2.  The loader rotates one host buffer more than that: a buffer is recycled only after the
+    # records of the chunk that was uploaded from it have been handed out, i.e. its upload is complete.
+    in_flight = 2 if want_metrics else 3
     loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
-                         workers=decode_workers, first_chunk=min(chunk, max(eng.B, 16)))
+                         workers=decode_workers, first_chunk=min(chunk, max(eng.B, 16)), depth=in_flight + 1)
     dm = M.DeviceMetrics(eng) if want_metrics else None
     plan = {}     # chunk index -> (first, n, global pairs)
 
@@ -201,7 +205,7 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
 
     k = 0
     try:
-        for lo, rec in StreamedSequence(eng, chunk).run(loader, after_process=after_process if want_metrics else None):
+        for lo, rec in StreamedSequence(eng, chunk, depth=in_flight).run(loader, after_process=after_process if want_metrics else None):
             emit(lo, rec.copy())
             if want_metrics:
                 first, n, pairs = plan.pop(k)

@@ -47,9 +47,11 @@ class ChunkLoader(object):
     sequence.  `source` is a list of image paths (decoded here) or a uint8 array
     [T,H,W,3] already in memory (copied through the same staging buffers so that both kinds
     of input take the same path).  `depth` staging buffers rotate: a chunk handed out stays
-    valid until `depth - 1` further chunks have been requested."""
+    valid until `depth - 1` further chunks have been requested (a StreamedSequence with N chunks in
+    flight needs depth >= N + 1: a buffer is then recycled only after the records of the chunk uploaded
+    from it have been handed out)."""
 
-    def __init__(self, source, image_size, chunk, workers=8, depth=3, pinned=True, decode=decode_image, first_chunk=None):
+    def __init__(self, source, image_size, chunk, workers=8, depth=4, pinned=True, decode=decode_image, first_chunk=None):
         """`first_chunk` (< chunk): length of the FIRST chunk only -- its decode is the one nothing overlaps, so a short
         one (a tower batch) gets the GPU going while the first full chunk is still decoding; every later chunk is `chunk`
         frames (deep launch queues: the consumer thread shares the interpreter with the decode and writer threads)."""
@@ -167,21 +169,27 @@ class StreamedSequence(object):
     [n,h,w,4]); a yielded array is a view of a rotating pinned buffer and is valid until the
     generator is advanced again."""
 
-    def __init__(self, eng, chunk=None):
+    def __init__(self, eng, chunk=None, depth=3):
+        """`depth` chunks may be in flight on the GPU (uploaded / computing / downloading) before the oldest one's records
+        are handed out: 2 = rounds 2-4 (the host fetches and enqueues chunk k+1 while chunk k computes); 3 keeps a second
+        chunk queued behind the running one, so a host stall of one chunk's compute time (the consumer thread shares the
+        interpreter with the decode and writer threads) no longer idles the GPU."""
         torch = eng.torch
         self.eng = eng
         self.chunk = int(chunk or eng.max_chunk)
         if self.chunk > eng.max_chunk:
             raise ValueError('chunk %d exceeds the engine\'s max_chunk %d' % (self.chunk, eng.max_chunk))
+        self.depth = max(2, int(depth))
         dev = eng.device
+        n = self.depth
         self.up = torch.cuda.Stream(device=dev)
         self.down = torch.cuda.Stream(device=dev)
-        self.dev_frames = [torch.empty((self.chunk, eng.H, eng.W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.dev_rec = [torch.empty((self.chunk, eng.h, eng.w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.host_rec = [_host_buffer((self.chunk, eng.h, eng.w, 4), torch.float32, True) for _ in range(2)]
-        self.ev_up = [torch.cuda.Event() for _ in range(2)]
-        self.ev_done = [None, None]
-        self.ev_down = [None, None]
+        self.dev_frames = [torch.empty((self.chunk, eng.H, eng.W, 3), dtype=torch.uint8, device=dev) for _ in range(n)]
+        self.dev_rec = [torch.empty((self.chunk, eng.h, eng.w, 4), dtype=torch.float32, device=dev) for _ in range(n)]
+        self.host_rec = [_host_buffer((self.chunk, eng.h, eng.w, 4), torch.float32, True) for _ in range(n)]
+        self.ev_up = [torch.cuda.Event() for _ in range(n)]
+        self.ev_done = [None] * n
+        self.ev_down = [None] * n
 
     def run(self, chunks, after_process=None):
         """`after_process(k, first_index, n)` (optional) is called right after chunk k's compute has been
@@ -189,20 +197,20 @@ class StreamedSequence(object):
         torch = self.eng.torch
         eng = self.eng
         main = torch.cuda.current_stream(eng.device)
-        pending = None   # (first_index, n, slot) whose download is in flight
+        pending = []     # [(first_index, n, slot)] whose downloads are in flight, oldest first
         for k, (lo, host) in enumerate(chunks):
             n = int(host.shape[0])
             if n > self.chunk:
                 raise ValueError('chunk of %d frames exceeds %d' % (n, self.chunk))
-            b = k & 1
+            b = k % self.depth
             with torch.cuda.stream(self.up):
                 if self.ev_done[b] is not None:
-                    self.up.wait_event(self.ev_done[b])      # compute of chunk k-2 has read dev_frames[b]
+                    self.up.wait_event(self.ev_done[b])      # compute of chunk k-depth has read dev_frames[b]
                 self.dev_frames[b][:n].copy_(host, non_blocking=True)
                 self.ev_up[b].record(self.up)
             main.wait_event(self.ev_up[b])
             if self.ev_down[b] is not None:
-                main.wait_event(self.ev_down[b])             # download of chunk k-2 has read dev_rec[b]
+                main.wait_event(self.ev_down[b])             # download of chunk k-depth has read dev_rec[b]
             rec = eng.process(self.dev_frames[b][:n], t0=lo)
             if after_process is not None:
                 after_process(k, lo, n)
@@ -214,12 +222,12 @@ class StreamedSequence(object):
                 self.host_rec[b][:n].copy_(self.dev_rec[b][:n], non_blocking=True)
                 self.ev_down[b] = torch.cuda.Event()
                 self.ev_down[b].record(self.down)
-            if pending is not None:
-                plo, pn, pb = pending
+            pending.append((lo, n, b))
+            if len(pending) >= self.depth:                   # the slot chunk k+1 will take must be handed out first
+                plo, pn, pb = pending.pop(0)
                 self.ev_down[pb].synchronize()
                 yield plo, self.host_rec[pb][:pn].numpy()
-            pending = (lo, n, b)
-        if pending is not None:
-            plo, pn, pb = pending
+        while pending:
+            plo, pn, pb = pending.pop(0)
             self.ev_down[pb].synchronize()
             yield plo, self.host_rec[pb][:pn].numpy()

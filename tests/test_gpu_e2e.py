@@ -533,11 +533,16 @@ def test_streamed_pipeline_is_bit_identical_to_resident(tmp_path):
         Image.fromarray(imgs[i]).save(paths[-1])
     eng = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=5, max_chunk=13)
     ref = eng.process(eng.upload_frames(imgs)).cpu().numpy().copy()
-    for source in (paths, imgs):
+    for source, depth in ((paths, 3), (imgs, 2), (imgs, 4)):      # chunks in flight on the GPU (round 5: 3 by default)
         eng2 = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=5, max_chunk=4)
-        got = [(lo, rec.copy()) for lo, rec in StreamedSequence(eng2, 4).run(ChunkLoader(source, (64, 96), 4, workers=3))]
+        got = [(lo, rec.copy()) for lo, rec in StreamedSequence(eng2, 4, depth=depth).run(
+            ChunkLoader(source, (64, 96), 4, workers=3, depth=depth + 1))]
         assert [lo for lo, _ in got] == [0, 4, 8, 12]
         assert np.array_equal(np.concatenate([r for _, r in got]), ref)
+    # a short first chunk (what eval() asks for) and a ragged tail
+    eng3 = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=5, max_chunk=4)
+    got = [(lo, rec.copy()) for lo, rec in StreamedSequence(eng3, 4).run(ChunkLoader(paths, (64, 96), 4, workers=2, first_chunk=2))]
+    assert [lo for lo, _ in got] == [0, 2, 6, 10] and np.array_equal(np.concatenate([r for _, r in got]), ref)
     out = tmp_path / 'out'
     out.mkdir()
     rec = kf_eval.eval(paths, None, W, str(out), image_size=(64, 96), batch=2, sequence_length=5, chunk=4,
