@@ -15,7 +15,38 @@
 #define KFN_NT_STORE_AUX 0
 #endif
 
+// Wait states behind a 16-byte buffer store whose data registers may be overwritten next (see buffer_store_b128): s_nop N
+// = N + 1 states.  (KFN_STORE_PAD=-1 builds the library WITHOUT the pad: the round-4 behaviour, for tools/debug_conv64.py.)
+#ifndef KFN_STORE_PAD
+#define KFN_STORE_PAD 7
+#endif
+
 namespace kfn {
+
+#if defined(__HIPCC__)
+// buffer_store_dwordx4 with an SGPR offset.  The store reads its four data VGPRs during the cycles AFTER it has issued.
+// hipcc's hazard table pads a following VALU write of those registers only for stores WITHOUT an SGPR offset (it takes
+// the SGPR operand to cost the missing cycle), and reuses the dead data registers at once -- e.g. as the next store's
+// per-lane offset.  Measured on gfx950 (round 5, conv64_rows_kernel, profiles/r05_conv64_store_hazard.log): with the
+// memory system loaded by another stream, about one launch in ten of 2x540x960 sent, for a few 4-lane groups of one wave,
+// the NEXT instruction's result (a byte offset) as the first dword of a 16-byte piece.  So every such store goes through
+// here: the data (and the per-lane offset) stay live up to an asm statement behind the store, and that statement spends the
+// wait states.
+template <int AUX, typename V>
+__device__ __forceinline__ void buffer_store_b128(V v, __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+  static_assert(sizeof(V) == 16, "buffer_store_b128 stores 16 bytes");
+  const u32x4_t d = __builtin_bit_cast(u32x4_t, v);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voffset, soffset, AUX);
+#if KFN_STORE_PAD >= 0
+#define KFN_STR2(x) #x
+#define KFN_STR(x) KFN_STR2(x)
+  asm volatile("s_nop " KFN_STR(KFN_STORE_PAD) : : "v"(d), "v"(voffset));
+#undef KFN_STR
+#undef KFN_STR2
+#endif
+}
+#endif
 
 // thread-local error text returned by kfn_last_error()
 char* err_buf();

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
         if constexpr (g == 1) {                     // the previous row's pieces leave (NO = 2 PXB <= 8 stores over 4 gaps)
 #pragma unroll
           for (int i = c; i < NO; i += 4)
-            __builtin_amdgcn_raw_buffer_store_b128(ov[i], rsY, prev_emit ? out_col[i] : OOB, prev_soff, KFN_NT_STORE_AUX);
+            kfn::buffer_store_b128<KFN_NT_STORE_AUX>(ov[i], rsY, prev_emit ? out_col[i] : OOB, prev_soff);
         }
         if constexpr (g >= 3 && (g - 3) % 3 < 2) {  // pixel block (g - 3) / 3 of the done row: pieces 2 * ((g - 3) % 3) + c / 2 ...
           constexpr int epb = (g - 3) / 3;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void conv64_rows_kernel(C64Args p) {
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(prev_tile + out_lds[i]);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (last - 1 >= r0) ? out_col[i] : OOB, soff, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, (last - 1 >= r0) ? out_col[i] : OOB, soff);
     }
   }
 }

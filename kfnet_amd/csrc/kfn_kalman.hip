@@ -276,8 +276,8 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
         nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], pc, xc, yc, off, reset, W, xmax, ymax, eps2, want_nis, valid);
       } else {
         nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), rsR, slot_index(tv, k) * 16u,
-                                               (unsigned)(t * HW + k * KT) * 16u, aux);      // (threads past the grid: dropped)
+        kfn::buffer_store_b128<NT ? 2 : 0>(rec, rsR, slot_index(tv, k) * 16u,
+                                           (unsigned)(t * HW + k * KT) * 16u);               // (threads past the grid: dropped)
       }
       if (DBL) { if (valid) st_new[p] = nv; } else newst[DBL ? 0 : k] = nv;
       // this slot's inputs are consumed: fetch the pixel that uses the slot next

@@ -436,8 +436,7 @@ __global__ __launch_bounds__(64, 1) void wino2_kernel(Wino2Args p) {
       const int oy = 2 * ty + a;
       const bool row_in = vr0 + trow < p.vrows && oy < p.H;        // uniform
       const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + ox0 + 8 * hx) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, row_in ? voff_h[hx] : OOBV, soff, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_in ? voff_h[hx] : OOBV, soff);
     }
     return;
   } else {

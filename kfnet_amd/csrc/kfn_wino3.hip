@@ -476,8 +476,7 @@ __device__ __forceinline__ void wino3_body(const Wino3Args& p) {
       const int oy = 2 * ty + a;
       const bool row_ok = vr0 + trow < p.vrows && oy < p.H;        // uniform
       const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + ox0 + 8 * hx) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, row_ok ? voff_h[hx] : OOBV, soff, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_h[hx] : OOBV, soff);
     }
   } else {
     // Cout or the row pitch not a multiple of 4 floats: one dword per store

@@ -671,8 +671,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(Wino4Args p) {
       const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
       const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
       const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);
     }
   }
   KFN_STAMP4(6);
@@ -1087,8 +1086,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
       const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
       const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
       const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);
     }
   }
 }

@@ -411,8 +411,7 @@ __global__ __launch_bounds__(64 * NWAVE, 1) void wino_s2_kernel(WinoS2Args p) {
       const int oy = 2 * ty + a;
       const bool row_ok = vr0 + trow < p.vrows && oy < p.Ho;        // uniform
       const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo + ox0 + 8 * hx) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, row_ok ? voff_h[hx] : OOBV, soff, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_h[hx] : OOBV, soff);
     }
   } else {
     // Cout or the row pitch not a multiple of 4 floats: one dword per store
@@ -678,8 +677,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
       const int oy = 2 * ty + a;
       const bool row_ok = vr0 + trow < p.vrows && oy < p.Ho;        // uniform
       const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo) * pix_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                             rsY, row_ok ? voff_q : OOBV, soff, KFN_NT_STORE_AUX);
+      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
     }
   } else {
     const int pix_bytes = p.ldy * 4;

@@ -431,7 +431,8 @@ class ConvOp(Op):
                           stride=self.stride, transposed=int(self.transposed), relu=int(self.relu),
                           epilogue=self.epilogue, config=self.config, operand_dtype=self.operand_dtype,
                           x_dtype=_lib.ACT_F16 if self.x.dtype == 'f16' else _lib.ACT_F32,
-                          y_dtype=_lib.ACT_F16 if self.y.dtype == 'f16' else _lib.ACT_F32, k_step=self.k_step)
+                          y_dtype=_lib.ACT_F16 if self.y.dtype == 'f16' else _lib.ACT_F32, k_step=self.k_step,
+                          weights_path=int(getattr(self.x.graph, 'conv_weights_path', 0)))
         return d
 
     def flops(self):
@@ -1339,6 +1340,9 @@ class Graph(object):
         # split-K for F(4x4,3x3) launches of fewer workgroups than CUs (single frames: conv4b 160, conv5 80, conv6 40): the
         # split WinogradF43ConvOp.best_k_split picks (eight-wave form; 0 / 1 = never split)
         self.winograd_f43_max_k_split = 8
+        # kfn_conv_desc.weights_path of the fp16-activation direct kernel (0 = the library's choice; 1 = operands through registers,
+        # 2 = weights by LDS-DMA, 3 = both operand tiles by LDS-DMA): an A/B and debugging switch
+        self.conv_weights_path = 0
         self.winograd_s2_max_k_split = 8         # the same for the eight-wave stride-2 kernel (conv4a at batch 1: 320 workgroups)
         # the eight-wave form of the F(4x4,3x3) kernel (wino4b_kernel; measured at batch 32 against the four-wave form, same
         # box: conv1b 2.66 -> 2.34 ms, conv2b 6.98 -> 6.54, conv3b 6.43 -> 6.13, conv4b 6.08 -> 5.85)
