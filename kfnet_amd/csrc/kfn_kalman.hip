@@ -25,6 +25,11 @@
 // touched again by this launch; the [h,w,4] state never leaves LDS).
 #include "kfn_common.h"
 
+// 1 = the scan kernel's buffer descriptors are forced into SGPRs (v_readfirstlane), 0 = as hipcc makes them (waterfall loops)
+#ifndef KFN_SCAN_UNIFORM_SRD
+#define KFN_SCAN_UNIFORM_SRD 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -182,10 +187,12 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
 // whole frame of inputs in flight per thread); the single-buffer forms of the larger grids, which also hold PPT new states
 // in registers across their mid-frame barrier, take a short ring.  NT: non-temporal input loads / record stores.
 // PTR: how the streams are addressed.  true = per-pixel 64-bit pointers (clamped index, predicated stores): the compiler
-// keeps them live across the frame loop (eight VGPRs per slot), which the double-buffered 60x80 form can afford -- and it
-// is the fastest form there (same box, S = 256: 0.662 / 0.672 of 8 TB/s at T = 64 / 256 against 0.633 / 0.645 with
-// descriptors).  false = buffer descriptors with scalar frame / slot offsets (below): no per-slot registers, which is what
-// lets the single-buffer forms of the larger grids run without spills (68x120: 0.644 against 0.42-0.43 for rounds 1-4's form).
+// keeps them live across the frame loop (eight VGPRs per slot), which the double-buffered 60x80 form can afford; it was the
+// fastest form there while the descriptors still sat in waterfall loops (0.662 / 0.672 of 8 TB/s at T = 64 / 256 against
+// 0.633 / 0.645), and with scalar descriptors the two are level (S = 256, same box: 0.664 / 0.630 against 0.661 / 0.629-0.647),
+// so the production 60x80 form stays as measured in the profiles.  false = buffer descriptors with scalar frame / slot
+// offsets (below): no per-slot registers, which is what lets the single-buffer forms of the larger grids run without spills
+// (68x120, S = 256: 0.720 against 0.43 for rounds 1-4's form).
 template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false>
 __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   static_assert(D >= 1 && D <= PPT && PPT % D == 0, "ring slots are compile-time constants");
@@ -214,16 +221,26 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   const size_t seq_px = (size_t)s * T * HW;
   const unsigned aux = NT ? 2u : 0u;          // the non-temporal bit: streamed once, not re-read by this launch
   // (hipcc does not prove these descriptors wave-uniform -- the sequence offset reaches them through the divergent
-  //  state-copy loop above -- and wraps every buffer instruction in a waterfall loop: four v_readfirstlane, two compares, a
-  //  branch.  Forcing them scalar with readfirstlane removes the loops (72 instead of 88 VGPRs, a quarter fewer
-  //  instructions) and measured the SAME speed on the 60x80 form, but the single-buffer forms built that way returned
-  //  wrong records (config 5's tests, the A/B harness: "DIFFERS"); the cause was not found in the time there was, so the
-  //  descriptors stay as the compiler makes them -- every form below is the one the harness holds bit-identical to
-  //  rounds 1-4's kernel.  profiles/r05_kalman_ab.log keeps all three runs.)
-  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x2*>(a.flow + seq_px), 0, T * HW * 8, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sigma_t + seq_px), 0, T * HW * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.meas + seq_px), 0, T * HW * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rec + seq_px, 0, T * HW * 16, 0x00020000);
+  //  state-copy loop above -- and would wrap every buffer instruction in a waterfall loop: four v_readfirstlane, two
+  //  compares, a branch.  The base pointers go through v_readfirstlane instead: 72 instead of 88 VGPRs, a quarter fewer
+  //  instructions; same box, S = 256: 68x120 0.651 -> 0.720 of 8 TB/s, config 5's S = 4 x T = 64 scan 0.711 -> 0.601 ms,
+  //  60x80 descriptor form 0.613 -> 0.661 (profiles/r05_kalman_srd_ab.log).  The first build of this returned WRONG records
+  //  in the single-buffer forms: that was the 16-byte-store hazard of kfn_common.h buffer_store_b128 -- without the
+  //  waterfall loop nothing separated the record store from the next write of its data registers -- and with the padded
+  //  store every form is bit-identical to rounds 1-4's kernel again.  KFN_SCAN_UNIFORM_SRD=0 builds the waterfall form.)
+#if KFN_SCAN_UNIFORM_SRD
+  auto uniform = [](auto* q) {       // the pointer's two halves through v_readfirstlane: the descriptor is built in SGPRs
+    const uintptr_t v = reinterpret_cast<uintptr_t>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<decltype(q)>((uintptr_t)lo | ((uintptr_t)hi << 32));
+  };
+#else
+  auto uniform = [](auto* q) { return q; };
+#endif
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(uniform(const_cast<f32x2*>(a.flow + seq_px)), 0, T * HW * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(uniform(const_cast<float*>(a.sigma_t + seq_px)), 0, T * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(uniform(const_cast<f32x4*>(a.meas + seq_px)), 0, T * HW * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(uniform(a.rec + seq_px), 0, T * HW * 16, 0x00020000);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned POISON = 0x08000000u;    // element index: x 4 / 8 / 16 >= num_records of the three element sizes
   PixIn ring[D];

@@ -711,7 +711,7 @@ constexpr int B_LDS = B_LDS_V > B_LDS_OUT ? B_LDS_V : B_LDS_OUT;
 #endif
 constexpr int NBB = KFN_W4B_NB;                   // B ring in position PAIRS (16 bytes per lane and pair)
 #ifndef KFN_W4B_NVB
-#define KFN_W4B_NVB 4
+#define KFN_W4B_NVB 2
 #endif
 constexpr int NVB = KFN_W4B_NVB;                  // V ring (16 bytes per lane and fragment)
 static_assert(18 % NBB == 0 && 36 % NVB == 0 && NBB <= WPOS / 2 && NVB <= WPOS, "ring slots are compile-time constants per super-step");
@@ -765,6 +765,42 @@ __device__ __forceinline__ void bt_d_b6s(float (&v)[36]) {   // v[6 r + c] -> v[
 #pragma unroll
   for (int c = 0; c < 6; ++c) bt6s(v[c], v[6 + c], v[12 + c], v[18 + c], v[24 + c], v[30 + c]);
 }
+
+// The same transform on ONE channel per lane with PACKED instructions (round 5): 72 v_pk instead of 144 plain ones.
+// The patch sits in 18 register pairs, pair (c, m) = rows (2m, 2m + 1) of column c.
+//   pass 1, along r, six instructions per column: with P0 = (d0,d1), P1 = (d2,d3), P2 = (d4,d5)
+//       (t0,t5) = 4 P0 - 5 P1 + P2                         two fma: the two outer outputs are ONE formula on shifted inputs
+//       (a, c)  = d4 - (4,1) d2     (b, e) = d3 - (4,1) d1  one fma each: broadcast halves (op_sel), constant pair (-4,-1)
+//       (t1,t3) = (a,c) + (1,2)(b,e)    (t2,t4) = (a,c) - (1,2)(b,e)
+//     leaves pairs over the TRANSFORMED row index: (xi 0, 5), (1, 3), (2, 4) -- still one column per pair, so
+//   pass 2, along c, is the plain formula (bt6 above, 12 instructions) on three rows of pairs.
+// Same products and sums as bt6s in the same roundings (fma(x, 1, y) = x + y, fma(x, -1, y) = y - x); the two passes run in
+// the other order than bt_d_b6s, so single results differ from that form in the last bit.
+#ifndef KFN_W4B_PACKED
+#define KFN_W4B_PACKED 1
+#endif
+struct BtConstP {
+  BtConst k;            // pass 2
+  f32x2 m41, p12, m12;  // (-4,-1), (1,2), (-1,-2)
+};
+__device__ __forceinline__ void bt6r(f32x2& P0, f32x2& P1, f32x2& P2, const BtConstP& k) {
+  f32x2 t, ac, be;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(P1), "s"(k.k.m5), "v"(P2));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(ac) : "v"(P1), "s"(k.m41), "v"(P2));   // lo halves: d2, d4
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(be) : "v"(P0), "s"(k.m41), "v"(P1));   // hi halves: d1, d3
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P0) : "v"(P0), "s"(k.k.p4), "v"(t));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P1) : "v"(be), "s"(k.p12), "v"(ac));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P2) : "v"(be), "s"(k.m12), "v"(ac));
+}
+__device__ __forceinline__ void bt_d_b6p(f32x2 (&pp)[18], const BtConstP& k) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) bt6r(pp[3 * c], pp[3 * c + 1], pp[3 * c + 2], k);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) bt6(pp[m], pp[3 + m], pp[6 + m], pp[9 + m], pp[12 + m], pp[15 + m], k.k);
+}
+// patch element (r, c) in the pairs, and transformed position (xi, nu) after bt_d_b6p
+#define KFN_PP_IN(pp, r, c) (pp)[3 * (c) + (r) / 2][(r) & 1]
+#define KFN_PP_OUT(pp, xi, nu) (pp)[3 * (nu) + ((xi) == 0 || (xi) == 5 ? 0 : ((xi) == 1 || (xi) == 3 ? 1 : 2))][((xi) == 5 || (xi) == 3 || (xi) == 4) ? 1 : 0]
 
 __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];   // [4][B_VBUF] floats, later the output image
@@ -845,7 +881,13 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
 #pragma unroll
     for (int th = 0; th < 2; ++th) acc[l][th] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if KFN_W4B_PACKED
+  f32x2 pp[18];
+  const BtConstP kp = {{{4.f, 4.f}, {-4.f, -4.f}, {-5.f, -5.f}, {2.f, 2.f}, {-2.f, -2.f}}, {-4.f, -1.f}, {1.f, 2.f}, {-1.f, -2.f}};
+  static_assert(!KFN_W4B_XDIST, "the distributed transform exists in the plain form only");
+#else
   float pv[36];
+#endif
   f32x4 bq[NBB];       // ring of position PAIRS
   f32x4 vq[NVB];
 
@@ -855,11 +897,20 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const int sc = ss < s_last ? ss : s_last;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
-    pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
+#if KFN_W4B_PACKED
+    KFN_PP_IN(pp, r, c) = v;
+#else
+    pv[i] = v;
+#endif
   };
   auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
+#if KFN_W4B_PACKED
+    smf[(ss & 1) * (CPS * B_VBUF) + v_st + g * B_VPOS] = KFN_PP_OUT(pp, g / 6, g % 6);
+#else
     smf[(ss & 1) * (CPS * B_VBUF) + v_st + g * B_VPOS] = pv[g];
+#endif
   };
   auto b_load = [&](auto sl_, int ch, int pr) __attribute__((always_inline)) {      // pair pr (0..8) of this wave's positions
     constexpr int sl = decltype(sl_)::value;
@@ -875,7 +926,11 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   // ---- prologue ----------------------------------------------------------------------------------------------------
   sfor4<36>([&](auto ic) { p_gather(ic, 0); });
   sfor4<NBB>([&](auto sc) { b_load(sc, 0, decltype(sc)::value); });
+#if KFN_W4B_PACKED
+  bt_d_b6p(pp, kp);
+#else
   bt_d_b6s(pv);
+#endif
   sfor4<36>([&](auto gc) { p_store(gc, 0); });
   // The two waves of a SIMD (w and w + 4) do their producer work in different HALVES of a super-step (KFN_W4B_STAGGER): in
   // lockstep both would stand in the same transform burst / load group at the same time and the MFMA pipe would idle
@@ -928,6 +983,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
             if constexpr (gi < 36) p_gather(std::integral_constant<int, gi>{}, ks + 1);
           });
         }
+#if !KFN_W4B_PACKED
         if constexpr (KFN_W4B_XDIST) {
           // the transform as 12 passes in 12 different slots (two waves per SIMD: a pass of 12 instructions can sit under the
           // partner's MFMAs, a burst of 144 on both waves at once cannot): row pass r (its loads went out by slot 12 r + 10) at
@@ -946,8 +1002,14 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
             constexpr int k = sj - 106;
             p_store(std::integral_constant<int, 6 * (k % 6) + k / 6>{}, ks + 1);
           }
-        } else {
+        } else
+#endif
+        {
+#if KFN_W4B_PACKED
+          if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6p(pp, kp);
+#else
           if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6s(pv);
+#endif
           if constexpr (!(KFN_W4B_DBG & 4) && sj >= S0 && (sj - S0) * SPS < 36) {
             sfor4<SPS>([&](auto uc) {
               constexpr int gi = (sj - S0) * SPS + decltype(uc)::value;
