@@ -289,6 +289,55 @@ def test_kalman_scan_vs_oracle(cfg):
         assert np.allclose(nis.cpu().numpy().reshape(r_nis.shape), r_nis, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('grid', [(60, 80), (68, 120)])
+def test_kalman_scan_is_reproducible_under_memory_load(grid):
+    """The production instantiations (no optional outputs; 60x80: double-buffered state, 68x120: single-buffer form whose
+    records leave through 16-byte buffer stores with scalar descriptors) beside a loaded memory system: 20 launches, records
+    and final state bit-identical to an unloaded launch and to the instantiation WITH the optional outputs.  (The first
+    scalar-descriptor build of round 5 returned wrong records here: the store hazard of kfn_common.h buffer_store_b128.)"""
+    import torch
+    from tests.gpu_util import dev, stream
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    H, W = grid
+    S, T = 48, 6
+    rng = np.random.default_rng(H)
+    flow = dev((rng.normal(size=(S, T, H, W, 2)) * 2.0).astype(np.float32))
+    sig = dev(np.abs(rng.normal(size=(S, T, H, W, 1)) * 0.05).astype(np.float32))
+    m = rng.normal(size=(S, T, H, W, 4)).astype(np.float32)
+    m[..., 3] = np.abs(m[..., 3]) * 0.3 + 0.05
+    meas = dev(m)
+    st0 = rng.normal(size=(S, H, W, 4)).astype(np.float32)
+    st0[..., 3] = np.abs(st0[..., 3]) * 0.3 + 0.05
+    state0 = dev(st0)
+    d = _lib.KalmanDesc(S=S, T=T, H=H, W=W, t0=1, reset_period=500, min_uncertainty=1e-5, nis_gate=0.0, has_transform=0)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(64 << 20, device='cuda')
+    big_b = torch.empty_like(big_a)
+
+    def launch(load, debug=False):
+        st = state0.clone()
+        rec = torch.zeros(S * T * H * W * 4, device='cuda')
+        tmp = torch.zeros(S * T * H * W * 4, device='cuda') if debug else None
+        torch.cuda.synchronize()
+        if load:
+            _side_stream_load(torch, side, big_a, big_b, copies=2)
+        _lib.check(lib.kfn_kalman_scan(C.byref(d), flow.data_ptr(), sig.data_ptr(), meas.data_ptr(), st.data_ptr(), rec.data_ptr(),
+                                       tmp.data_ptr() if debug else None, None, None, stream()), 'scan')
+        torch.cuda.synchronize()
+        return rec, st
+
+    ref_rec, ref_st = launch(False)
+    dbg_rec, dbg_st = launch(False, debug=True)
+    assert torch.equal(dbg_rec, ref_rec) and torch.equal(dbg_st, ref_st)
+    bad = []
+    for r in range(20):
+        rec, st = launch(True)
+        if not (torch.equal(rec, ref_rec) and torch.equal(st, ref_st)):
+            bad.append(r)
+    assert not bad, 'launches %s differ from the unloaded one' % bad
+
+
 def test_kalman_fuse2_symmetric_variance():
     """kfn_kalman_fuse2 = KFNet.GetKFCoord2's fusion (KFNet/KFNet.py:487-502): bit exact vs the fp32 numpy oracle;
     KAT: equal noise -> K = 1/2, mean of the two, sigma / sqrt(2); its sigma equals BuildKFCoord's up to round-off."""
@@ -638,6 +687,85 @@ def test_conv3x3_c64_f16_vs_oracle(case):
         tol = _conv_tol(x.astype(np.float32), wt) + np.abs(ref) * 2.0 ** -11 + 1e-7
         assert np.all(np.abs(got - ref) <= tol), float((np.abs(got - ref) - tol).max())
         yd.fill_(-123.0)
+
+
+def _side_stream_load(torch, side, big_a, big_b, copies=6):
+    """512 MB copies on another stream: HBM / fabric back-pressure beside the kernel under test."""
+    with torch.cuda.stream(side):
+        for _ in range(copies):
+            big_b.copy_(big_a)
+
+
+def test_conv3x3_c64_f16_is_reproducible_under_memory_load():
+    """Regression test of the 16-byte buffer-store hazard (kfn_common.h buffer_store_b128): round 4's kernel sent,
+    for one launch in seven of this shape while another stream loaded the memory system, the NEXT store's byte offset as the
+    first dword of a few 16-byte pieces (the compiler reuses a store's dead data register at once; the store reads it late).
+    40 launches beside 3 GB of copies each: all bit-identical to the first AND to an unloaded launch."""
+    import torch
+    from tests.gpu_util import stream
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_conv64_rows_kernel
+    lib = _lib.load()
+    n, h, w = 5, 540, 960
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float16)).cuda()
+    wt = (rng.normal(size=(3, 3, 64, 64)) * np.sqrt(2.0 / 576)).astype(np.float32)
+    wp = torch.from_numpy(pack_conv64_rows_kernel(wt)).cuda()
+    b = torch.from_numpy(rng.normal(size=64).astype(np.float32)).cuda()
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=64, ldx=64, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1, relu=1,
+                      operand_dtype=_lib.OPERAND_F16, x_dtype=_lib.ACT_F16, y_dtype=_lib.ACT_F16)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(64 << 20, device='cuda')
+    big_b = torch.empty_like(big_a)
+
+    def launch(load):
+        y = torch.full((n * h * w, 64), -3.0, dtype=torch.float16, device='cuda')
+        torch.cuda.synchronize()
+        if load:
+            _side_stream_load(torch, side, big_a, big_b)
+        _lib.check(lib.kfn_conv3x3_c64_f16(C.byref(d), x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), stream()), 'c64')
+        torch.cuda.synchronize()
+        return y
+
+    ref = launch(False)
+    bad = [r for r in range(40) if not torch.equal(launch(True), ref)]
+    assert not bad, 'launches %s differ from the unloaded one' % bad
+
+
+@pytest.mark.parametrize('kind,form', [('f43', 3), ('s2', 4), ('fused', 0)])
+def test_winograd_16_byte_stores_are_reproducible_under_memory_load(kind, form):
+    """The same condition for the Winograd epilogues (their 16-byte image-row stores carry an SGPR row offset too)."""
+    import torch
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_f43_kernel_b, pack_winograd_fused_kernel, pack_winograd_s2_kernel_b
+    from tests.gpu_util import stream
+    lib = _lib.load()
+    n, h, w, ci, co = 8, 120, 160, 128, 128
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.normal(size=(n, h, w, ci)).astype(np.float32)).cuda()
+    wt = (rng.normal(size=(3, 3, ci, co)) / np.sqrt(9 * ci)).astype(np.float32)
+    stride = 2 if kind == 's2' else 1
+    pack = {'f43': pack_winograd_f43_kernel_b, 's2': pack_winograd_s2_kernel_b, 'fused': pack_winograd_fused_kernel}[kind]
+    entry = {'f43': lib.kfn_conv2d_winograd_f43, 's2': lib.kfn_conv2d_winograd_s2, 'fused': lib.kfn_conv2d_winograd_fused}[kind]
+    u = torch.from_numpy(pack(wt)).cuda()
+    b = torch.from_numpy(rng.normal(size=co).astype(np.float32)).cuda()
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=stride, relu=1, wino_form=form)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(64 << 20, device='cuda')
+    big_b = torch.empty_like(big_a)
+
+    def launch(load):
+        y = torch.full((n * (h // stride) * (w // stride), co), -3.0, device='cuda')
+        torch.cuda.synchronize()
+        if load:
+            _side_stream_load(torch, side, big_a, big_b, copies=3)
+        _lib.check(entry(C.byref(d), x.data_ptr(), u.data_ptr(), b.data_ptr(), y.data_ptr(), stream()), kind)
+        torch.cuda.synchronize()
+        return y
+
+    ref = launch(False)
+    bad = [r for r in range(25) if not torch.equal(launch(True), ref)]
+    assert not bad, '%s: launches %s differ from the unloaded one' % (kind, bad)
 
 
 def test_conv3x3_c64_f16_rejects_what_it_cannot_do():
