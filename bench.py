@@ -93,6 +93,7 @@ def parse():
     ap.add_argument('--block', type=int, default=32, help='multi-rank runs: frames per block of the block-cyclic sharding measured beside the contiguous one')
     ap.add_argument('--decode-workers', type=int, default=0, help='PNG decode threads of the end-to-end block (0 = min(32, cores / 2))')
     ap.add_argument('--eval-chunk', type=int, default=32, help='frames per host chunk of the PNG end-to-end block')
+    ap.add_argument('--eval-ramp', default='', help='lengths of the first chunks of the PNG end-to-end block, e.g. "8,16" (default: eval()\'s own: 8, 16); "0" = none')
     ap.add_argument('--no-config3', action='store_true',
                     help='when --steps < 256: skip the additional literal 256-frame / batch-32 pass of BASELINE configs[2]')
     ap.add_argument('--conv-operands', choices=['f32', 'f16', 'f16x3'], default='f32',
@@ -306,7 +307,7 @@ def host_streamed(eng, host_frames, dev_frames, chunk=None):
                     '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
 
 
-def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4, workers=0):
+def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4, workers=0, ramp=None):
     """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
     (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
     package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the
@@ -342,8 +343,9 @@ def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_record
         tele = Telemetry(dev_index)
         with tele:
             t0 = time.perf_counter()
+            host_stats = {}
             rec = KE.eval(image_paths, transform, Wt, outd, image_size=(eng.H, eng.W), chunk=chunk, verbose=False,
-                          decode_workers=workers, engine=eng)
+                          decode_workers=workers, engine=eng, stats=host_stats, ramp=ramp)
             dt = time.perf_counter() - t0
         files = sorted(os.listdir(outd))
         on_disk = np.stack([np.load(os.path.join(outd, 'coord_%d.npy' % i)) for i in (0, T // 2, T - 1)])
@@ -353,12 +355,17 @@ def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_record
         t_same = bool(np.array_equal(np.asarray(transform, np.float32), np.asarray(T4, np.float32)))
         return {'value': round(NT / dt, 3), 'unit': 'frames/s', 'frames': NT, 'distinct_png_files': T, 'chunk': chunk, 'seconds': round(dt, 3),
                 'decode_threads': workers, 'host_cores': cores, 'npy_files_written': len(files),
+                'first_chunks': [r for r in ((8, 16) if ramp is None else ramp) if r < chunk],
                 'png_megabytes': round(png_mb, 1), 'png_write_seconds_untimed': round(t_w, 2),
                 'gpu_busy_pct': (tele.summary().get('busy_pct') or {}).get('mean'),
                 'bit_identical_to_resident_run': same, 'transform_roundtrip_exact': t_same,
+                # the consumer thread's wall time (seconds): waiting for decoded chunks (`loader_wait`, of which the first
+                # chunk's exposed decode `loader_wait_first`), enqueueing launches, waiting for records, copying + queueing the
+                # .npy writes (`emit`), waiting for the last writes (`saves_wait`)
+                'consumer_thread_seconds': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in host_stats.items()},
                 'note': 'image_list.txt -> PIL PNG decode on a thread pool -> pinned staging -> H2D -> towers + scan -> D2H '
-                        '-> coord_<i>.npy (np.save on 2 writer threads); a short first chunk (one tower batch) whose decode is '
-                        'exposed, then chunks of `chunk` frames that decode while the GPU computes'}
+                        '-> coord_<i>.npy (np.save on 2 writer threads); a ramp of short first chunks (`first_chunks`: the first decode is '
+                        'exposed, each chunk\'s compute covers the next one\'s decode), then chunks of `chunk` frames'}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -594,7 +601,9 @@ def config3_literal(args, Wt, T4, transform_txt, device, dev_index, frames=256, 
         if not args.no_eval_png:
             resident = eng.process(dev, t0=0).cpu().numpy()
             extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index,
-                                                               chunk=args.eval_chunk, workers=args.decode_workers)
+                                                               chunk=args.eval_chunk, workers=args.decode_workers,
+                                                               ramp=([int(v) for v in args.eval_ramp.split(',') if int(v) > 0]
+                                                                     if args.eval_ramp else None))
             hs = extra['host_streamed']['value']
             extra['eval_png_end_to_end']['fraction_of_host_streamed'] = round(extra['eval_png_end_to_end']['value'] / hs, 4)
     del eng, dev

@@ -40,13 +40,28 @@ extern "C" {
 
 /* 5 (round 4): kfn_conv_desc starts with `struct_size` (the struct had grown at its end -- weights_path -- without a
  * version bump); kfn_comm_rank asks RCCL; kfn_kalman_scan_ex no longer allocates.  A host checks
- * kfn_abi_version() == KFN_ABI_VERSION once after loading the library. */
-#define KFN_ABI_VERSION 6
+ * kfn_abi_version() == KFN_ABI_VERSION once after loading the library.
+ * 6 (round 5): split-K Winograd entry points, kfn_winograd_lds_bytes.  7 (round 5): kfn_decode_png_rgb8. */
+#define KFN_ABI_VERSION 7
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
 /* Device facts used by the host-side tile heuristics.  arch receives e.g. "gfx950". */
 int kfn_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- host side of the image stream ---------------------------------------------------------------------------------
+ * tf.image.decode_png(channels=3) of the reference's queue runners (KFNet/train.py:195-239, the decode at :213-217):
+ * n PNG files -> dst [n][H][W][3] uint8 RGB, decoded by `threads` native threads (<= 0: one per file, at most the
+ * hardware's) straight into the caller's staging buffer (page-locked or not).  Host code only -- no device access, no GIL.
+ * Non-interlaced files of bit depth <= 8, colour types gray / RGB / palette / gray+alpha / RGBA (alpha dropped, gray
+ * replicated: what decode_png(channels=3) and PIL's convert('RGB') return).  status [n] (may be NULL) receives one of the
+ * KFN_PNG_* codes per file: an interlaced or 16-bit file is KFN_PNG_UNSUPPORTED -- its frame in dst is left untouched and
+ * the call still succeeds (kfnet_amd.pipeline decodes those with PIL); a missing, corrupt or wrong-sized file is
+ * KFN_PNG_ERROR and the call returns KFN_ERR_ARG with kfn_last_error() naming the first such file. */
+#define KFN_PNG_OK 0
+#define KFN_PNG_UNSUPPORTED 1
+#define KFN_PNG_ERROR 2
+int kfn_decode_png_rgb8(const char* const* paths, int n, int H, int W, unsigned char* dst, int* status, int threads);
 
 /* ---- plumbing for hosts that do not bring their own allocator/streams (PyTorch does) -- */
 int kfn_malloc(void** dptr, size_t bytes);

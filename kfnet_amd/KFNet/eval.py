@@ -127,13 +127,16 @@ def eval_sharded_cyclic(image_paths, transform, weights, output_folder, rank, wo
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=RESET_PERIOD, chunk=256, verbose=True, label_paths=None, labels=None,
-         decode_workers=8, device=None, metrics_sequence_length=1000, engine=None, save_workers=2):
+         decode_workers=8, device=None, metrics_sequence_length=1000, engine=None, save_workers=2, stats=None, ramp=None):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
     returns (records, metrics) in that case.  `engine`: a ready KFNetEngine to run on (its batch / max_chunk / transform
     are used; bench.py times the path without the one-off graph build); `save_workers`: threads that write the
-    coord_<i>.npy files behind the consumer loop (np.save releases the GIL in the file write)."""
+    coord_<i>.npy files behind the consumer loop (np.save releases the GIL in the file write); `stats`: a dict that receives
+    where the consumer thread's wall time went (StreamedSequence.stats + `emit` and `saves_wait` seconds); `ramp`: lengths of
+    the first chunks (default (8, 16) in front of chunks of >= 32 frames: the first decode is exposed, keep it short, and let
+    each ramp chunk's compute cover the next one's decode -- pipeline.ChunkLoader)."""
     from ..engine import KFNetEngine
     from . import metrics as M
     from ..pipeline import ChunkLoader, StreamedSequence
@@ -185,7 +188,8 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     # records of the chunk that was uploaded from it have been handed out, i.e. its upload is complete.
     in_flight = 2 if want_metrics else 3
     loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
-                         workers=decode_workers, first_chunk=min(chunk, max(eng.B, 16)), depth=in_flight + 1)
+                         workers=decode_workers, first_chunk=[r for r in ((8, 16) if ramp is None else ramp) if r < chunk],
+                         depth=in_flight + 1)
     dm = M.DeviceMetrics(eng) if want_metrics else None
     plan = {}     # chunk index -> (first, n, global pairs)
 
@@ -204,9 +208,14 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
         plan[k] = (lo, n, pairs)
 
     k = 0
+    import time
+    t_emit = t_saves = 0.0
+    seq = StreamedSequence(eng, chunk, depth=in_flight)
     try:
-        for lo, rec in StreamedSequence(eng, chunk, depth=in_flight).run(loader, after_process=after_process if want_metrics else None):
+        for lo, rec in seq.run(loader, after_process=after_process if want_metrics else None):
+            t_e = time.perf_counter()
             emit(lo, rec.copy())
+            t_emit += time.perf_counter() - t_e
             if want_metrics:
                 first, n, pairs = plan.pop(k)
                 for m in dm.collect(k & 1, first, n, pairs):
@@ -216,8 +225,13 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
             elif verbose:
                 print('frames %d~%d done' % (lo, lo + rec.shape[0] - 1))
             k += 1
+        t_e = time.perf_counter()
         for f in pending_saves:
             f.result()          # re-raise write errors; every file is on disk when eval() returns
+        t_saves = time.perf_counter() - t_e
+        if stats is not None:
+            stats.update(getattr(seq, 'stats', {}), emit=t_emit, saves_wait=t_saves,
+                         producer={k: round(v, 4) for k, v in getattr(loader, 'stats', {}).items()})
     finally:
         if saver is not None:   # also when the loop raised: no writer thread outlives the call
             saver.shutdown()

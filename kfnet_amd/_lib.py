@@ -10,11 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
 ACT_F32, ACT_F16 = 0, 1
+PNG_OK, PNG_UNSUPPORTED, PNG_ERROR = 0, 1, 2
 WINO_ORDER_AUTO, WINO_ORDER_M_FAST, WINO_ORDER_N_FAST = 0, 1, 2
 CFG_128x256 = 9
 CFG_256x64, CFG_256x256, CFG_256x256_W8 = 12, 13, 14
@@ -107,6 +108,7 @@ SYMBOLS = {
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
     'kfn_kalman_fuse2': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    'kfn_decode_png_rgb8': (_i, [C.POINTER(C.c_char_p), _i, _i, _i, _vp, C.POINTER(_i), _i]),
     'kfn_comm_available': (_i, []),
     'kfn_comm_unique_id': (_i, [_vp, _sz]),
     'kfn_comm_init': (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),

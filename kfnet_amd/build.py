@@ -73,7 +73,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs + ['-lz'])     # zlib: kfn_png.hip
     return LIB
 
 

@@ -16,8 +16,10 @@ Here a sequence is cut into chunks:
 Nothing here touches the numbers: records are bit-identical to `KFNetEngine.process` on a
 resident sequence (tests/test_gpu_e2e.py).
 """
+import os
 import queue
 import threading
+import time
 
 import numpy as np
 
@@ -33,13 +35,45 @@ def decode_image(path, image_size):
     return a
 
 
+def decode_png_batch(paths, dst, image_size, threads):
+    """PNG files -> dst [n,H,W,3] uint8 (a numpy view of the staging buffer) on the library's own threads
+    (`kfn_decode_png_rgb8`, csrc/kfn_png.hip): one call per chunk, no interpreter lock while it runs.  Files the native
+    decoder does not take (interlaced, 16-bit) go through PIL; a broken file raises ValueError naming it."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(paths)
+    if n == 0:
+        return
+    H, W = image_size
+    assert dst.dtype == np.uint8 and dst.shape[1:] == (H, W, 3) and dst.shape[0] >= n and dst.flags['C_CONTIGUOUS']
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    status = (C.c_int * n)()
+    rc = lib.kfn_decode_png_rgb8(arr, n, H, W, dst.ctypes.data, status, int(threads))
+    if rc != 0:
+        raise ValueError(lib.kfn_last_error().decode())
+    for i in range(n):
+        if status[i] == _lib.PNG_UNSUPPORTED:
+            dst[i] = decode_image(paths[i], image_size)
+
+
+def _native_png_available():
+    if os.environ.get('KFN_PNG_DECODER', 'native') == 'pil':     # A/B switch (bench runs, tools/experiments)
+        return False
+    try:
+        from . import _lib
+        _lib.load()
+        return True
+    except Exception:      # library not built (a source checkout without hipcc): PIL decodes
+        return False
+
+
 def _host_buffer(shape, dtype, pinned):
     """uint8/float32 staging buffer; page-locked when a GPU runtime is there to lock it."""
     import torch
-    t = torch.empty(shape, dtype=dtype)
     if pinned and torch.cuda.is_available():
-        t = t.pin_memory()
-    return t
+        return torch.empty(shape, dtype=dtype, pin_memory=True)     # (not empty().pin_memory(): that allocates twice and copies)
+    return torch.empty(shape, dtype=dtype)
 
 
 class ChunkLoader(object):
@@ -51,20 +85,29 @@ class ChunkLoader(object):
     flight needs depth >= N + 1: a buffer is then recycled only after the records of the chunk uploaded
     from it have been handed out)."""
 
-    def __init__(self, source, image_size, chunk, workers=8, depth=4, pinned=True, decode=decode_image, first_chunk=None):
+    def __init__(self, source, image_size, chunk, workers=8, depth=4, pinned=True, decode=decode_image, first_chunk=None,
+                 native=True):
         """`first_chunk` (< chunk): length of the FIRST chunk only -- its decode is the one nothing overlaps, so a short
-        one (a tower batch) gets the GPU going while the first full chunk is still decoding; every later chunk is `chunk`
-        frames (deep launch queues: the consumer thread shares the interpreter with the decode and writer threads)."""
+        one gets the GPU going while the first full chunk is still decoding -- or a sequence of lengths, a RAMP (e.g. (8, 16)
+        in front of chunks of 32: decoding n frames on n threads takes about as long as decoding one, computing them takes n
+        frame times, so each ramp chunk's compute covers the next one's decode); every later chunk is `chunk` frames (deep
+        launch queues: the consumer thread shares the interpreter with the decode and writer threads)."""
         import torch
         self.image_size = tuple(image_size)
         self.chunk = int(chunk)
         if self.chunk <= 0:
             raise ValueError('chunk must be positive')
-        self.first_chunk = self.chunk if not first_chunk else max(1, min(int(first_chunk), self.chunk))
+        ramp = [] if not first_chunk else ([first_chunk] if isinstance(first_chunk, (int, np.integer)) else list(first_chunk))
+        self.ramp = [max(1, min(int(r), self.chunk)) for r in ramp]
+        self.ramp = [r for r in self.ramp if r < self.chunk]           # a "ramp" chunk as long as a chunk is just a chunk
+        self.first_chunk = self.ramp[0] if self.ramp else self.chunk
         self.source = source
         self.T = len(source)
         self.workers = max(1, int(workers))
         self.decode = decode
+        # PNG lists are decoded by the C-ABI library when it is there (kfn_decode_png_rgb8); `native=False` or a custom `decode`
+        # callable selects the Python thread pool (PIL)
+        self.native = bool(native) and _native_png_available()
         H, W = self.image_size
         if isinstance(source, np.ndarray):
             if source.dtype != np.uint8 or source.shape[1:] != (H, W, 3):
@@ -76,9 +119,11 @@ class ChunkLoader(object):
         self.pinned = bool(pinned)
         self._torch = torch
         self.bufs = [None] * self.depth
-        self.first_buf = None
-        if self.first_chunk < self.chunk and self.T > 0:
-            self.first_buf = _host_buffer((self.first_chunk, H, W, 3), torch.uint8, pinned)
+        # ramp chunks: their own small buffers, outside the rotation (valid for the loader's whole life); the first is locked
+        # here, the others by the producer thread
+        self.ramp_bufs = [None] * len(self.ramp)
+        if self.ramp and self.T > 0:
+            self.ramp_bufs[0] = _host_buffer((self.ramp[0], H, W, 3), torch.uint8, pinned)
         self.free = queue.Queue()
         for i in range(self.depth):
             self.free.put(i)
@@ -91,7 +136,7 @@ class ChunkLoader(object):
         """[(lo, hi)] of the chunks, in order."""
         out, lo = [], 0
         while lo < self.T:
-            hi = min(self.T, lo + (self.first_chunk if lo == 0 else self.chunk))
+            hi = min(self.T, lo + (self.ramp[len(out)] if len(out) < len(self.ramp) else self.chunk))
             out.append((lo, hi))
             lo = hi
         return out
@@ -103,6 +148,9 @@ class ChunkLoader(object):
         dst = buf.numpy()
         if isinstance(self.source, np.ndarray):
             dst[:hi - lo] = self.source[lo:hi]
+            return
+        if self.decode is decode_image and self.native:      # the default decoder: the library's threads, one call
+            decode_png_batch(self.source[lo:hi], dst, self.image_size, self.workers)
             return
         def one(i):
             dst[i - lo] = self.decode(self.source[i], self.image_size)
@@ -116,19 +164,34 @@ class ChunkLoader(object):
             list(self._pool.map(one, range(lo, hi)))   # list(): re-raise decode errors here
 
     def _produce(self):
+        # the producer thread's wall time (seconds): page-locking staging buffers, decoding / copying, waiting for a free buffer
+        st = self.stats = {'alloc': 0.0, 'fill': 0.0, 'free_wait': 0.0}
+        clock = time.perf_counter
         try:
             H, W = self.image_size
-            for lo, hi in self.bounds():
-                if lo == 0 and self.first_buf is not None:      # its own buffer, outside the rotation
-                    self._fill(self.first_buf, lo, hi)
-                    self.ready.put((lo, hi - lo, -1, None))
+            for k, (lo, hi) in enumerate(self.bounds()):
+                if k < len(self.ramp):                          # its own buffer, outside the rotation
+                    t0 = clock()
+                    if self.ramp_bufs[k] is None:
+                        self.ramp_bufs[k] = _host_buffer((self.ramp[k], H, W, 3), self._torch.uint8, self.pinned)
+                    t1 = clock()
+                    self._fill(self.ramp_bufs[k], lo, hi)
+                    st['alloc'] += t1 - t0
+                    st['fill'] += clock() - t1
+                    self.ready.put((lo, hi - lo, -1 - k, None))
                     continue
+                t0 = clock()
                 b = self.free.get()
                 if b is None:
                     return
+                t1 = clock()
                 if self.bufs[b] is None:
                     self.bufs[b] = _host_buffer((self.chunk, H, W, 3), self._torch.uint8, self.pinned)
+                t2 = clock()
                 self._fill(self.bufs[b], lo, hi)
+                st['free_wait'] += t1 - t0
+                st['alloc'] += t2 - t1
+                st['fill'] += clock() - t2
                 self.ready.put((lo, hi - lo, b, None))
             self.ready.put((None, 0, None, None))
         except BaseException as e:   # hand decode errors to the consumer thread
@@ -151,7 +214,7 @@ class ChunkLoader(object):
                 if lo is None:
                     return
                 if b < 0:
-                    yield lo, self.first_buf[:n]
+                    yield lo, self.ramp_bufs[-1 - b][:n]
                     continue
                 # recycle the buffer handed out depth-1 chunks ago
                 self._held.append(b)
@@ -198,7 +261,23 @@ class StreamedSequence(object):
         eng = self.eng
         main = torch.cuda.current_stream(eng.device)
         pending = []     # [(first_index, n, slot)] whose downloads are in flight, oldest first
-        for k, (lo, host) in enumerate(chunks):
+        # where the consumer thread's wall time goes (seconds): waiting for the loader's next chunk, enqueueing a chunk's work,
+        # waiting for a chunk's records; `consumer` (the caller's time between two yields) is the rest of the wall time
+        st = self.stats = {'loader_wait': 0.0, 'enqueue': 0.0, 'records_wait': 0.0, 'chunks': 0, 'loader_wait_first': 0.0}
+        it = iter(chunks)
+        k = -1
+        while True:
+            t0 = time.perf_counter()
+            try:
+                lo, host = next(it)
+            except StopIteration:
+                break
+            k += 1
+            t1 = time.perf_counter()
+            st['loader_wait'] += t1 - t0
+            if k == 0:
+                st['loader_wait_first'] = t1 - t0
+            st['chunks'] += 1
             n = int(host.shape[0])
             if n > self.chunk:
                 raise ValueError('chunk of %d frames exceeds %d' % (n, self.chunk))
@@ -223,11 +302,16 @@ class StreamedSequence(object):
                 self.ev_down[b] = torch.cuda.Event()
                 self.ev_down[b].record(self.down)
             pending.append((lo, n, b))
+            t2 = time.perf_counter()
+            st['enqueue'] += t2 - t1
             if len(pending) >= self.depth:                   # the slot chunk k+1 will take must be handed out first
                 plo, pn, pb = pending.pop(0)
                 self.ev_down[pb].synchronize()
+                st['records_wait'] += time.perf_counter() - t2
                 yield plo, self.host_rec[pb][:pn].numpy()
         while pending:
             plo, pn, pb = pending.pop(0)
+            t2 = time.perf_counter()
             self.ev_down[pb].synchronize()
+            st['records_wait'] += time.perf_counter() - t2
             yield plo, self.host_rec[pb][:pn].numpy()

@@ -137,3 +137,21 @@ def test_chunk_loader_short_first_chunk(tmp_path):
     assert [g[0] for g in got] == [0, 2, 6, 10] and [g[1].shape[0] for g in got] == [2, 4, 4, 1]
     assert np.array_equal(np.concatenate([g[1] for g in got]), frames)
     assert ChunkLoader(frames, (6, 8), chunk=4, pinned=False, first_chunk=9).bounds()[0] == (0, 4)     # never longer than a chunk
+
+
+def test_chunk_loader_ramp(tmp_path):
+    """first_chunk as a sequence = a ramp of short chunks (own buffers, outside the rotation) in front of the full ones; every
+    chunk handed out stays intact while later chunks are produced; a sequence shorter than the ramp just ends inside it."""
+    from kfnet_amd.pipeline import ChunkLoader
+    frames, paths = _png_sequence(tmp_path, 23)
+    loader = ChunkLoader(paths, (6, 8), chunk=8, workers=3, pinned=False, first_chunk=(2, 4, 8, 9), depth=2)
+    assert loader.ramp == [2, 4]                       # entries >= chunk are not a ramp
+    assert loader.bounds() == [(0, 2), (2, 6), (6, 14), (14, 22), (22, 23)]
+    views = [(lo, host) for lo, host in loader]        # (no copies: the ramp chunks must still hold their frames at the end)
+    assert np.array_equal(views[0][1].numpy(), frames[0:2]) and np.array_equal(views[1][1].numpy(), frames[2:6])
+    assert np.array_equal(views[-1][1].numpy(), frames[22:23])
+    got = [(lo, host.numpy().copy()) for lo, host in ChunkLoader(frames, (6, 8), chunk=8, pinned=False, first_chunk=[3, 5])]
+    assert [g[0] for g in got] == [0, 3, 8, 16] and np.array_equal(np.concatenate([g[1] for g in got]), frames)
+    short = ChunkLoader(frames[:4], (6, 8), chunk=8, pinned=False, first_chunk=(3, 5))
+    assert short.bounds() == [(0, 3), (3, 4)]
+    assert np.array_equal(np.concatenate([h.numpy().copy() for _, h in short]), frames[:4])

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 OBJS=$(ls kfnet_amd/csrc/build/*.o | grep -v kfn_conv64.o)
 for v in ${C64_PADS--1 0 1}; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DKFN_STORE_PAD=$v -c kfnet_amd/csrc/kfn_conv64.hip -o /tmp/kfn_conv64_pad$v.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_pad$v.so /tmp/kfn_conv64_pad$v.o $OBJS ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_pad$v.so /tmp/kfn_conv64_pad$v.o $OBJS -lz ) &
 done
 wait
 ls -la tools/mb/libkfnet_pad*.so

@@ -6,11 +6,11 @@ cd "$(dirname "$0")/../.."
 OBJS=$(ls kfnet_amd/csrc/build/*.o | grep -v kfn_wino4.o)
 for v in ${W4_VARIANTS-1 2 4 8 15}; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DKFN_W4_DBG=$v -c kfnet_amd/csrc/kfn_wino4.hip -o /tmp/kfn_wino4_dbg$v.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_w4dbg$v.so /tmp/kfn_wino4_dbg$v.o $OBJS ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_w4dbg$v.so /tmp/kfn_wino4_dbg$v.o $OBJS -lz ) &
 done
 if [ -n "$W4_DEFS" ]; then
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $W4_DEFS -c kfnet_amd/csrc/kfn_wino4.hip -o /tmp/kfn_wino4_$W4_TAG.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_w4$W4_TAG.so /tmp/kfn_wino4_$W4_TAG.o $OBJS ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/mb/libkfnet_w4$W4_TAG.so /tmp/kfn_wino4_$W4_TAG.o $OBJS -lz ) &
 fi
 wait
 ls -la tools/mb/libkfnet_w4*.so
