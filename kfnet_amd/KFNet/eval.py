@@ -44,11 +44,15 @@ def get_transform(transform_file=None):
     return np.eye(4, dtype=np.float32)
 
 
-def load_images(paths, image_size):
-    """tf.image.decode_png(channels=3) replacement (KFNet/train.py:213-217)."""
-    from ..pipeline import decode_image
+def load_images(paths, image_size, workers=None):
+    """tf.image.decode_png(channels=3) replacement (KFNet/train.py:213-217): the library's threaded decoder
+    (kfn_decode_png_rgb8 through pipeline.decode_png_batch), PIL where the library is not built."""
+    from ..pipeline import _native_png_available, decode_image, decode_png_batch
     H, W = image_size
     out = np.empty((len(paths), H, W, 3), dtype=np.uint8)
+    if _native_png_available():
+        decode_png_batch(list(paths), out, image_size, workers or max(4, min(32, (os.cpu_count() or 8) // 2)))
+        return out
     for i, p in enumerate(paths):
         out[i] = decode_image(p, image_size)
     return out
@@ -61,7 +65,7 @@ RESET_PERIOD = 500
 
 def eval_sharded(image_paths, transform, weights, output_folder, rank, world, link, nis=False,
                  image_size=(480, 640), batch=4, frames=None, sequence_length=RESET_PERIOD, verbose=True,
-                 device=None, decode_workers=8):
+                 device=None, decode_workers=None):
     """Frame-sharded prediction (BASELINE config 4): this rank owns the contiguous chunk
     `chunk_bounds(T, world, rank)`, runs the state-independent heavy phase for it at once,
     receives the [h,w,4] Kalman state from rank-1 (unless its chunk starts on a reset
@@ -80,7 +84,7 @@ def eval_sharded(image_paths, transform, weights, output_folder, rank, world, li
     if frames is not None:
         host = np.ascontiguousarray(frames[lo - need_prev:hi])
     else:
-        host = load_images(image_paths[lo - need_prev:hi], image_size)
+        host = load_images(image_paths[lo - need_prev:hi], image_size, decode_workers)
     dev_all = eng.upload_frames(host) if host.shape[0] else torch.empty((0, eng.H, eng.W, 3), dtype=torch.uint8, device=dev)
     rec = run_chunk(eng, dev_all[need_prev:], lo, rank, world, link, dev_all[0] if need_prev else None)
     rec = rec.cpu().numpy().copy()
@@ -127,7 +131,7 @@ def eval_sharded_cyclic(image_paths, transform, weights, output_folder, rank, wo
 
 def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(480, 640), batch=4,
          frames=None, sequence_length=RESET_PERIOD, chunk=256, verbose=True, label_paths=None, labels=None,
-         decode_workers=8, device=None, metrics_sequence_length=1000, engine=None, save_workers=2, stats=None, ramp=None):
+         decode_workers=None, device=None, metrics_sequence_length=1000, engine=None, save_workers=2, stats=None, ramp=None):
     """Runs the sequence and writes coord_<i>.npy files; returns the [T,h,w,4] records.
     With label maps (label_list.txt, or `labels` [T,H,W,4] in memory) the reference's per-frame
     log line and final median/mean/std summary are printed (KFNet/eval.py:113-118,162-164);
@@ -187,6 +191,8 @@ def eval(image_paths, transform, weights, output_folder, nis=False, image_size=(
     # its results, so it keeps 2.  The loader rotates one host buffer more than that: a buffer is recycled only after the
     # records of the chunk that was uploaded from it have been handed out, i.e. its upload is complete.
     in_flight = 2 if want_metrics else 3
+    if not decode_workers:      # decode threads of the library (kfn_decode_png_rgb8): a chunk's files side by side
+        decode_workers = max(4, min(32, (os.cpu_count() or 8) // 2))
     loader = ChunkLoader(frames if frames is not None else list(image_paths), image_size, chunk,
                          workers=decode_workers, first_chunk=[r for r in ((8, 16) if ramp is None else ramp) if r < chunk],
                          depth=in_flight + 1)
