@@ -55,7 +55,7 @@ int kfn_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch
  * hardware's) straight into the caller's staging buffer (page-locked or not).  Host code only -- no device access, no GIL.
  * Non-interlaced files of bit depth <= 8, colour types gray / RGB / palette / gray+alpha / RGBA (alpha dropped, gray
  * replicated: what decode_png(channels=3) and PIL's convert('RGB') return).  status [n] (may be NULL) receives one of the
- * KFN_PNG_* codes per file: an interlaced or 16-bit file is KFN_PNG_UNSUPPORTED -- its frame in dst is left untouched and
+ * KFN_PNG_* codes per file: an interlaced or 16-bit file (or one without the PNG signature) is KFN_PNG_UNSUPPORTED -- its frame in dst is left untouched and
  * the call still succeeds (kfnet_amd.pipeline decodes those with PIL); a missing, corrupt or wrong-sized file is
  * KFN_PNG_ERROR and the call returns KFN_ERR_ARG with kfn_last_error() naming the first such file. */
 #define KFN_PNG_OK 0

@@ -10,8 +10,8 @@
 //
 // Scope: what the reference's data holds and PIL's writer produces -- non-interlaced PNGs of bit depth <= 8, colour types
 // 0 (gray), 2 (RGB), 3 (palette), 4 (gray + alpha), 6 (RGBA); alpha is dropped and gray replicated, as decode_png(channels=3)
-// / PIL's convert('RGB') do.  Interlaced or 16-bit files are reported per file as KFN_PNG_UNSUPPORTED and the host decodes
-// those with PIL; a corrupt or wrong-sized file is an error that names the file.  Host code only: no device access.
+// / PIL's convert('RGB') do.  Interlaced or 16-bit files, and files without the PNG signature, are reported per file as
+// KFN_PNG_UNSUPPORTED and the host decodes those with PIL; a corrupt or wrong-sized file is an error that names the file.  Host code only: no device access.
 #include "kfn_common.h"
 
 #include <zlib.h>
@@ -77,7 +77,8 @@ PngResult decode_one(const char* path, int H, int W, unsigned char* dst) {
     if (got != (size_t)sz) return {KFN_PNG_ERROR, std::string("short read of ") + path};
   }
   static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-  if (std::memcmp(file.data(), sig, 8) != 0) return {KFN_PNG_ERROR, std::string(path) + " is not a PNG file (signature)"};
+  // (not a PNG at all -- a JPEG in the list, say: the host's general-purpose decoder decides, as it did before this file existed)
+  if (std::memcmp(file.data(), sig, 8) != 0) return {KFN_PNG_UNSUPPORTED, std::string(path) + " is not a PNG file (signature)"};
   size_t pos = 8;
   int w = 0, h = 0, depth = 0, ctype = -1, interlace = 0;
   unsigned char palette[256 * 3] = {0};      // (an index past PLTE's entries reads black, as libpng's readers do)

@@ -54,7 +54,12 @@ def decode_png_batch(paths, dst, image_size, threads):
         raise ValueError(lib.kfn_last_error().decode())
     for i in range(n):
         if status[i] == _lib.PNG_UNSUPPORTED:
-            dst[i] = decode_image(paths[i], image_size)
+            try:
+                dst[i] = decode_image(paths[i], image_size)
+            except ValueError:
+                raise
+            except Exception as e:      # PIL's own error types (UnidentifiedImageError, OSError, ...): one type for the caller
+                raise ValueError('%s: %s' % (paths[i], e))
 
 
 def _native_png_available():

@@ -145,7 +145,7 @@ def test_sixteen_bit_files_go_back_to_pil_and_errors_name_the_file(tmp_path):
     cut = tmp_path / 'cut.png'
     cut.write_bytes(ok.read_bytes()[:-40])
     junk = tmp_path / 'junk.png'
-    junk.write_bytes(b'not a png at all' * 8)
+    junk.write_bytes(b'not a png at all' * 8)           # (no PNG signature: handed to PIL, whose error is re-raised as ValueError)
     for bad in (small, cut, junk, tmp_path / 'missing.png'):
         with pytest.raises(ValueError) as e:
             _native([ok, bad])
@@ -153,6 +153,10 @@ def test_sixteen_bit_files_go_back_to_pil_and_errors_name_the_file(tmp_path):
     with pytest.raises(ValueError) as e:
         _native([small])
     assert '%dx%d' % (H - 1, W) in str(e.value) and 'expected %dx%d' % (H, W) in str(e.value)       # decode_image's message
+    # a file that is not a PNG but that PIL reads (the reference's lists hold PNGs; nothing forbids a JPEG) is decoded, not refused
+    jpg = tmp_path / 'photo.jpg'
+    Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)).save(jpg, quality=95)
+    assert np.array_equal(_native([ok, jpg]), _pil([ok, jpg]))
     st3 = (C.c_int * 3)()
     arr3 = (C.c_char_p * 3)(*[os.fsencode(str(p)) for p in (ok, cut, ok)])
     dst3 = np.zeros((3, H, W, 3), np.uint8)
