@@ -191,3 +191,47 @@ def test_chunk_loader_is_the_same_on_both_decoders(tmp_path):
         return decode_image(path, size)
     out = [h.numpy().copy() for _, h in ChunkLoader(paths, (48, 64), chunk=4, workers=2, pinned=False, decode=dec)]
     assert sorted(calls) == sorted(paths) and np.array_equal(np.concatenate(out), frames)
+
+
+def test_mutated_files_never_crash_the_library(tmp_path):
+    """600 byte-level mutations of valid files (overwritten / deleted / inserted bytes, header and chunk-length fields among
+    them) through ONE call on several threads: every file comes back OK, UNSUPPORTED or ERROR -- native code that parses
+    files must not fall over them -- and an OK frame of an untouched seed equals PIL's."""
+    from PIL import Image
+    from kfnet_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    seeds = []
+    for mode, ch in (('RGB', 3), ('RGBA', 4), ('L', 1), ('LA', 2)):
+        a = rng.integers(0, 256, size=(H, W, ch), dtype=np.uint8)
+        p = tmp_path / ('seed_%s.png' % mode)
+        Image.fromarray(a[..., 0] if ch == 1 else a, mode).save(p)
+        seeds.append(p.read_bytes())
+    p = tmp_path / 'seed_P.png'
+    Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)).quantize(colors=7).save(p)
+    seeds.append(p.read_bytes())
+    paths = [str(tmp_path / 'seed_RGB.png')]
+    for i in range(600):
+        b = bytearray(seeds[i % len(seeds)])
+        for _ in range(int(rng.integers(1, 6))):
+            op, pos = int(rng.integers(0, 4)), int(rng.integers(8, len(b)))
+            if op == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif op == 1:
+                del b[pos:pos + int(rng.integers(1, 20))]
+            elif op == 2:
+                b[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 20)), dtype=np.uint8))
+            else:
+                b[int(rng.integers(8, min(len(b), 40)))] = int(rng.integers(0, 256))       # IHDR fields / first chunk lengths
+        q = tmp_path / ('m%04d.png' % i)
+        q.write_bytes(bytes(b))
+        paths.append(str(q))
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(q) for q in paths])
+    st = (C.c_int * n)()
+    dst = np.zeros((n, H, W, 3), np.uint8)
+    rc = lib.kfn_decode_png_rgb8(arr, n, H, W, dst.ctypes.data, st, 4)
+    assert rc in (0, -1) and set(st) <= {_lib.PNG_OK, _lib.PNG_UNSUPPORTED, _lib.PNG_ERROR}
+    assert st[0] == _lib.PNG_OK and np.array_equal(dst[0], decode_image(paths[0], (H, W)))
+    assert list(st).count(_lib.PNG_ERROR) > 400          # most mutations are caught (bad inflate / sizes / chunks)
