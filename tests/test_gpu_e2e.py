@@ -454,6 +454,39 @@ def test_config5_batch_independence_at_full_size():
         assert np.array_equal(alone[0], both[s]), 'sequence %d depends on its batch neighbours' % s
 
 
+@pytest.mark.parametrize('cfg', [('f32', (480, 640), 8), ('f16', (540, 960), 4)])
+def test_records_are_reproducible_under_memory_load(cfg):
+    """The whole path, fp32 (config 3's geometry) and fp16 (config 5's), run again and again while another stream keeps the
+    memory system busy: every pass bit-identical to an unloaded one.  (What round 5's store hazard broke for config 5 --
+    DESIGN 3.1j -- checked end to end: two towers on two streams plus the copy stream, all kernels of the step.)"""
+    import torch
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    operands, size, frames = cfg
+    W = synthetic_weights(1234)
+    dev = torch.from_numpy(synthetic_sequence(frames, size[0], size[1], seed=5)).cuda()
+    eng = KFNetEngine(W, image_size=size, batch=min(frames, 4), transform=np.eye(4, dtype=np.float32), reset_period=500,
+                      max_chunk=frames, conv_operands=operands)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(64 << 20, device='cuda')
+    big_b = torch.empty_like(big_a)
+
+    def run(load):
+        torch.cuda.synchronize()      # (t0 = 0 is a reset frame: a pass does not depend on the state the previous one left)
+        if load:
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    big_b.copy_(big_a)
+        rec = eng.process(dev, t0=0).clone()
+        torch.cuda.synchronize()
+        return rec
+
+    ref = run(False)
+    bad = [r for r in range(12) if not torch.equal(run(True), ref)]
+    assert not bad, 'passes %s differ from the unloaded one' % bad
+
+
 @pytest.mark.parametrize('size,batch', [((64, 96), 2), ((480, 640), 3)])
 def test_f16x3_split_mode_meets_fp32_tolerance(size, batch):
     """conv_operands='f16x3' (operands split into hi+lo halfs, 3 fp16 MFMA products, fp32
