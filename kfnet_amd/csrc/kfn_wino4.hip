@@ -802,6 +802,42 @@ __device__ __forceinline__ void bt_d_b6p(f32x2 (&pp)[18], const BtConstP& k) {
 #define KFN_PP_IN(pp, r, c) (pp)[3 * (c) + (r) / 2][(r) & 1]
 #define KFN_PP_OUT(pp, xi, nu) (pp)[3 * (nu) + ((xi) == 0 || (xi) == 5 ? 0 : ((xi) == 1 || (xi) == 3 ? 1 : 2))][((xi) == 5 || (xi) == 3 || (xi) == 4) ? 1 : 0]
 
+// KFN_W4B_PAIR (round 5, experiment): TWO channels and HALF the patch rows per producer lane.  Lane = (row half rh, tile row
+// of 4, channel pair of 8): a lane loads rows 3 rh .. 3 rh + 2 of its tile's patch for two adjacent channels -- 18 loads of 8
+// bytes instead of 36 of 4 (8 lanes on 64 contiguous bytes of a pixel; an instruction touches 4 tiles x 2 rows) --, runs the
+// pass along c on its three rows (packed over the channel pair), trades columns with its partner lane (lane ^ 32, the other
+// row half of the same tile and pair) through 18 v_permlane32_swap -- lower lanes end with all six rows of columns 0..2, upper
+// lanes of columns 3..5 --, runs the pass along r on its three columns and stores 18 positions x 8 bytes (the pair = the two
+// k-steps of one k: adjacent floats of V).  Per wave and super-step: 18 + 18 vector-memory instructions instead of 36 + 18, 18
+// ds_write_b64 instead of 36 ds_write_b32, 72 v_pk + 18 swaps.  Same products and sums as bt_d_b6s, in its order.
+// MEASURED (profiles/r05_wino4b_pair_ab.log, batch 32, same box, two runs): correct on the first run (all F(4x4) and border
+// tests) and 3-4 % SLOWER on every layer (conv4b 5.80 -> 6.00 ms, conv2b 6.41 -> 6.65): a third fewer vector-memory INSTRUCTIONS
+// buy nothing when each of them still touches eight separate 64-byte half-lines -- what the gather costs is L1 line
+// transactions (4 per old instruction, 8 per new one: the same 144 per wave and super-step), not instruction issue.  OFF.
+#ifndef KFN_W4B_PAIR
+#define KFN_W4B_PAIR 0
+#endif
+constexpr int P_NG = KFN_W4B_PAIR ? 18 : 36;      // producer: loads / V stores per lane and super-step
+constexpr int P_NS = KFN_W4B_PAIR ? 18 : 36;
+__device__ __forceinline__ void bt_d_b6q(f32x2 (&q)[3][6], const BtConst& k) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) bt6(q[r][0], q[r][1], q[r][2], q[r][3], q[r][4], q[r][5], k);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {       // upper half of q[r][j] <-> lower half of q[r][j + 3]
+      // (scalars first: this clang's __builtin_bit_cast of a vector ELEMENT -- v.y, v[1] -- reads element 0)
+      const float ax = q[r][j].x, ay = q[r][j].y, bx = q[r][j + 3].x, by = q[r][j + 3].y;
+      const auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ax), __builtin_bit_cast(unsigned, bx), false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ay), __builtin_bit_cast(unsigned, by), false, false);
+      const unsigned x0 = sx[0], x1 = sx[1], y0 = sy[0], y1 = sy[1];
+      q[r][j] = f32x2{__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)};
+      q[r][j + 3] = f32x2{__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+    }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bt6(q[0][j], q[1][j], q[2][j], q[0][j + 3], q[1][j + 3], q[2][j + 3], k);
+}
+
 __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];   // [4][B_VBUF] floats, later the output image
   float* const smf = reinterpret_cast<float*>(smem4);
@@ -832,9 +868,16 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   // ---- PRODUCER: tile (row ptr = 4 (wave >> 2) + (lane >> 4), column tc = wave & 3), channel c16 = lane & 15 of the super-step's
   // 16 (chunk pch = c16 >> 3): 16 lanes read 64 contiguous bytes of a pixel, a load instruction touches four rows (the 8-channel
   // x 8-row form touched eight 32-byte pieces: twice the L1 transactions of the four-wave kernel) ---------
+#if KFN_W4B_PAIR
+  const int rh = lane >> 5, cp = lane & 7;
+  const int pch = cp >> 2, kq = cp & 3;          // the pair's chunk of the super-step and its k (channels 2 cp, 2 cp + 1 = k-steps 0, 1)
+  const int tc = wave & 3, ptr = 4 * (wave >> 2) + ((lane >> 3) & 3);
+  unsigned roff[3];                              // patch rows 3 rh + 0 .. 2
+#else
   const int c16 = lane & 15, c8 = c16 & 7, pch = c16 >> 3;
   const int tc = wave & 3, ptr = 4 * (wave >> 2) + (lane >> 4);
   unsigned roff[6];
+#endif
   unsigned coff[6];
   bool cok[6];
   {
@@ -842,12 +885,21 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const int ty = ptr < brk ? ty0 + ptr : ptr - brk;
     const int tx = cb * BW4 + tc;
     const bool row_tile_ok = (vr0 + ptr < p.vrows);
+#if KFN_W4B_PAIR
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = 4 * ty - 1 + 3 * rh + r;
+      roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
+                    ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(cp * 8) : ROW_POISON;
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int yy = 4 * ty - 1 + r;
       roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
                     ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(c16 * 4) : ROW_POISON;
     }
+#endif
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int xx = 4 * tx - 1 + c;
@@ -858,7 +910,12 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   const int x_records = (int)(a_rest < two_img ? a_rest : two_img);
   // V store address (floats) inside a super-step's buffer pair: chunk pch, k = c8 >> 1, k-step = c8 & 1, tile t = 4 ptr + tc
   const int pt = 4 * ptr + tc;
+#if KFN_W4B_PAIR
+  // (both k-steps of k = kq in one 8-byte store; this lane's positions are nu = j + 3 rh: the row half picks the column half)
+  const int v_st = pch * B_VBUF + kq * 64 + (((pt & 15) ^ kq) * 4) + (pt >> 4) * 2 + 3 * rh * B_VPOS;
+#else
   const int v_st = pch * B_VBUF + (c8 >> 1) * 64 + (((pt & 15) ^ (c8 >> 1)) * 4) + (pt >> 4) * 2 + (c8 & 1);
+#endif
   const int n_chunks = p.Cin / 8;
   const int ks0 = split * p.ss_per_split;                                   // first super-step of this split (0 without split-K)
   const int n_super = p.k_split > 1 ? ((n_chunks / CPS - ks0) < p.ss_per_split ? (n_chunks / CPS - ks0) : p.ss_per_split)
@@ -881,6 +938,10 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
 #pragma unroll
     for (int th = 0; th < 2; ++th) acc[l][th] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if KFN_W4B_PAIR
+  f32x2 pq[3][6];
+  static_assert(KFN_W4B_PACKED && !KFN_W4B_STAGGER, "the pair producer shares the packed constants; no staggered schedule");
+#endif
 #if KFN_W4B_PACKED
   f32x2 pp[18];
   const BtConstP kp = {{{4.f, 4.f}, {-4.f, -4.f}, {-5.f, -5.f}, {2.f, 2.f}, {-2.f, -2.f}}, {-4.f, -1.f}, {1.f, 2.f}, {-1.f, -2.f}};
@@ -897,16 +958,23 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const int sc = ss < s_last ? ss : s_last;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
+#if KFN_W4B_PAIR
+    pq[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
+#else
     const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
 #if KFN_W4B_PACKED
     KFN_PP_IN(pp, r, c) = v;
 #else
     pv[i] = v;
 #endif
+#endif
   };
   auto p_store = [&](auto gc, int ss) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
-#if KFN_W4B_PACKED
+#if KFN_W4B_PAIR
+    constexpr int xi = g / 3, j = g % 3;      // position (xi, nu = j + 3 rh): xi < 3 sits in pq[xi][j], the others in pq[xi - 3][j + 3]
+    *reinterpret_cast<f32x2*>(smf + (ss & 1) * (CPS * B_VBUF) + v_st + (6 * xi + j) * B_VPOS) = xi < 3 ? pq[xi % 3][j] : pq[xi % 3][j + 3];
+#elif KFN_W4B_PACKED
     smf[(ss & 1) * (CPS * B_VBUF) + v_st + g * B_VPOS] = KFN_PP_OUT(pp, g / 6, g % 6);
 #else
     smf[(ss & 1) * (CPS * B_VBUF) + v_st + g * B_VPOS] = pv[g];
@@ -924,14 +992,16 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   };
 
   // ---- prologue ----------------------------------------------------------------------------------------------------
-  sfor4<36>([&](auto ic) { p_gather(ic, 0); });
+  sfor4<P_NG>([&](auto ic) { p_gather(ic, 0); });
   sfor4<NBB>([&](auto sc) { b_load(sc, 0, decltype(sc)::value); });
-#if KFN_W4B_PACKED
+#if KFN_W4B_PAIR
+  bt_d_b6q(pq, kp.k);
+#elif KFN_W4B_PACKED
   bt_d_b6p(pp, kp);
 #else
   bt_d_b6s(pv);
 #endif
-  sfor4<36>([&](auto gc) { p_store(gc, 0); });
+  sfor4<P_NS>([&](auto gc) { p_store(gc, 0); });
   // The two waves of a SIMD (w and w + 4) do their producer work in different HALVES of a super-step (KFN_W4B_STAGGER): in
   // lockstep both would stand in the same transform burst / load group at the same time and the MFMA pipe would idle
   // (timing builds: the transform alone cost 9.5 % that way).  Waves 0-3 gather, transform and store in slots 0..71, waves
@@ -977,10 +1047,10 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
           else if constexpr (cc < CPS - 1) v_read(std::integral_constant<int, sv>{}, ch + 1, l + NVB - WPOS);
         }
         constexpr int sj = cc * SPC + j;
-        if constexpr (!(KFN_W4B_DBG & 2) && sj >= G0 && (sj - G0) % GST == 0 && (sj - G0) / GST * GPS < 36) {
+        if constexpr (!(KFN_W4B_DBG & 2) && sj >= G0 && (sj - G0) % GST == 0 && (sj - G0) / GST * GPS < P_NG) {
           sfor4<GPS>([&](auto uc) {
             constexpr int gi = (sj - G0) / GST * GPS + decltype(uc)::value;
-            if constexpr (gi < 36) p_gather(std::integral_constant<int, gi>{}, ks + 1);
+            if constexpr (gi < P_NG) p_gather(std::integral_constant<int, gi>{}, ks + 1);
           });
         }
 #if !KFN_W4B_PACKED
@@ -1005,15 +1075,17 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
         } else
 #endif
         {
-#if KFN_W4B_PACKED
+#if KFN_W4B_PAIR
+          if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6q(pq, kp.k);
+#elif KFN_W4B_PACKED
           if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6p(pp, kp);
 #else
           if constexpr (!(KFN_W4B_DBG & 1) && sj == XS) bt_d_b6s(pv);
 #endif
-          if constexpr (!(KFN_W4B_DBG & 4) && sj >= S0 && (sj - S0) * SPS < 36) {
+          if constexpr (!(KFN_W4B_DBG & 4) && sj >= S0 && (sj - S0) * SPS < P_NS) {
             sfor4<SPS>([&](auto uc) {
               constexpr int gi = (sj - S0) * SPS + decltype(uc)::value;
-              if constexpr (gi < 36) p_store(std::integral_constant<int, gi>{}, ks + 1);
+              if constexpr (gi < P_NS) p_store(std::integral_constant<int, gi>{}, ks + 1);
             });
           }
         }
