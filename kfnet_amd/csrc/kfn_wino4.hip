@@ -817,6 +817,12 @@ __device__ __forceinline__ void bt_d_b6p(f32x2 (&pp)[18], const BtConstP& k) {
 #ifndef KFN_W4B_PAIR
 #define KFN_W4B_PAIR 0
 #endif
+// cache-policy bits of the patch loads (buffer instruction aux: 1 = sc0, 2 = nt, 3 = both): A/B only.  MEASURED
+// (profiles/r05_wino4b_patch_aux_ab.log): sc0 = the same time, nt (alone or with sc0) 17-25 % SLOWER -- the patches of neighbouring
+// tiles overlap (6x6 on a 4x4 pitch) and the four tile rows of a wave follow each other: those re-reads are L1 hits that nt gives up.
+#ifndef KFN_W4B_PATCH_AUX
+#define KFN_W4B_PATCH_AUX 0
+#endif
 constexpr int P_NG = KFN_W4B_PAIR ? 18 : 36;      // producer: loads / V stores per lane and super-step
 constexpr int P_NS = KFN_W4B_PAIR ? 18 : 36;
 __device__ __forceinline__ void bt_d_b6q(f32x2 (&q)[3][6], const BtConst& k) {
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
 #if KFN_W4B_PAIR
     pq[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
 #else
-    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), KFN_W4B_PATCH_AUX));
 #if KFN_W4B_PACKED
     KFN_PP_IN(pp, r, c) = v;
 #else
