@@ -1,33 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- frames/sec of the MI355X-native KFNet prediction path.
+"""bench.py -- frames/sec of the MI355X-native KFNet prediction path (the headline pass + the driver's line).
 
-A "step" is ONE 480x640 frame through the whole hot path (SCoordNet + flow-feature tower
-+ cost volume + OFlowNet + flow head + warp/Kalman fuse/emit).  Workload = BASELINE.json
-configs[2]: full KFNet on a synthetic 480x640 sequence, random weights, fp32.  The timed
-region starts with the uint8 frames already resident in HBM and ends when the [K,60,80,4]
-records are in HBM.
+A "step" is ONE 480x640 frame through the whole hot path (SCoordNet + flow-feature tower + cost volume + OFlowNet +
+flow head + warp / Kalman fuse / emit).  Workload = BASELINE.json configs[2]: full KFNet on a synthetic 480x640
+sequence, random weights, fp32.  The timed region starts with the uint8 frames already resident in HBM and ends when
+the [K,60,80,4] records are in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the N*K-frame sequence is
-sharded into contiguous K-frame chunks (weak scaling).  Every rank runs the
-state-independent heavy phase for its chunk at once; the recurrent Kalman state (76.8 KB)
-is handed rank r -> r+1 with RCCL send/recv just before the rank's scan launch.
+N > 1 (one rank per GPU under torch.distributed.run; `python bench.py --gpus N` starts the ranks itself): the N*K-frame
+sequence is sharded into contiguous K-frame chunks (weak scaling); every rank runs the state-independent heavy phase
+of its chunk at once, the recurrent Kalman state (76.8 KB) goes rank r -> r+1 by RCCL send/recv before the scan.
 
-Timing: W untimed warm-up steps, then the K-step pass is REPEATED until at least
---min-seconds (2 s) have been timed; every repetition is exactly K steps bracketed by a
-barrier + torch.cuda.synchronize() on both sides, timed per rank, MAX over ranks; the line
-reports the MEDIAN repetition (`ms_per_step`, `value`), the repetition count and the spread.
+Timing: W untimed warm-up steps, then the K-step pass is repeated until --min-seconds are timed; every repetition is
+exactly K steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks; the line reports the
+MEDIAN repetition.
 
-One JSON line on rank 0; extra objects: roofline (the dominant kernel instantiation of the step -- round 4: wino4b_kernel,
-Winograd F(4x4,3x3) on the fp32 MFMA), roofline_kalman (batched persistent scan, HBM; at T = 64 and T = 256),
-cpu_baseline (reference-faithful torch-CPU restatement timed on a bounded sample, N=1 only).
-
-On one GPU the default (`c3`, BASELINE configs[2]: the headline the driver records) line ALSO carries, each in its own
-block: config3_256_frames (the literal 256-frame pass), host_streamed = value_streamed (SURVEY 8(d)'s definition: H2D of
-the frames and D2H of the records inside the timed region), eval_png_end_to_end (PNG files -> coord_<i>.npy files through
-kfnet_amd.KFNet.eval), config5_960x540 (BASELINE configs[4]: value, roofline of its dominant fp16 kernel, masked parity
-against the fp32 path), config2_single_frame (configs[1], latency), and LAST a `summary` of the numbers a reader wants
-first.  Multi-rank lines carry `handoff` (the measured serial chain of scans and hand-offs) and, at 8 ranks with fewer
-than 256 steps, `config4_2048_frames` (configs[3]).  `--config c2` / `--config c5` print those configurations alone.
+OUTPUT.  The LAST stdout line is ONE compact JSON object (< 4 KB, no prose; `compact_line`): the contract fields,
+`roofline` of the step's dominant kernel (executed MFMA FLOPs / HIP-event time of its launches; `traffic` = PMC bytes
+per launch quoted from profiles/), `cpu_baseline` (the torch-CPU restatement on config 1's 16 frames), and one number
+each for the side measurements (value_streamed, parity, Kalman rooflines, config 5, config 2, multi-rank extras).
+Everything else -- per-kernel tables, telemetry, notes -- goes to the sidecar file gpurun_out/bench_detail.json
+(`--detail PATH`; bench_extra.py holds the code of those blocks).  `--config c2` / `--config c5` print those
+configurations alone.
 """
 import argparse
 import json
@@ -41,23 +34,125 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s achievable)
-C5_DELTA_PX = 0.05            # config 5's tolerance is stated >= this far from the sampler's steps (tools/parity.py)
-PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA (measured 2495)
+from bench_extra import (PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS, Telemetry, auto_batch, bench_c2, bench_c5,  # noqa: E402,F401
+                         chain_timing, config3_literal, config4_literal, cyclic_sharding_block, host_streamed,
+                         kalman_fuse_roofline, kalman_roofline, latest_pmc_traffic, measure_c2, measure_c5,
+                         per_kernel_profile, pipeline_io_bytes, timed_repetitions)
+
+COMPACT_LIMIT = 4096     # bytes; the driver reads a bounded tail of stdout (BENCH_r05: a 21 KB line was not parsed)
 
 
-def latest_pmc_traffic(suffix='pmc_traffic'):
-    """(path, dict) of the newest per-round PMC summary profiles/rNN_<suffix>.json (written by
-    tools/profile_round.sh from separate rocprofv3 --pmc passes), or (None, {})."""
-    import glob
-    import re
-    cands = [p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % suffix))
-             if re.match(r'r\d\d_%s\.json$' % suffix, os.path.basename(p))]
-    if not cands:
-        return None, {}
-    path = max(cands)
-    return path, json.load(open(path))
+def _pick(d, *ks):
+    return None if not isinstance(d, dict) else {k: d.get(k) for k in ks if d.get(k) is not None}
+
+
+def _short(s, n=160):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + '...'
+
+
+def compact_line(out):
+    """The driver's line from the full result dict: contract fields + roofline + cpu_baseline + one number per side
+    measurement.  Strict JSON, under COMPACT_LIMIT bytes whatever the detail holds (tests/test_host_logic.py)."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data')
+    line = {k: out.get(k) for k in keep}
+    line['dtype'] = _short(line['dtype'], 48)
+    line['data'] = _short(line['data'], 96)
+    cfg = out.get('config') or {}
+    line['config'] = {k: (_short(v) if isinstance(v, str) else v) for k, v in cfg.items()}
+    for k in ('repetitions', 'timed_seconds', 'state_link', 'dist_backend', 'rccl_ranks', 'sharding', 'watchdog_fired'):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    rf = out.get('roofline')
+    if rf is not None:
+        r = _pick(rf, 'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'launches_per_batch',
+                  'executed_gflop_per_launch_avg', 'share_of_step_time')
+        t = rf.get('traffic')
+        r['traffic'] = None if not t else {'fetch': t.get('fetch_bytes_per_launch'), 'write': t.get('write_bytes_per_launch'),
+                                           'hbm': t.get('hbm_bytes_per_launch'), 'algorithmic': t.get('algorithmic_bytes_per_launch'),
+                                           'from': t.get('quoted_from'), 'tower_batch': (t.get('sampled') or {}).get('tower_batch')}
+        line['roofline'] = r
+    cb = out.get('cpu_baseline')
+    if cb is not None:
+        c = _pick(cb, 'value', 'unit', 'cores', 'kind', 'deduplicated_value')
+        c['sample'] = _short(cb.get('sample', ''), 140)
+        line['cpu_baseline'] = c
+        line['speedup_vs_cpu_baseline'] = out.get('speedup_vs_cpu_baseline')
+    hs = out.get('host_streamed')
+    if hs is not None:
+        line['value_streamed'] = hs['value']
+    png = out.get('eval_png_end_to_end')
+    if png is not None:
+        line['value_png_to_npy'] = png.get('value')
+    c3 = out.get('config3_256_frames')
+    if c3 is not None:
+        line['config3_256_frames'] = _pick(c3, 'value', 'ms_per_step')
+    pc = out.get('parity_vs_cpu_restatement')
+    if pc is not None:
+        line['parity'] = _pick(pc, 'frames', 'coord_max_abs', 'conf_max_rel')
+    if 'roofline_kalman' in out:
+        line['roofline_kalman'] = {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                   'T64': out['roofline_kalman'].get('frac'),
+                                   'T256': (out.get('roofline_kalman_T256') or {}).get('frac'),
+                                   'fuse': (out.get('roofline_kalman_fuse') or {}).get('frac')}
+    c5 = out.get('config5_960x540')
+    if c5 is not None:
+        rf5 = c5.get('roofline') or {}
+        p5 = c5.get('parity_vs_fp32_path') or {}
+        line['config5'] = {'value': c5.get('value'), 'unit': c5.get('unit'), 'kernel': rf5.get('kernel'), 'frac': rf5.get('frac'),
+                           'unmasked_outside_tolerance': p5.get('unmasked_outside_tolerance')}
+    c2 = out.get('config2_single_frame')
+    if c2 is not None:
+        line['config2_ms'] = (c2.get('latency_ms') or {}).get('hipgraph_replay_median')
+    for k, ks in (('handoff', ('scan_chain_ms', 'tail_ms', 'handoff_us_net', 'error')),
+                  ('sharding_cyclic', ('value', 'block', 'tail_ms', 'error')),
+                  ('config4_2048_frames', ('value', 'ms_per_step', 'error'))):
+        if out.get(k) is not None:
+            line[k] = {a: (_short(b) if isinstance(b, str) else b) for a, b in (_pick(out[k], *ks) or {}).items()}
+    if out.get('multi_rank_extras'):
+        line['multi_rank_extras'] = _short(out['multi_rank_extras'], 80)
+    if out.get('detail_file'):
+        line['detail_file'] = out['detail_file']
+    s = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    if len(s) >= COMPACT_LIMIT:      # cannot happen with the fields above; if it ever does, drop the optional ones
+        for k in ('config4_2048_frames', 'sharding_cyclic', 'handoff', 'config3_256_frames', 'rccl_ranks', 'multi_rank_extras'):
+            line.pop(k, None)
+        s = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    assert len(s) < COMPACT_LIMIT, len(s)
+    return s
+
+
+def _json_safe(o):
+    """NaN / inf -> None, numpy scalars -> Python (the sidecar stays strict JSON too)."""
+    if isinstance(o, dict):
+        return {str(k): _json_safe(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_json_safe(v) for v in o]
+    if isinstance(o, (np.floating, float)):
+        f = float(o)
+        return f if np.isfinite(f) else None
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    return o
+
+
+def emit(out, args):
+    """Full result -> sidecar file; compact line -> the LAST line of stdout."""
+    out = _json_safe(out)
+    path = args.detail
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1, allow_nan=False)
+            f.write('\n')
+        out['detail_file'] = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError as e:
+        sys.stderr.write('bench.py: could not write %s: %s\n' % (path, e))
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def parse():
@@ -103,271 +198,28 @@ def parse():
                          'winograd_f43_eight_wave=0 (recorded in the line as graph_options)')
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='sidecar file for the full result (per-kernel tables, telemetry, notes); stdout gets the compact line')
     return ap.parse_args()
 
 
-def per_kernel_profile(eng, dev_frames):
-    """Time every launch of one heavy batch with HIP events on the launch stream.
-    Returns [(op_name, kernel_tag, flops, ms)]."""
-    import torch
-    from kfnet_amd.graph import ConvOp, WinogradConvOp
-    stream = eng._stream()
-    eng._set_batch_images(dev_frames, 0, eng.B, stream)
-    eng.graph.run(stream, eng.heavy_ops, active=(eng.B, eng.B))  # warm
-    eng.graph.active = (eng.B, eng.B)
-    torch.cuda.synchronize()
-    rows = []
-    reps = 3
-    def timed(fn):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    for op in eng.heavy_ops:
-        if isinstance(op, WinogradConvOp):
-            # two kernels: the 16 GEMMs carry the layer's algorithmic FLOPs, the output
-            # transform is a separate HBM-bound kernel
-            ms1 = timed(lambda: op.launch(eng.lib, stream, 1))
-            ms2 = timed(lambda: op.launch(eng.lib, stream, 2))
-            rows.append((op.name, op.kernel_name(eng.lib), op.flops(), ms1, op.mfma_flops()))
-            rows.append((op.name + ':out', 'wino_output_kernel', 0.0, ms2, 0.0))
-            continue
-        ms = timed(lambda: op.launch(eng.lib, stream))
-        tag = op.kernel_name(eng.lib) if hasattr(op, 'kernel_name') else op.name.split('[')[0] + '_kernel'
-        fl = op.flops() if hasattr(op, 'flops') else 0.0
-        rows.append((op.name, tag, fl, ms, op.mfma_flops() if hasattr(op, 'mfma_flops') else fl))
-    return rows
-
-
-def pipeline_io_bytes(eng):
-    """Algorithmic HBM bytes of one batch if every launch reads its input tensor(s) and weights
-    once and writes its output once (layer-by-layer execution, fp32 activations)."""
-    from kfnet_amd.graph import (ConvOp, CostVolumeConvOp, CostVolumeGatherOp, FirstConvOp, FlowHeadOp, OFlowHeadOp,
-                                 OFlowTail2Op, PadOp, WinogradConvOp)
-    def tb(t):
-        n, h, w, c = t.shape
-        return n * h * w * c * {'f32': 4, 'f16': 2, 'u8': 1}[t.dtype]
-    total = 0
-    for op in eng.heavy_ops:
-        if isinstance(op, FirstConvOp):
-            total += tb(op.img) + sum(tb(hd[1]) for hd in op.heads)
-        elif isinstance(op, CostVolumeConvOp):
-            total += 2 * tb(op.f2) + tb(op.y)
-        elif isinstance(op, CostVolumeGatherOp):
-            total += tb(op.t) + tb(op.gp) + tb(op.y)
-        elif isinstance(op, PadOp):
-            total += tb(op.x) + tb(op.y)
-        elif isinstance(op, ConvOp):
-            total += tb(op.x) + tb(op.y) + int(np.prod(op.kernel.shape)) * 4
-            if isinstance(op, WinogradConvOp):
-                total += 2 * op.workspace_bytes()   # the [16][tiles][Cout] workspace is written and re-read
-        elif isinstance(op, FlowHeadOp):
-            total += tb(op.x) + tb(op.flow)
-        elif isinstance(op, OFlowHeadOp):      # conv0 from the factored maps + conv1a: maps in, conv1a's output out
-            total += tb(op.t) + tb(op.gp) + tb(op.y)
-        elif isinstance(op, OFlowTail2Op):     # maps + conv5's patch in, flow out
-            total += tb(op.t) + tb(op.gp) + tb(op.x5) + tb(op.flow)
-    return total
-
-
-def kalman_roofline(device, S=256, T=64, H=60, W=80):
-    """Batched persistent scan: S sequences x T frames per launch,
-    76 B/px algorithmic traffic (44 read + 32 written)."""
-    import ctypes as C
-    import torch
-    from kfnet_amd import _lib
-    lib = _lib.load()
-    hw = H * W
-    g = torch.Generator(device=device).manual_seed(0)     # generated in HBM: 1.5 G values at T = 256
-    flow = torch.randn(S * T * hw * 2, generator=g, device=device) * 1.5
-    sig = torch.rand(S * T * hw, generator=g, device=device) * 0.05 + 0.001
-    meas = torch.randn(S * T * hw * 4, generator=g, device=device)
-    meas[3::4] = meas[3::4].abs() * 0.3 + 0.05
-    state = meas[:S * hw * 4].clone()
-    rec = torch.empty(S * T * hw * 4, device=device)
-    d = _lib.KalmanDesc(S=S, T=T, H=H, W=W, t0=1, reset_period=500, min_uncertainty=1e-5, nis_gate=0.0,
-                        has_transform=1)
-    for i, v in enumerate([1, 0, 0, 0.1, 0, 1, 0, 0.2, 0, 0, 1, 0.3]):
-        d.transform[i] = float(v)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def launch():
-        _lib.check(lib.kfn_kalman_scan(C.byref(d), flow.data_ptr(), sig.data_ptr(), meas.data_ptr(),
-                                       state.data_ptr(), rec.data_ptr(), None, None, None, stream), 'scan')
-    launch()
-    torch.cuda.synchronize()
-    reps = 5
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    bytes_alg = float(S) * T * hw * 76.0
-    bytes_hbm = float(S) * T * hw * 44.0 + 2.0 * S * hw * 16.0   # + state load / store-back once per launch
-    gbs = bytes_alg / (ms * 1e-3) / 1e9
-    gbs_hbm = bytes_hbm / (ms * 1e-3) / 1e9
-    traffic = None
-    tpath, tj = latest_pmc_traffic()
-    t = tj.get('kalman_scan_kernel@S=%d,T=%d' % (S, T))
-    if t:   # this exact launch shape, sampled in its own PMC passes (tools/kalman_roofline.py)
-        traffic = dict(t, quoted_from=os.path.relpath(tpath, ROOT))
-    # `achieved` / `frac` count the bytes that REALLY cross HBM (VERDICT r4 Next #1c: every frac in the line is a fraction).
-    # SURVEY 8(d)'s per-unit figure is 76 B/px (44 read incl. 16 of previous state + 32 written incl. 16 of new state); this
-    # kernel keeps the state in LDS for the whole scan, so 32 of those 76 bytes never exist as HBM traffic: 28 B/px in + 16
-    # B/px out (+ the state once per launch).  The rate by the 76 B/px definition is reported beside it under a key that
-    # is not called a fraction -- it may exceed the HBM peak, which is the point of keeping the state on chip.
-    return {'kernel': 'kalman_scan_kernel', 'bound': 'hbm', 'achieved': round(gbs_hbm, 1), 'peak': PEAK_HBM_GBS,
-            'unit': 'GB/s', 'frac': round(gbs_hbm / PEAK_HBM_GBS, 4), 'traffic': traffic,
-            'shape': 'S=%d sequences x T=%d frames x %dx%d px' % (S, T, H, W),
-            'bytes_per_launch': int(bytes_hbm),
-            'bytes_per_px_frame': '44 B crossing HBM: 28 in (flow 8, sigma_trans 4, measurement 16) + 16 out (record); the '
-                                  '[h,w,4] state is read and written ONCE per launch and lives in LDS in between',
-            'survey_8d_definition': {'bytes_per_px_frame': 76, 'bytes_per_launch': int(bytes_alg),
-                                     'rate_GBs': round(gbs, 1),
-                                     'note': '76 B/px counts the previous / new state (16 + 16 B) of every frame as traffic; '
-                                             'here those bytes stay in LDS, so this RATE is not bounded by the HBM peak and '
-                                             'is not a roofline fraction'},
-            'avg_launch_ms': round(ms, 4)}
-
-
-def kalman_fuse_roofline(device, P=256 * 64 * 4800):
-    """KFNet.BuildKFCoord alone: 48 B/px = 32 read + 16 written, all HBM."""
-    import torch
-    from kfnet_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator(device='cpu').manual_seed(1)
-    pred = torch.randn(P * 4, generator=g)
-    pred[3::4] = pred[3::4].abs() * 0.3 + 0.05
-    meas = pred.flip(0).contiguous()
-    meas[3::4] = meas[3::4].abs() * 0.3 + 0.05
-    pred, meas = pred.to(device), meas.to(device)
-    out = torch.empty(P * 4, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def launch():
-        _lib.check(lib.kfn_kalman_fuse(pred.data_ptr(), meas.data_ptr(), out.data_ptr(), None, P, stream), 'fuse')
-    launch()
-    torch.cuda.synchronize()
-    reps = 5
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    gbs = P * 48.0 / (ms * 1e-3) / 1e9
-    traffic = None
-    tpath, tj = latest_pmc_traffic()
-    t = tj.get('kalman_fuse_kernel@P=%d' % P)
-    if t:   # this exact launch, sampled in its own PMC passes (tools/kalman_roofline.py)
-        traffic = dict(t, quoted_from=os.path.relpath(tpath, ROOT))
-    return {'kernel': 'kalman_fuse_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS,
-            'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': traffic,
-            'bytes_per_launch': int(P * 48),
-            'shape': 'P=%d px, 48 B/px (BuildKFCoord only)' % P, 'avg_launch_ms': round(ms, 4)}
-
-
-def host_streamed(eng, host_frames, dev_frames, chunk=None):
-    """SURVEY 8(d)'s frames/sec definition (H2D of the uint8 frames and D2H of the records INSIDE the timed
-    region): the same frames start in pinned HOST memory and the records end there; uploads (0.92 MB/frame) and
-    downloads (76.8 KB/frame) run on their own streams beside the compute (kfnet_amd/pipeline.py)."""
-    import torch
-    from kfnet_amd.pipeline import ChunkLoader, StreamedSequence
-    K = int(host_frames.shape[0])
-    chunk = int(chunk) if chunk else max(eng.B, min(4 * eng.B, eng.max_chunk))
-    runner = StreamedSequence(eng, chunk, depth=2)      # (frames already pinned: nothing on the host can stall the queue)
-    pinned = torch.from_numpy(np.ascontiguousarray(host_frames)).pin_memory()
-    chunks = [(lo, pinned[lo:lo + chunk]) for lo in range(0, K, chunk)]
-    for _ in runner.run(chunks[:2]):       # warm the copy streams
-        pass
-    torch.cuda.synchronize()
-    dts = []
-    last = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        for lo, rec in runner.run(chunks):
-            last = (lo, rec.copy())
-        dts.append(time.perf_counter() - t0)
-    dt = float(np.median(dts))
-    ref = eng.process(dev_frames, t0=0)[last[0]:last[0] + last[1].shape[0]].cpu().numpy()
-    return {'value': round(K / dt, 3), 'unit': 'frames/s', 'frames': K, 'chunk': chunk, 'passes': len(dts),
-            'ms_per_step': round(dt * 1e3 / K, 4),
-            'bit_identical_to_resident_run': bool(np.array_equal(ref, last[1])),
-            'note': 'frames start in pinned host memory, records end in host memory; H2D (0.92 MB/frame) and D2H '
-                    '(76.8 KB/frame) on their own streams beside the compute; median of the passes'}
-
-
-def eval_png_end_to_end(eng, Wt, T4, transform_txt, host_frames, resident_records, dev_index, chunk=32, repeat=4, workers=0, ramp=None):
-    """The real-data path, timed end to end on synthetic files (VERDICT r3 Next #7): image_list.txt -> PNG decode
-    (thread pool) -> pinned staging -> HBM -> both towers + scan -> records -> coord_<i>.npy on disk, through the
-    package's own `kfnet_amd.KFNet.eval.eval` (KFNet/train.py:195-239 + KFNet/eval.py:121-126).  The PNGs are the
-    synthetic sequence's frames written to a temporary directory first (untimed); image_list.txt walks them `repeat`
-    times (a 1024-entry list: the one-off costs of a run -- page-locking the staging buffers, the first chunk's
-    decode, the last chunk's download and file writes, ~0.1 s -- are a quarter of a 256-frame run but not of a real
-    sequence of 1000-4000 frames); the first pass's records are compared with the resident run."""
-    import shutil
-    import tempfile
-    from concurrent.futures import ThreadPoolExecutor
-    from PIL import Image
-    from kfnet_amd.KFNet import eval as KE
-    from kfnet_amd.tools.io import read_lines
-    T = int(host_frames.shape[0])
-    cores = os.cpu_count() or 8
-    workers = int(workers) if workers else max(4, min(32, cores // 2))
-    root = tempfile.mkdtemp(prefix='kfn_png_')
-    try:
-        inp, outd = os.path.join(root, 'in'), os.path.join(root, 'out')
-        os.makedirs(inp)
-        os.makedirs(outd)
-        paths = [os.path.join(inp, 'frame_%05d.png' % i) for i in range(T)]
-        t_w = time.perf_counter()
-        with ThreadPoolExecutor(workers) as pool:     # (untimed set-up: random textures do not compress; level 1)
-            list(pool.map(lambda i: Image.fromarray(host_frames[i]).save(paths[i], compress_level=1), range(T)))
-        t_w = time.perf_counter() - t_w
-        with open(os.path.join(inp, 'image_list.txt'), 'w') as f:
-            f.write('\n'.join(paths * repeat) + '\n')
-        np.savetxt(os.path.join(inp, 'transform.txt'), transform_txt)   # what transform.txt holds: get_transform inverts it
-        image_paths = read_lines(os.path.join(inp, 'image_list.txt'))
-        transform = KE.get_transform(os.path.join(inp, 'transform.txt'))
-        png_mb = sum(os.path.getsize(p) for p in paths) / 1e6
-        tele = Telemetry(dev_index)
-        with tele:
-            t0 = time.perf_counter()
-            host_stats = {}
-            rec = KE.eval(image_paths, transform, Wt, outd, image_size=(eng.H, eng.W), chunk=chunk, verbose=False,
-                          decode_workers=workers, engine=eng, stats=host_stats, ramp=ramp)
-            dt = time.perf_counter() - t0
-        files = sorted(os.listdir(outd))
-        on_disk = np.stack([np.load(os.path.join(outd, 'coord_%d.npy' % i)) for i in (0, T // 2, T - 1)])
-        same = bool(np.array_equal(rec[:T], resident_records)) and bool(np.array_equal(on_disk, resident_records[[0, T // 2, T - 1]]))
-        NT = T * repeat
-        # (transform.txt went through text: it must come back as the very matrix the resident run used)
-        t_same = bool(np.array_equal(np.asarray(transform, np.float32), np.asarray(T4, np.float32)))
-        return {'value': round(NT / dt, 3), 'unit': 'frames/s', 'frames': NT, 'distinct_png_files': T, 'chunk': chunk, 'seconds': round(dt, 3),
-                'decode_threads': workers, 'host_cores': cores, 'npy_files_written': len(files),
-                'first_chunks': [r for r in ((8, 16) if ramp is None else ramp) if r < chunk],
-                'png_megabytes': round(png_mb, 1), 'png_write_seconds_untimed': round(t_w, 2),
-                'gpu_busy_pct': (tele.summary().get('busy_pct') or {}).get('mean'),
-                'bit_identical_to_resident_run': same, 'transform_roundtrip_exact': t_same,
-                # the consumer thread's wall time (seconds): waiting for decoded chunks (`loader_wait`, of which the first
-                # chunk's exposed decode `loader_wait_first`), enqueueing launches, waiting for records, copying + queueing the
-                # .npy writes (`emit`), waiting for the last writes (`saves_wait`)
-                'consumer_thread_seconds': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in host_stats.items()},
-                'note': 'image_list.txt -> PIL PNG decode on a thread pool -> pinned staging -> H2D -> towers + scan -> D2H '
-                        '-> coord_<i>.npy (np.save on 2 writer threads); a ramp of short first chunks (`first_chunks`: the first decode is '
-                        'exposed, each chunk\'s compute covers the next one\'s decode), then chunks of `chunk` frames'}
-    finally:
-        shutil.rmtree(root, ignore_errors=True)
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: start the N ranks
+    ourselves (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 at a free
+    port) and pass rank 0's JSON line through.  The driver's own form -- `python -m
+    torch.distributed.run ... bench.py --gpus N` -- sets WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's P2P buffers need it on this driver
+    env['KFN_BENCH_SELF_LAUNCHED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(frames, W, T4, steps):
@@ -397,624 +249,6 @@ def cpu_baseline(frames, W, T4, steps):
                       'sequence, torch-CPU fp32, %.1f s' % (steps, dt),
             'deduplicated_value': round(nd / dt_d, 4),
             'deduplicated_sample': '%d frames, towers once per frame, %.1f s' % (nd, dt_d)}, np.stack(recs)
-
-
-def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: start the N ranks
-    ourselves (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 at a free
-    port) and pass rank 0's JSON line through.  The driver's own form -- `python -m
-    torch.distributed.run ... bench.py --gpus N` -- sets WORLD_SIZE and never comes here."""
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's P2P buffers need it on this driver
-    env['KFN_BENCH_SELF_LAUNCHED'] = '1'
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
-
-
-class Telemetry(object):
-    """Shader clock / power / busy readings of one GPU from the amdgpu sysfs nodes, sampled on a
-    host thread while a timed region runs (file reads only: nothing touches the GPU queues).
-    Falls back to one `rocm-smi` call before and after when sysfs is not exposed."""
-
-    def __init__(self, dev_index, period=0.1, sysfs='/sys/class/drm'):
-        import glob
-        self.period = period
-        self.samples = []
-        self.dir = None
-        self._stop = None
-        self._thr = None
-        # The box exposes ONE GPU to the process but sysfs lists every card of the host (and the partition nodes,
-        # which have no pp_dpm_sclk): find OUR card by PCI address; if that fails, watch every card and report the
-        # busiest one (`source` says which rule was used).
-        cards = sorted(glob.glob(os.path.join(sysfs, 'card[0-9]*', 'device')))
-        self.cards = [c for c in cards if os.path.exists(os.path.join(c, 'pp_dpm_sclk'))]
-        self.how = None
-        try:
-            import torch
-            pr = torch.cuda.get_device_properties(dev_index)
-            want = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
-            for c in self.cards:
-                if os.path.basename(os.path.realpath(c)).lower() == want:
-                    self.dir, self.how = c, 'PCI address ' + want
-        except Exception:
-            pass
-        if self.dir is None and len(self.cards) == 1:
-            self.dir, self.how = self.cards[0], 'the only card with pp_dpm_sclk'
-        self.watch_all = self.dir is None and bool(self.cards)
-        if self.watch_all:
-            self.dir, self.how = self.cards[0], 'busiest of %d cards (PCI match failed)' % len(self.cards)
-        self.hwmon = None
-        if self.dir:
-            hm = sorted(glob.glob(os.path.join(self.dir, 'hwmon', 'hwmon*')))
-            self.hwmon = hm[0] if hm else None
-
-    @staticmethod
-    def _read(path):
-        try:
-            with open(path) as f:
-                return f.read()
-        except OSError:
-            return None
-
-    def _hwmon_of(self, d):
-        import glob
-        hm = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*')))
-        return hm[0] if hm else None
-
-    def settle(self):
-        """watch_all: keep the card with the highest mean gpu_busy_percent over the samples taken so far."""
-        if not self.watch_all or not self.all_samples:
-            return
-        best = max(self.all_samples, key=lambda c: sum(x.get('busy_pct', 0) for x in self.all_samples[c]))
-        self.dir, self.samples = best, self.all_samples[best]
-
-    def read_once(self, d=None):
-        out = {}
-        if d is not None:
-            keep = (self.dir, self.hwmon)
-            self.dir, self.hwmon = d, self._hwmon_of(d)
-            try:
-                return self.read_once()
-            finally:
-                self.dir, self.hwmon = keep
-        if not self.dir:
-            return out
-        txt = self._read(os.path.join(self.dir, 'pp_dpm_sclk'))
-        if txt:
-            for line in txt.splitlines():
-                if line.rstrip().endswith('*'):
-                    try:
-                        out['sclk_mhz'] = float(line.split(':')[1].strip().rstrip('*').strip().lower().replace('mhz', ''))
-                    except (IndexError, ValueError):
-                        pass
-        if self.hwmon:
-            v = self._read(os.path.join(self.hwmon, 'freq1_input'))
-            if v and v.strip().isdigit():
-                out['sclk_mhz_hwmon'] = int(v) / 1e6
-            for name in ('power1_average', 'power1_input'):
-                v = self._read(os.path.join(self.hwmon, name))
-                if v and v.strip().isdigit():
-                    out['power_w'] = int(v) / 1e6
-                    break
-        v = self._read(os.path.join(self.dir, 'gpu_busy_percent'))
-        if v and v.strip().isdigit():
-            out['busy_pct'] = int(v)
-        return out
-
-    @staticmethod
-    def smi_once():
-        """{'sclk_mhz':…, 'power_w':…} from `rocm-smi --showclocks --showpower --json` (first card), or {}."""
-        import subprocess
-        try:
-            r = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--json'], stdout=subprocess.PIPE,
-                               stderr=subprocess.DEVNULL, text=True, timeout=20)
-            card = next(iter(json.loads(r.stdout[r.stdout.index('{'):]).values()))
-        except Exception:
-            return {}
-        out = {}
-        for k, v in card.items():
-            kl = k.lower()
-            try:
-                if 'sclk' in kl and 'clock' in kl and 'sclk_mhz' not in out:
-                    out['sclk_mhz'] = float(str(v).strip('()').lower().replace('mhz', ''))
-                elif 'power' in kl and '(w)' in kl and 'power_w' not in out:
-                    out['power_w'] = float(v)
-            except ValueError:
-                pass
-        return out
-
-    def __enter__(self):
-        import threading
-        self.before = self.read_once() or self.smi_once()
-        if self.dir:
-            self._stop = threading.Event()
-
-            self.all_samples = {c: [] for c in self.cards} if self.watch_all else {}
-
-            def loop():
-                while not self._stop.wait(self.period):
-                    if self.watch_all:
-                        for c in self.cards:
-                            self.all_samples[c].append(self.read_once(c))
-                        continue
-                    smp = self.read_once()
-                    if smp:
-                        self.samples.append(smp)
-            self._thr = threading.Thread(target=loop, daemon=True)
-            self._thr.start()
-        return self
-
-    def __exit__(self, *exc):
-        if self._thr is not None:
-            self._stop.set()
-            self._thr.join()
-            self.settle()
-            self.hwmon = self._hwmon_of(self.dir)
-        self.after = self.read_once() or self.smi_once()
-        return False
-
-    def summary(self):
-        def agg(key):
-            v = [x[key] for x in self.samples if key in x]
-            return {'min': round(min(v), 1), 'mean': round(sum(v) / len(v), 1), 'max': round(max(v), 1)} if v else None
-        return {'source': ('sysfs %s (%s)' % (self.dir, self.how)) if self.dir else 'rocm-smi before/after (no sysfs nodes)',
-                'before': self.before, 'after': self.after, 'samples_during_timed_region': len(self.samples),
-                'sclk_mhz': agg('sclk_mhz') or agg('sclk_mhz_hwmon'), 'power_w': agg('power_w'),
-                'busy_pct': agg('busy_pct')}
-
-
-def config3_literal(args, Wt, T4, transform_txt, device, dev_index, frames=256, batch=32):
-    """BASELINE configs[2] to the letter -- ONE 256-frame 480x640 sequence, tower batch 32 -- for driver
-    runs whose --steps is smaller (per-step work is the same; this removes the extrapolation)."""
-    import torch
-    from kfnet_amd.engine import KFNetEngine
-    from kfnet_amd.synth import synthetic_sequence
-    eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=batch, transform=T4, reset_period=500,
-                      max_chunk=frames, device=str(device))
-    eng.two_streams = not args.one_stream
-    host = synthetic_sequence(frames, args.height, args.width, seed=1)
-    dev = eng.upload_frames(host)
-    eng.process(dev[:2 * batch], t0=0)
-    torch.cuda.synchronize()
-    tele = Telemetry(dev_index)
-    with tele:
-        times = timed_repetitions(lambda: eng.process(dev, t0=0), None, device, None, max(args.min_seconds, 3.0))
-    med = float(np.median(times))
-    out = {'value': round(frames / med, 3), 'unit': 'frames/s', 'ms_per_step': round(med * 1e3 / frames, 4),
-           'frames': frames, 'tower_batch': batch, 'repetitions': len(times),
-           'timed_seconds': round(float(np.sum(times)), 3),
-           'ms_per_step_min_max': [round(min(times) * 1e3 / frames, 4), round(max(times) * 1e3 / frames, 4)],
-           'gpu_telemetry': tele.summary(),
-           'note': 'the literal BASELINE configs[2] pass (256-frame sequence, frames resident in HBM -> records in '
-                   'HBM), median of the repetitions; `value` of this line is the same path at --steps frames'}
-    extra = {}
-    if not args.no_host_streamed:
-        # SURVEY 8(d)'s definition of the metric (transfers inside the timed region) on the SAME 256-frame sequence
-        extra['host_streamed'] = host_streamed(eng, host, dev, chunk=128)
-        if not args.no_eval_png:
-            resident = eng.process(dev, t0=0).cpu().numpy()
-            extra['eval_png_end_to_end'] = eval_png_end_to_end(eng, Wt, T4, transform_txt, host, resident, dev_index,
-                                                               chunk=args.eval_chunk, workers=args.decode_workers,
-                                                               ramp=([int(v) for v in args.eval_ramp.split(',') if int(v) > 0]
-                                                                     if args.eval_ramp else None))
-            hs = extra['host_streamed']['value']
-            extra['eval_png_end_to_end']['fraction_of_host_streamed'] = round(extra['eval_png_end_to_end']['value'] / hs, 4)
-    del eng, dev
-    torch.cuda.empty_cache()
-    return out, extra
-
-
-def auto_batch(K, lo=15, hi=32, prefer=32):
-    """Tower batch for a K-frame pass: the size in [lo, hi] with the least ragged tail, ties to the size
-    closest to `prefer` (measured on one box, K = 256: batch 16 492.0, 24 490.3, 32 497.1 frames/s -- at 32 the
-    tile-block counts of the wide layers are closer to multiples of the 256 CUs)."""
-    if K <= hi:
-        return max(1, K)
-    best = None
-    for b in range(lo, hi + 1):
-        launched = -(-K // b) * b
-        key = (launched - K, abs(b - prefer))
-        if best is None or key < best[0]:
-            best = (key, b)
-    return best[1]
-
-
-def timed_repetitions(run_once, dist, device, backend, min_seconds, max_reps=400):
-    """Repeat `run_once` (exactly K steps) until >= min_seconds are timed.  Every repetition is
-    bracketed by barrier + synchronize on both sides and timed on every rank; returns the
-    per-repetition MAX-over-ranks times (seconds)."""
-    import torch
-    times = []
-    total = 0.0
-    while True:
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_once()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())      # identical on every rank -> identical stop decision
-        times.append(dt)
-        total += dt
-        if total >= min_seconds or len(times) >= max_reps:
-            return times
-
-
-def measure_c2(args, device, min_seconds=None, min_steps=None):
-    """BASELINE configs[1]: SCoordNet alone on ONE 480x640 frame (batch 1, no recurrence) --
-    a latency number: ms per frame, eager launches and hipGraph replay."""
-    min_seconds = args.min_seconds if min_seconds is None else min_seconds
-    min_steps = args.steps if min_steps is None else min_steps
-    import torch
-    from kfnet_amd import _lib
-    from kfnet_amd.cnn_wrapper.SCoordNet import SCoordNet
-    from kfnet_amd.graph import Graph, variable_scope
-    from kfnet_amd.synth import synthetic_sequence
-    from kfnet_amd.weights import synthetic_weights
-    g = Graph()
-    g.conv_operands = args.conv_operands
-    img = g.placeholder((1, args.height, args.width, 3), 'u8', name='images')
-    with variable_scope('ScoreNet'):
-        net = SCoordNet({'input': img}, is_training=False, focal_x=525., focal_y=525., u=320., v=240.)
-    coord, unc = net.GetOutput()
-    g.finalize(str(device))
-    g.load_weights(synthetic_weights(1234))
-    frame = synthetic_sequence(1, args.height, args.width, seed=0)
-    img.upload(frame)
-    stream = torch.cuda.current_stream(device)
-    for _ in range(max(args.warmup, 3)):
-        g.run(stream.cuda_stream)
-    torch.cuda.synchronize()
-
-    def time_loop(fn, min_s):
-        lat = []
-        t_all = time.perf_counter()
-        while time.perf_counter() - t_all < min_s or len(lat) < min_steps:
-            t0 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t0)
-        return np.array(lat)
-    eager = time_loop(lambda: g.run(stream.cuda_stream), min_seconds)
-    cap = torch.cuda.Stream(device=device)
-    cg = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(cap):
-        with torch.cuda.graph(cg, stream=cap):
-            g.run(torch.cuda.current_stream(device).cuda_stream)
-    graph = time_loop(cg.replay, min_seconds)
-    # device-side time of one frame (events; excludes host launch gaps)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        cg.replay()
-    e1.record()
-    e1.synchronize()
-    dev_ms = e0.elapsed_time(e1) / 20
-    flops = g.total_flops()
-    med = float(np.median(graph))
-    # per-layer table at batch 1 (VERDICT r4 Next #1b): every launch timed alone with HIP events on the launch stream, its
-    # workgroup count (256 CUs: a launch below ~256 workgroups leaves CUs idle) and the FLOPs its MFMAs EXECUTE
-    lib = _lib.load()
-    layers = []
-    executed = 0.0
-    for op in g.ops:
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        op.launch(lib, stream.cuda_stream)
-        ea.record(stream)
-        for _ in range(reps):
-            op.launch(lib, stream.cuda_stream)
-        eb.record(stream)
-        eb.synchronize()
-        ms = ea.elapsed_time(eb) / reps
-        fl = op.flops() if hasattr(op, 'flops') else 0.0
-        ex = op.mfma_flops() if hasattr(op, 'mfma_flops') else fl
-        executed += ex
-        wg = None
-        if hasattr(op, 'launch_workgroups'):
-            wg = op.launch_workgroups()
-        elif hasattr(op, 'workgroups'):
-            wg = op.workgroups(lib)
-        layers.append({'op': op.name, 'kernel': op.kernel_name(lib) if hasattr(op, 'kernel_name') else type(op).__name__,
-                       'ms': round(ms, 4), 'workgroups': wg,
-                       'executed_tflops': round(ex / (ms * 1e-3) / 1e12, 1) if ex else None,
-                       'algorithmic_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if fl else None})
-    exec_tf = executed / (dev_ms * 1e-3) / 1e12
-    out = {'metric': 'frames/sec on 480x640 seq', 'value': round(1.0 / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
-           'steps': int(len(graph)), 'warmup': max(args.warmup, 3), 'ms_per_step': round(med * 1e3, 4),
-           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_operands,
-           'data': 'synthetic (one seeded uint8 frame, seeded random weights)',
-           'config': {'workload': 'BASELINE configs[1]: SCoordNet-only single %dx%d frame, batch 1, no recurrence '
-                                  '(latency)' % (args.height, args.width)},
-           'latency_ms': {'hipgraph_replay_median': round(med * 1e3, 4),
-                          'hipgraph_replay_p90': round(float(np.percentile(graph, 90)) * 1e3, 4),
-                          'eager_launches_median': round(float(np.median(eager)) * 1e3, 4),
-                          'device_time_per_frame': round(dev_ms, 4),
-                          'sum_of_isolated_launches': round(sum(r['ms'] for r in layers), 4)},
-           # achieved = FLOPs the MFMAs EXECUTE (Winograd F(4x4) 9/36, F(2x2) 16/36, polyphase 25/36 of the nominal count, +
-           # tile padding) / device time of one frame: a hardware-utilisation fraction, <= 1 by construction
-           'roofline': {'kernel': 'SCoordNet, all %d launches of one frame (batch 1)' % len(layers), 'bound': 'mfma',
-                        'achieved': round(exec_tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                        'traffic': None,
-                        'executed_gflop_per_frame': round(executed / 1e9, 3),
-                        'algorithmic_gflop_per_frame': round(flops / 1e9, 3),
-                        'algorithmic_tflops': round(flops / (dev_ms * 1e-3) / 1e12, 2),
-                        'note': 'frac = executed MFMA FLOPs / device time / fp32 MFMA peak; algorithmic_tflops (nominal dense '
-                                'FLOPs of SURVEY App. C / the same time) exceeds the peak because the minimal-filtering kernels '
-                                'execute fewer multiplies -- it is a rate, not a roofline fraction'},
-           'per_layer_batch1': layers}
-    del g, cg
-    torch.cuda.empty_cache()
-    return out
-
-
-def bench_c2(args, device):
-    print(json.dumps(measure_c2(args, device)))
-
-
-def c5_traffic(kernel, batch):
-    """HBM-side bytes per launch of config 5's dominant kernel from the newest profiles/rNN_c5_pmc_traffic.json
-    (separate rocprofv3 --pmc passes of `bench.py --config c5`, tools/profile_round.sh) -- quoted, not measured here."""
-    path, tj = latest_pmc_traffic('c5_pmc_traffic')
-    t = tj.get(kernel)
-    if t is None:
-        return None
-    return dict(t, quoted_from=os.path.relpath(path, ROOT), sampled={'command': 'bench.py --config c5', 'tower_batch': 16},
-                this_run_tower_batch=batch)
-
-
-def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
-    """BASELINE configs[4]: 960x540 input (68x120 grid), S independent sequences of T frames,
-    fp16 conv operands (fp32 accumulate) + fp32 Kalman scan advancing all sequences in one
-    launch.  A step = one 540x960 frame."""
-    min_seconds = args.min_seconds if min_seconds is None else min_seconds
-    import torch
-    from kfnet_amd.KFNet.eval import get_transform  # noqa: F401  (package's own; no oracle import here)
-    from kfnet_amd.engine import KFNetEngine
-    from kfnet_amd.synth import synthetic_sequence, synthetic_transform
-    from kfnet_amd.weights import synthetic_weights
-    H, W = 540, 960
-    S = args.sequences
-    T = min(args.steps, 64) if T is None else T
-    B = (args.batch if args.config == 'c5' else 0) or auto_batch(T, 8, 16, 16)
-    Wt = synthetic_weights(1234)
-    T4 = np.linalg.inv(synthetic_transform())
-    eng = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * T,
-                      device=str(device), conv_operands='f16')
-    eng.two_streams = not args.one_stream      # (--one-stream: the rocprof trace whose per-kernel averages match the isolated launches)
-    seqs = np.stack([synthetic_sequence(T, H, W, seed=3 + s) for s in range(S)])
-    dev = torch.from_numpy(seqs).to(device)
-    eng.process_sequences(dev)
-    torch.cuda.synchronize()
-    tele = Telemetry(device.index if device.index is not None else 0)
-    with tele:
-        times = timed_repetitions(lambda: eng.process_sequences(dev), None, device, None, min_seconds)
-    med = float(np.median(times))
-    PF = min(T, 16)     # frames per sequence of the parity sample
-    rec16 = eng.process_sequences(dev)[:, :PF].cpu().numpy().copy()
-    flow16 = eng.debug(S * T)['flow'].reshape(S, T, eng.h, eng.w, 2)[:, :PF].copy()
-    rows = per_kernel_profile(eng, dev[0])
-    by_kernel = {}
-    for r in rows:
-        k = by_kernel.setdefault(r[1], [0, 0.0, 0.0, 0.0])
-        k[0] += 1; k[1] += r[2]; k[2] += r[3]; k[3] += r[4]
-    heavy_ms = sum(r[3] for r in rows)
-    is16 = lambda name: (name.endswith('<true>') or name.startswith('conv64_rows_kernel')
-                         or (name.startswith('conv_mfma_kernel') and name.rstrip('>').split(', ')[-1] in ('1', '4', '5', '6', '7', '8')))
-    k16 = {k: v for k, v in by_kernel.items() if is16(k)}
-    dom = max(k16, key=lambda k: k16[k][2])
-    n_dom, fl_dom, ms_dom, ex_dom = k16[dom]
-    ms16 = sum(v[2] for v in k16.values())
-    fl16 = sum(v[1] for v in k16.values())
-    out = {'metric': 'frames/sec on 960x540 seq', 'value': round(S * T / med, 3), 'unit': 'frames/s', 'n_gpus': 1,
-           'steps': S * T, 'warmup': S * T, 'ms_per_step': round(med * 1e3 / (S * T), 4), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f16 conv operands (f32 accumulate) incl. the convolutions inside the window-resident OFlowNet kernels, f16 '
-                    'activations in SCoordNet, f32 first-layer arithmetic / cost-volume subtraction / softmax / Kalman',
-           'data': 'synthetic (rolled random texture uint8 frames, seeded random weights)',
-           'repetitions': len(times), 'gpu_telemetry': tele.summary(),
-           'config': {'workload': 'BASELINE configs[4]: %d sequences x %d frames of %dx%d (grid 68x120), fp16 convs + '
-                                  'fp32 Kalman, one batched scan launch' % (S, T, H, W), 'tower_batch': B},
-           # the dominant fp16-operand kernel; achieved = ALGORITHMIC (nominal direct-convolution) FLOPs of its layers /
-           # its time -- the Winograd / polyphase kernels execute 16/36 resp. 25/36 of them (executed_tflops)
-           'roofline': {'kernel': dom, 'bound': 'mfma', 'achieved': round(fl_dom / (ms_dom * 1e-3) / 1e12, 1),
-                        'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(fl_dom / (ms_dom * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': c5_traffic(dom, B),
-                        'executed_tflops': round(ex_dom / (ms_dom * 1e-3) / 1e12, 1),
-                        'launches_per_batch': n_dom, 'share_of_step_time': round(ms_dom / heavy_ms, 4),
-                        'all_fp16_operand_launches_algorithmic_tflops': round(fl16 / (ms16 * 1e-3) / 1e12, 1),
-                        'all_fp16_operand_launches_share_of_step_time': round(ms16 / heavy_ms, 4),
-                        'note': 'conv_mfma_kernel<TM,TN,WM,WN,BK,MODE,PREC>: PREC 6 = direct implicit GEMM on '
-                                'v_mfma_f32_32x32x16_f16 with fp16 activations in AND out of HBM (tap-innermost K order, '
-                                'chunk-major weights, LDS-transposed 16-byte output runs), PREC 7 = the same with the weight '
-                                'tile going global -> LDS directly (buffer_load ... lds), PREC 8 = both operand tiles that way (the '
-                                'eight-wave 256x256 tile <4,2,2,4,...>), PREC 4 = fp16 in / fp32 out, PREC 1 = '
-                                'fp16 operands rounded while staging fp32 activations (OFlowNet, feature tower); '
-                                'conv64_rows_kernel = the 64 -> 64 layer with register-resident weights (kfn_conv3x3_c64_f16); '
-                                'oflow_*_kernel<true> = the window-resident OFlowNet launches with their convolutions on '
-                                'v_mfma_f32_16x16x16_f16; '
-                                'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
-                                'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},
-           'kernels_ms_per_batch': {k: {'launches': v[0], 'ms': round(v[2], 4),
-                                        'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[1] else None}
-                                    for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])[:8]},
-           'per_layer_ms_per_batch': {'%s#%d' % (r[0], i): round(r[3], 4) for i, r in enumerate(rows)},
-           'tolerance': 'own tolerance (tests/test_gpu_e2e.py::test_config5_tolerance_at_bench_scale): coord max-abs <= 2e-2, '
-                        'confidence max-rel <= 5e-2 on every pixel away from the steps of the reference sampler; see '
-                        'parity_vs_fp32_path'}
-    if with_parity:
-        # parity of the fp16 path against the fp32 HIP path on the same frames (the fp32 path is
-        # itself checked against the oracle in tests/)
-        del eng
-        torch.cuda.empty_cache()
-        eng32 = KFNetEngine(Wt, image_size=(H, W), batch=B, transform=T4, reset_period=500, max_chunk=S * PF,
-                            device=str(device))
-        r32 = eng32.process_sequences(dev[:, :PF].contiguous()).cpu().numpy()
-        flow32 = eng32.debug(S * PF)['flow'].reshape(S, PF, eng32.h, eng32.w, 2)
-        from kfnet_amd.tools.parity import masked_parity, merge_parity
-        mp = merge_parity([masked_parity(rec16[s_], r32[s_], flow32[s_], coord_tol=2e-2, conf_rel_tol=5e-2,
-                                         delta=C5_DELTA_PX, reset_period=500, test_flow=flow16[s_]) for s_ in range(S)])
-        mp['sequences'] = S
-        mp['note'] = ('fp16 path vs the fp32 HIP path (itself held to the oracle at 1e-4 in tests/) on the first %d frames of '
-                      'every sequence.  The reference sampler (tools/util.py:36-93) returns 0 for a sample at x < 0 or x >= W-1 '
-                      '(same in y) and the border value just inside: where the two paths\' flows (equal to flow_max_abs_diff_px) '
-                      'put a sample on different sides of such a step (`crossings`, all within crossing_max_step_distance_px '
-                      '< %.2f px of it) the pixel differs by the whole state value and hands that on to the pixels that sample '
-                      'it later.  The tolerance (coord max-abs <= 2e-2, confidence max-rel <= 5e-2) holds on EVERY pixel that '
-                      'is not such a descendant (`unmasked_outside_tolerance` = 0; the descendants are `masked_fraction` of the '
-                      'pixel-frames, kfnet_amd/tools/parity.py); `outside_tolerance_fraction` of all pixel-frames actually '
-                      'deviate by more' % (PF, C5_DELTA_PX))
-        out['parity_vs_fp32_path'] = mp
-        del eng32
-    torch.cuda.empty_cache()
-    return out
-
-
-def bench_c5(args, device):
-    print(json.dumps(measure_c5(args, device, with_parity=not args.no_cpu_baseline)))
-
-
-def chain_timing(run_with_timer, dist, device, world):
-    """One extra, instrumented sharded pass (NOT a timed repetition): every rank stamps heavy-end / recv-end /
-    scan-end / send-end with HIP events relative to an origin taken right behind a barrier + synchronize, so the
-    stamps of different ranks sit on the node's monotonic clock.  Collective: every rank calls it.
-      scan_chain_ms  = last rank's scan end - rank 0's scan start: the serial part of the sharded configuration
-                       (world scans + world-1 hand-offs; it hides behind the heavy phase only on rank 0 .. world-2);
-      handoff_us     = per rank: recv (time from its own heavy-phase end until the state has arrived -- includes
-                       waiting for the predecessor's scan) and send (issue -> complete on the stream);
-      handoff_us_net = (scan_chain_ms - sum of the ranks' scan times) / (world - 1): what one hand-off adds."""
-    import torch
-    from kfnet_amd.dist import ChunkTimer
-    timer = ChunkTimer(torch, device)
-    torch.cuda.synchronize()
-    dist.barrier()
-    timer.origin()
-    run_with_timer(timer)
-    torch.cuda.synchronize()
-    mine = timer.summary()
-    allr = [None] * world
-    dist.all_gather_object(allr, mine)
-    t_abs = lambda r, name: allr[r]['t_origin_monotonic_s'] * 1e3 + allr[r]['ms_since_origin'][name]
-    chain = t_abs(world - 1, 'scan_end') - t_abs(0, 'recv_end')
-    scans = [a['scan_ms'] for a in allr]
-    tail = max(t_abs(r, 'scan_end') for r in range(world)) - max(t_abs(r, 'heavy_end') for r in range(world))
-    return {'sharding': 'contiguous', 'scan_chain_ms': round(chain, 4), 'tail_ms': round(tail, 4),
-            'scan_ms_per_rank': [round(x, 4) for x in scans],
-            'heavy_ms_per_rank': [round(a['heavy_ms'], 3) for a in allr],
-            'handoff_us': [{'recv_wait_us': None if a['recv_wait_us'] is None else round(a['recv_wait_us'], 1),
-                            'send_us': None if a['send_us'] is None else round(a['send_us'], 1)} for a in allr],
-            'handoff_us_net': round((chain - sum(scans)) * 1e3 / max(world - 1, 1), 1),
-            'note': 'one instrumented pass after the timed repetitions; HIP events on each rank\'s stream, origins '
-                    'aligned through a barrier and time.monotonic()'}
-
-
-def cyclic_sharding_block(args, eng, rank, world, K, link, dist, device, backend):
-    """The same N*K-frame job with BLOCK-CYCLIC sharding (kfnet_amd.dist.run_cyclic: blocks of --block frames dealt round-robin,
-    the state hopping once per block) beside the contiguous chunks of the headline: timed the same way, plus one instrumented
-    pass whose `tail_ms` = last scan end over all ranks - last heavy-phase end over all ranks, i.e. the serial part nothing
-    hides (contiguous: world scans + world-1 hand-offs; cyclic: the start-up skew of one block's scan per rank).
-    Collective: every rank calls it."""
-    import torch
-    from kfnet_amd.dist import cyclic_blocks, needs_state, run_cyclic
-    from kfnet_amd.synth import synthetic_sequence
-    total = K * world
-    block = max(1, min(args.block, K, eng.max_chunk))
-    store = {}
-    for j, lo, hi in cyclic_blocks(total, block, rank, world):
-        need = 1 if needs_state(lo, 500) else 0
-        store[lo - need] = eng.upload_frames(synthetic_sequence(hi - lo + need, args.height, args.width, seed=1, start=lo - need))
-    frames_of = lambda lo, hi: store[lo][:hi - lo]
-    sink = lambda lo, rec: None
-    run = lambda stamp=None: run_cyclic(eng, frames_of, total, block, rank, world, link, on_block=sink, stamp=stamp)
-    run()
-    torch.cuda.synchronize()
-    times = timed_repetitions(run, dist, device, backend, args.min_seconds)
-    med = float(np.median(times))
-    # instrumented pass: HIP events on this rank's stream at every block's heavy end / scan start / scan end
-    ev = {}
-
-    def stamp(name, j):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(torch.cuda.current_stream(device))
-        ev[(name, j)] = e
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t_origin = time.monotonic()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e0.record(torch.cuda.current_stream(device))
-    run(stamp)
-    torch.cuda.synchronize()
-    rel = {k: float(e0.elapsed_time(e)) for k, e in ev.items()}
-    mine = {'t0': t_origin,
-            'last_heavy_end': max([v for (n_, _), v in rel.items() if n_ == 'heavy_end'], default=None),
-            'last_scan_end': max([v for (n_, _), v in rel.items() if n_ == 'scan_end'], default=None),
-            'recv_wait_ms': sum(rel[('scan_start', j)] - rel[('heavy_end', j)] for (n_, j) in rel if n_ == 'heavy_end'),
-            'scan_ms': sum(rel[('scan_end', j)] - rel[('scan_start', j)] for (n_, j) in rel if n_ == 'scan_end')}
-    allr = [None] * world
-    dist.all_gather_object(allr, mine)
-    ab = lambda a, k: None if a[k] is None else a['t0'] * 1e3 + a[k]
-    ends = [ab(a, 'last_scan_end') for a in allr if a['last_scan_end'] is not None]
-    heavies = [ab(a, 'last_heavy_end') for a in allr if a['last_heavy_end'] is not None]
-    del store
-    return {'sharding': 'block-cyclic', 'block': block, 'blocks_total': -(-total // block),
-            'value': round(total / med, 3), 'unit': 'frames/s', 'ms_per_step': round(med * 1e3 / K, 4), 'repetitions': len(times),
-            'tail_ms': round(max(ends) - max(heavies), 4) if ends and heavies else None,
-            'recv_wait_ms_per_rank': [round(a['recv_wait_ms'], 3) for a in allr],
-            'scan_ms_per_rank': [round(a['scan_ms'], 3) for a in allr],
-            'note': 'same job, same timing protocol as the headline (contiguous chunks); tail_ms = serial part left exposed after the '
-                    'last heavy phase of any rank has ended'}
-
-
-def config4_literal(args, Wt, T4, rank, world, link, dist, device, backend, dev_index, frames_per_rank=256, batch=32):
-    """BASELINE configs[3] to the letter when the driver runs 8 ranks with fewer steps: ONE 2048-frame sequence,
-    rank r owns frames [256 r, 256 r + 256), Kalman state handed rank -> rank (resets at 500/1000/1500/2000 fall
-    inside chunks).  Collective: every rank calls it; returns the block (the same on every rank)."""
-    import torch
-    from kfnet_amd.dist import needs_state, run_chunk
-    from kfnet_amd.engine import KFNetEngine
-    from kfnet_amd.synth import synthetic_sequence
-    K = frames_per_rank
-    lo = rank * K
-    need_prev = 1 if needs_state(lo, 500) else 0
-    host = synthetic_sequence(K + need_prev, args.height, args.width, seed=2, start=lo - need_prev)
-    eng = KFNetEngine(Wt, image_size=(args.height, args.width), batch=batch, transform=T4, reset_period=500,
-                      max_chunk=K, device=str(device))
-    eng.two_streams = not args.one_stream
-    dev_all = eng.upload_frames(host)
-    prev = dev_all[0] if need_prev else None
-    dev = dev_all[need_prev:]
-    run = lambda timer=None: run_chunk(eng, dev, lo, rank, world, link, prev, timer=timer)
-    run()
-    torch.cuda.synchronize()
-    times = timed_repetitions(run, dist, device, backend, max(args.min_seconds, 3.0))
-    med = float(np.median(times))
-    chain = chain_timing(run, dist, device, world)
-    del eng, dev_all
-    torch.cuda.empty_cache()
-    return {'value': round(K * world / med, 3), 'unit': 'frames/s', 'frames_total': K * world, 'frames_per_rank': K,
-            'tower_batch': batch, 'ms_per_step': round(med * 1e3 / K, 4), 'repetitions': len(times),
-            'timed_seconds': round(float(np.sum(times)), 3), 'handoff': chain,
-            'image': '%dx%d' % (args.height, args.width),
-            'is_literal_config4': bool((args.height, args.width) == (480, 640) and world == 8 and K == 256),
-            'note': 'BASELINE configs[3]: one %d-frame sequence over %d ranks (resets at 500 / 1000 / ... fall inside '
-                    'chunks), median repetition, MAX over ranks' % (K * world, world)}
 
 
 def main():
@@ -1151,19 +385,35 @@ def main():
             if rank == 0:
                 out['multi_rank_extras'] = ('TIMED OUT after %.0f s: handoff / sharding_cyclic / config4_2048_frames and the '
                                             'rank-0 rooflines are missing from this line; the headline fields are complete' % deadline)
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                out['watchdog_fired'] = True
+                emit(out, args)
+            os._exit(3)
         watchdog = threading.Timer(deadline, bail)
         watchdog.daemon = True
         watchdog.start()
     if dist is not None:
+        extras_ok = [True]
+
         def extra(key, fn):
-            """an extra that raises on this rank is recorded, not fatal (the other ranks' side of its collectives is then
-            caught by the watchdog)"""
+            """An extra is a sequence of collectives: a rank that failed inside one must not walk into the next while its
+            peers are still in the previous (mispaired send/recv).  Every rank reports its outcome, all-reduced (MIN) after
+            each extra; after the first failure anywhere, every rank skips the rest.  (A rank that dies INSIDE a collective
+            leaves the others waiting: that case is the watchdog's.)"""
+            if not extras_ok[0]:
+                out[key] = {'error': 'skipped: an earlier multi-rank extra failed on some rank'}
+                return
+            ok = 1
             try:
                 out[key] = fn()
             except Exception as e:      # noqa: BLE001
                 out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+                ok = 0
+            flag = torch.tensor([ok], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                extras_ok[0] = False
+                if ok:
+                    out[key] = dict(out[key] if isinstance(out[key], dict) else {}, error='failed on another rank')
         extra('handoff', lambda: chain_timing(lambda timer: run_chunk(eng, dev_frames, lo, rank, world, link, dev_prev, timer=timer),
                                               dist, device, world))
         out['sharding'] = 'contiguous'       # of the headline `value`; the block-cyclic alternative is measured beside it
@@ -1186,10 +436,22 @@ def main():
         tf_exec = ex_dom / (ms_dom * 1e-3) / 1e12
         conv_ms = sum(v[2] for k, v in by_kernel.items() if k.startswith('conv_mfma_kernel'))
         conv_fl = sum(v[1] for k, v in by_kernel.items() if k.startswith('conv_mfma_kernel'))
+        # algorithmic HBM bytes of one launch of the dominant kernel: its input and output tensors once, its weights once
+        # (averaged over its launches of a batch, at the tower batch the PMC passes sampled so that it compares with them)
+        def alg_bytes(batch):
+            tot, n = 0.0, 0
+            for op in eng.heavy_ops:
+                if hasattr(op, 'kernel_name') and op.kernel_name(eng.lib) == dom and hasattr(op, 'x') and hasattr(op, 'y'):
+                    esz = {'f32': 4, 'f16': 2, 'u8': 1}
+                    act = sum(float(np.prod(t.shape[1:])) * esz[t.dtype] for t in (op.x, op.y))
+                    tot += act * batch + float(np.prod(op.kernel.shape)) * 4
+                    n += 1
+            return int(tot / n) if n else None
         traffic = None
         tpath, tj = latest_pmc_traffic()
         traffic = tj.get(dom)
         if traffic is not None:
+            traffic = dict(traffic, algorithmic_bytes_per_launch=alg_bytes((tj.get('__sampled__') or {}).get('tower_batch', 32)))
             # NOT measured by this run: PMC counters need their own rocprofv3 passes (tools/profile_round.sh)
             traffic = dict(traffic, quoted_from=os.path.relpath(tpath, ROOT), sampled=tj.get('__sampled__', {
                 'command': 'bench.py --steps 64 --batch 32', 'tower_batch': 32}), this_run_tower_batch=B)
@@ -1292,50 +554,16 @@ def main():
             c2 = measure_c2(args, device, min_seconds=1.0, min_steps=50)
             out['config2_single_frame'] = {k: c2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'latency_ms',
                                                                'roofline', 'per_layer_batch1')}
-        # ---- the numbers a reader wants first, LAST in the line (a log tail shows them) ------------------
-        hs, c5b, c2b = out.get('host_streamed'), out.get('config5_960x540'), out.get('config2_single_frame')
-        # `value` follows the bench contract of this build (inputs already resident in HBM when the timed region starts; a
-        # PCIe-inclusive rate is never `value`); SURVEY 8(d)'s own definition -- H2D of the uint8 frames and D2H of the records
-        # inside the timed region -- is `value_streamed`.  Both are top-level, both are named for what they are.
-        out['value_hbm_resident'] = out['value']
-        out['value_definition'] = ('value = value_hbm_resident: frames resident in HBM -> records in HBM (the round\'s bench contract); '
-                                   'value_streamed: SURVEY 8(d)\'s definition, frames start in pinned host memory and the records end '
-                                   'there (256-frame sequence, chunk 128, median of 3 passes)')
-        if hs is not None:
-            out['value_streamed'] = hs['value']
-        pick = lambda d, *ks: None if d is None else {k: d.get(k) for k in ks}
-        summ = {
-            'value_hbm_resident_frames_per_s': out['value'],
-            'value_streamed_h2d_d2h_inclusive_frames_per_s': out.get('value_streamed'),
-            'value_streamed_is': None if hs is None else '%d frames, chunk %d, from pinned host memory' % (hs['frames'], hs['chunk']),
-            'config3_256_frames': pick(out.get('config3_256_frames'), 'value', 'ms_per_step'),
-            'eval_png_end_to_end': pick(out.get('eval_png_end_to_end'), 'value', 'fraction_of_host_streamed', 'decode_threads',
-                                        'gpu_busy_pct', 'bit_identical_to_resident_run'),
-            'roofline_frac_dominant_kernel': [out['roofline']['kernel'], out['roofline']['frac']],
-            'roofline_kalman_frac': None if 'roofline_kalman' not in out else {
-                'S256xT64': out['roofline_kalman']['frac'], 'S256xT256': out['roofline_kalman_T256']['frac'],
-                'fuse_only': out['roofline_kalman_fuse']['frac'],
-                'is': 'bytes that cross HBM per launch (44 B/px scan, 48 B/px fuse) / avg launch time / 8 TB/s'},
-            'cpu_baseline_frames_per_s': None if 'cpu_baseline' not in out else [out['cpu_baseline']['value'], out['cpu_baseline']['cores']],
-            'parity_vs_cpu': pick(out.get('parity_vs_cpu_restatement'), 'coord_max_abs', 'conf_max_rel'),
-            'config5_960x540': None if c5b is None else {
-                'value': c5b['value'], 'ms_per_step': c5b['ms_per_step'],
-                'roofline': pick(c5b['roofline'], 'kernel', 'achieved', 'frac'),
-                'sclk_mhz_mean': ((c5b.get('gpu_telemetry') or {}).get('sclk_mhz') or {}).get('mean'),
-                'parity_vs_fp32_path': pick(c5b.get('parity_vs_fp32_path'), 'unmasked_outside_tolerance', 'masked_fraction',
-                                            'outside_tolerance_fraction', 'frames', 'sequences', 'crossings')},
-            'config2_single_frame_ms': None if c2b is None else c2b['latency_ms'],
-            'handoff': pick(out.get('handoff'), 'scan_chain_ms', 'tail_ms', 'handoff_us_net'),
-            'sharding_cyclic': pick(out.get('sharding_cyclic'), 'value', 'block', 'tail_ms'),
-            'config4_2048_frames': pick(out.get('config4_2048_frames'), 'value', 'ms_per_step'),
-        }
-        out['summary'] = {k: v for k, v in summ.items() if v is not None}
-        print(json.dumps(out))
+        emit(out, args)
     if link is not None:
         link.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
 
 
 if __name__ == '__main__':

@@ -98,10 +98,12 @@ def test_two_rank_state_transfer_over_rccl(tmp_path):
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
     b = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '2',
-                        '--min-seconds', '0.5', '--no-kalman-roofline'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=900, env=env, cwd=ROOT)
+                        '--min-seconds', '0.5', '--no-kalman-roofline', '--detail', str(tmp_path / 'detail.json')],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
     assert b.returncode == 0, b.stderr[-3000:]
-    line = json.loads([l for l in b.stdout.splitlines() if l.startswith('{')][-1])
+    compact = json.loads(b.stdout.strip().splitlines()[-1])
+    assert compact['n_gpus'] == 2 and compact['rccl_ranks'] == [[0, 2], [1, 2]]
+    line = json.load(open(tmp_path / 'detail.json'))
     assert line['n_gpus'] == 2 and line['dist_backend'] == 'nccl'
     assert line['rccl_ranks'] == [[0, 2], [1, 2]]                      # ncclCommUserRank / ncclCommCount of every rank
     assert line['state_link'].startswith('C-ABI kfn_send_state')

@@ -155,7 +155,7 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     assert out['n_gpus'] == 2 and out['config']['frames_total'] == 12 and out['value'] > 0
 
 
-def test_bench_gpus_2_launches_two_ranks_by_itself():
+def test_bench_gpus_2_launches_two_ranks_by_itself(tmp_path):
     """`python bench.py --gpus 2` -- the plain form, no torch.distributed.run around it -- must start
     two ranks itself.  On a one-GPU box the ranks share the GPU over gloo and the
     line says so; on a multi-GPU node the same command hands the state over RCCL (rccl_ranks)."""
@@ -168,12 +168,17 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'KFN_DIST_BACKEND')}
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2', '--block', '2']
+           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2', '--block', '2',
+           '--detail', str(tmp_path / 'detail.json')]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, 'exactly one JSON line (rank 0)'
-    out = json.loads(lines[0])
+    assert lines[0] == r.stdout.strip().splitlines()[-1] and len(lines[0]) < 4096      # the driver's line: last, compact
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['handoff']['scan_chain_ms'] > 0 and line['sharding_cyclic']['block'] == 2
+    out = json.load(open(tmp_path / 'detail.json'))                 # the full result (sidecar file)
+    assert out['value'] == line['value']
     assert out['n_gpus'] == 2 and out['self_launched'] is True
     assert out['config']['frames_total'] == 12 and out['value'] > 0
     assert len(out['rccl_ranks']) == 2 and len(out['rank_devices']) == 2
@@ -197,7 +202,7 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
         assert 'FUNCTIONAL FALLBACK' in out['config']['parallelism']
 
 
-def test_bench_gpus_8_carries_the_config4_block():
+def test_bench_gpus_8_carries_the_config4_block(tmp_path):
     """The driver's 8-rank command with fewer than 256 steps also runs BASELINE configs[3] -- 8 x 256 = 2048 frames, state
     handed rank -> rank -- and reports it with the measured chain (Next #4b).  Here the 8 ranks share the
     box's GPU(s) (gloo fallback when there are fewer than 8) on small frames; the arithmetic path is the driver's."""
@@ -209,10 +214,12 @@ def test_bench_gpus_8_carries_the_config4_block():
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'KFN_DIST_BACKEND')}
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2',
-           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2']
+           '--batch', '2', '--height', '64', '--width', '96', '--no-kalman-roofline', '--min-seconds', '0.2',
+           '--detail', str(tmp_path / 'detail.json')]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.load(open(tmp_path / 'detail.json'))
     assert out['n_gpus'] == 8 and out['config']['frames_total'] == 32
     c4 = out['config4_2048_frames']
     assert c4['frames_total'] == 2048 and c4['frames_per_rank'] == 256 and c4['value'] > 0
@@ -221,7 +228,7 @@ def test_bench_gpus_8_carries_the_config4_block():
     assert len(h['scan_ms_per_rank']) == 8 and h['scan_chain_ms'] >= sum(h['scan_ms_per_rank']) * 0.5
     # chunks [256 r, 256 r + 256): frames 500, 1000, 1500, 2000 are inside chunks 1, 3, 5, 7 -- every boundary hands over
     assert all(x['recv_wait_us'] is not None for x in h['handoff_us'][1:]) and h['handoff_us'][0]['recv_wait_us'] is None
-    assert out['summary']['config4_2048_frames']['value'] == c4['value']
+    assert line['config4_2048_frames']['value'] == c4['value'] and line['n_gpus'] == 8
 
 
 def test_config5_shape_batch_of_sequences():

@@ -553,12 +553,8 @@ def test_epilogue_on_f43_and_conv64_routed_layers_reroutes_to_the_direct_kernel(
 def test_bench_telemetry_picks_the_busy_card_and_parses_sysfs(tmp_path):
     """bench.py's clock / power sampler on a fake sysfs tree: partition nodes (no pp_dpm_sclk) are ignored;
     when the PCI address cannot be matched (no GPU here) every card is watched and the busiest reported."""
-    import importlib.util
     import time
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location('kfn_bench', os.path.join(root, 'bench.py'))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
+    bench, _ = _load_bench()
     for i, (busy, mhz, uw) in enumerate([(0, 132, 90000000), (97, 2104, 912000000)]):
         d = tmp_path / ('card%d' % i) / 'device'
         (d / 'hwmon' / 'hwmon3').mkdir(parents=True)
@@ -573,6 +569,62 @@ def test_bench_telemetry_picks_the_busy_card_and_parses_sysfs(tmp_path):
     assert s['samples_during_timed_region'] >= 3 and 'card1' in s['source'] and 'busiest of 2' in s['source']
     assert s['sclk_mhz']['mean'] == 2104.0 and s['power_w']['max'] == 912.0 and s['busy_pct']['min'] == 97
     assert s['after']['sclk_mhz'] == 2104.0
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kfn_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench, root
+
+
+def test_bench_compact_line_fits_the_drivers_reader(tmp_path, capsys):
+    """BENCH_r05.json had `parsed: null`: the one stdout line had grown to 21 KB.  The driver's line is now
+    `compact_line(full result)`: strict JSON, < 4 KB, carrying the contract fields + roofline + cpu_baseline, whatever the
+    full result holds -- checked on the round-5 result itself (the 21 KB object) and on a multi-rank one with error
+    strings and NaNs; `emit` writes the full object to the sidecar and prints the compact line LAST."""
+    import argparse
+    import json
+    bench, root = _load_bench()
+    full = json.load(open(os.path.join(root, 'profiles', 'r05_bench_driver_command.json')))
+    assert len(json.dumps(full)) > 20000
+    s = bench.compact_line(full)
+    assert len(s) < 4096 and '\n' not in s
+    d = json.loads(s, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))     # NaN / Infinity are not JSON
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['value'] == full['value'] and d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1
+    assert d['config']['workload'].startswith('full KFNet')
+    r = d['roofline']
+    assert r['kernel'] == 'wino4b_kernel' and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert set(r['traffic']) >= {'fetch', 'write', 'algorithmic'} and r['traffic']['fetch'] > 1e9
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['deduplicated_value'] > 0 and len(c['sample']) <= 140
+    assert d['value_streamed'] == full['host_streamed']['value']
+    assert d['parity']['coord_max_abs'] < 1e-4 and d['parity']['conf_max_rel'] < 1e-4
+    assert set(d['roofline_kalman']) >= {'T64', 'T256', 'fuse'}
+    assert d['config5']['value'] > 0 and 0 < d['config5']['frac'] < 1 and d['config2_ms'] > 0
+    assert not any(isinstance(v, str) and len(v) > 200 for v in d.values())          # no prose
+    # a hostile multi-rank result: long error strings, NaN, numpy scalars
+    import numpy as np
+    bad = dict(full, n_gpus=8, state_link='rccl', dist_backend='nccl', rccl_ranks=[[i, 8] for i in range(8)],
+               handoff={'error': 'RuntimeError: ' + 'x' * 5000}, sharding_cyclic={'value': np.float32(1.5), 'block': 32, 'tail_ms': float('nan')},
+               config4_2048_frames={'value': 5000.0, 'ms_per_step': 0.2, 'note': 'y' * 9000},
+               multi_rank_extras='TIMED OUT ' + 'z' * 3000, data='d' * 4000, dtype='t' * 4000)
+    args = argparse.Namespace(detail=str(tmp_path / 'sub' / 'detail.json'))
+    print('an earlier line')
+    bench.emit(bad, args)
+    lines = capsys.readouterr().out.strip().split('\n')
+    assert len(lines[-1]) < 4096
+    d2 = json.loads(lines[-1], parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert d2['n_gpus'] == 8 and d2['sharding_cyclic'].get('tail_ms') is None and len(d2['handoff']['error']) <= 160
+    side = json.load(open(args.detail))
+    assert side['handoff']['error'].endswith('x' * 100) and side['sharding_cyclic']['tail_ms'] is None
+    assert d2['detail_file'].endswith('detail.json')
 
 
 def test_f43_split_k_is_chosen_for_single_frames_only():

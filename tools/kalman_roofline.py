@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import bench  # noqa: E402
+import bench_extra as bench  # noqa: E402
 
 if __name__ == '__main__':
     # `--T 256`: SURVEY 8(d)'s default shape (S = 256 x T = 256) alone, for its own PMC passes (the kernel name is the same, so
