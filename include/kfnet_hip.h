@@ -42,7 +42,7 @@ extern "C" {
  * version bump); kfn_comm_rank asks RCCL; kfn_kalman_scan_ex no longer allocates.  A host checks
  * kfn_abi_version() == KFN_ABI_VERSION once after loading the library.
  * 6 (round 5): split-K Winograd entry points, kfn_winograd_lds_bytes.  7 (round 5): kfn_decode_png_rgb8. */
-#define KFN_ABI_VERSION 7
+#define KFN_ABI_VERSION 8
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -149,6 +149,8 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_FORM_F43_FOUR_WAVE 2  /* kfn_conv2d_winograd_f43: wino4_kernel (four waves, 32x32x2 MFMA tiles) */
 #define KFN_WINO_FORM_F43_EIGHT_WAVE 3 /* kfn_conv2d_winograd_f43: wino4b_kernel (eight waves, 16x16x4 MFMA tiles) */
 #define KFN_WINO_FORM_S2_EIGHT_WAVE 4  /* kfn_conv2d_winograd_s2: wino_s2b_kernel (eight waves, 16x16x4 MFMA tiles; fp32 operands) */
+#define KFN_WINO_FORM_S2_F42 5         /* kfn_conv2d_winograd_s2: wino_s2c_kernel, polyphase + F(4,2) on 4x4 output tiles (81 instead of 100
+                                        * products per 16 outputs; fp32, H and W multiples of 8; weights: pack_winograd_s2_kernel_c) */
 
 #define KFN_OPERAND_F32 0
 #define KFN_OPERAND_F16 1
@@ -473,6 +475,23 @@ int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt
 /* KFNet.GetKFCoord2 (KFNet/KFNet.py:487-502; not on eval.py's path): the same fusion with the posterior variance in
  * the symmetric form (1-K)^2 P^- + K^2 R.  pred / meas / out packed [P,4] = (x, y, z, sigma) as for kfn_kalman_fuse. */
 int kfn_kalman_fuse2(const float* pred, const float* meas, float* out, long P, void* stream);
+
+/* ---- the graph-level helpers of the reference as stand-alone launches ----------------------------------------
+ * On eval.py's path they are fused into the scan (kfn_kalman_scan: warp, fuse, transform in one kernel); these entry
+ * points serve Python-level callers (KFNet/eval.py:57-59 calls ApplyTransform itself).  All tensors NHWC fp32 with a
+ * pixel stride `ld_*` (floats) so that channel views of packed buffers can be passed.
+ *   kfn_apply_transform   KFNet/util.py:12-40: out[p,0:3] = (T [x;1])[0:3], no perspective divide.  `transform` is a DEVICE
+ *                         pointer to one 4x4 (per_batch = 0) or B 4x4 (per_batch = 1) row-major matrices.
+ *   kfn_pixel_map         KFNet/util.py:42-63: out[b,y,x] = (x, y); normalize != 0: ((x - u) / focal_x, (y - v) / focal_y).
+ *   kfn_bilinear_sampler  tools/util.py:3-94: imgs [B,Hs,Ws,C] sampled at coords [B,Ht,Wt,2] = (x, y) -> out [B,Ht,Wt,C];
+ *                         corner indices clamped to the image AND weights taken from the clamped corners (so any sample
+ *                         with x < 0 or x >= Ws-1 evaluates to 0, x = Ws-1 included), sum in tf.add_n order. */
+int kfn_apply_transform(const float* coords, int ld_in, const float* transform, int per_batch, int B, int H, int W,
+                        float* out, int ld_out, void* stream);
+int kfn_pixel_map(float* out, int ld_out, int B, int H, int W, int normalize, float u, float v, float focal_x,
+                  float focal_y, void* stream);
+int kfn_bilinear_sampler(const float* imgs, int ld_img, int B, int Hs, int Ws, int C, const float* coords, int ld_coords,
+                         int Ht, int Wt, float* out, int ld_out, void* stream);
 
 /* ---- Network.concat fallback (cnn_wrapper/network.py:316-318): strided channel copy -- */
 int kfn_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, int P, int C,

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
@@ -108,6 +108,9 @@ SYMBOLS = {
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
     'kfn_kalman_fuse2': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    'kfn_apply_transform': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'kfn_pixel_map': (_i, [_vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    'kfn_bilinear_sampler': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     'kfn_decode_png_rgb8': (_i, [C.POINTER(C.c_char_p), _i, _i, _i, _vp, C.POINTER(_i), _i]),
     'kfn_comm_available': (_i, []),
     'kfn_comm_unique_id': (_i, [_vp, _sz]),

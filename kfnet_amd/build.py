@@ -27,6 +27,8 @@ EXTRA = {
     'kfn_kalman.hip': ['-ffp-contract=off'],
     # the metrics kernel restates TF elementwise ops whose results are thresholded and counted
     'kfn_metrics.hip': ['-ffp-contract=off'],
+    # ApplyTransform / bilinear_sampler as stand-alone launches: the same unfused arithmetic as inside the scan
+    'kfn_util_ops.hip': ['-ffp-contract=off'],
 }
 
 

@@ -698,6 +698,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2b_kernel(WinoS2Args p) {
 
 // Can the polyphase kernel take this layer?  (host-side routing; no device access)
 int kfn::wino_s2_lds_bytes(int wino_form, int operand_dtype) {
+  if (wino_form == KFN_WINO_FORM_S2_F42) return operand_dtype == KFN_OPERAND_F32 ? kfn::wino_s2c_lds_bytes() : -1;
   if (wino_form == KFN_WINO_FORM_S2_EIGHT_WAVE) return operand_dtype == KFN_OPERAND_F32 ? SB_LDS : -1;
   if (wino_form != KFN_WINO_FORM_AUTO) return -1;
   return operand_dtype == KFN_OPERAND_F16 ? VLayoutS2<true>::LDS : VLayoutS2<false>::LDS;
@@ -707,6 +708,7 @@ extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
   kfn_conv_desc d_full;
   if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_s2_supported") != KFN_OK) return 0;
   d = &d_full;
+  if (d->wino_form == KFN_WINO_FORM_S2_F42) return kfn::wino_s2c_supported(d);
   if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32) return 0;
   if (d->kh != 3 || d->kw != 3 || d->stride != 2 || d->transposed) return 0;
   if (d->H <= 0 || d->W <= 0 || (d->H & 1) || (d->W & 1)) return 0;     // 'same' pads after the image only
@@ -817,6 +819,7 @@ extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, co
                                       float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
   KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2");
+  if (d->wino_form == KFN_WINO_FORM_S2_F42) return kfn::launch_wino_s2c(d, x, u2_packed, bias, y, stream);   // kfn_wino_s2c.hip
   return s2_launch(d, x, u2_packed, bias, y, d->ldy, d->relu, 1, stream);
 }
 

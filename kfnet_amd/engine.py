@@ -74,9 +74,28 @@ class KFNetEngine(object):
         # chunk-level scan buffers
         hw = self.h * self.w
         T = self.max_chunk
-        self.c_flow = g.tensor((T, self.h, self.w, 2), name='chunk_flow')
-        self.c_sigma = g.tensor((T, self.h, self.w, 1), name='chunk_sigma_trans')
-        self.c_meas = g.tensor((T, self.h, self.w, 4), name='chunk_meas')
+        # The three per-frame scan inputs are WRITTEN IN PLACE: the launches that produce a batch's measurement / flow /
+        # sigma_trans write straight into frame slots [d0, d0 + B) of the chunk buffers (Tensor.slide before every batch),
+        # so nothing is copied between the heavy phase and the scan.  B frames of slack behind slot T: a partial batch
+        # still addresses B slots, and the hipGraph-replay mode (pointers fixed at capture) parks its batch there.
+        Ts = T + self.B
+        self.c_flow = g.tensor((Ts, self.h, self.w, 2), name='chunk_flow')
+        self.c_sigma = g.tensor((Ts, self.h, self.w, 1), name='chunk_sigma_trans')
+        self.c_meas = g.tensor((Ts, self.h, self.w, 4), name='chunk_meas')
+        for t, c in ((self.meas, self.c_meas), (self.flow, self.c_flow), (self.sigma_t, self.c_sigma)):
+            if t.base is not None or t.ld != t.C or t.ch_off != 0:
+                raise _lib.KfnError('scan input %r is not a dense root tensor: cannot be produced in place' % t.name)
+            t.rebind(c.storage, 0, t.C)
+        # ... and the flow-feature ring is LONG: [T + B + 1] maps instead of [B + 1].  Batch k's maps are written behind
+        # batch k-1's, so "the previous frame's map" is simply the slot before -- the per-batch hand-over copy of the last
+        # map to slot 0 happens once per chunk (at the start of heavy()), not once per batch.
+        ring = self.net.temp_feat_maps
+        self.ring_slots = T + self.B + 1
+        from .graph import Storage
+        ring_store = Storage(self.ring_slots * self.h * self.w * ring.C, ring.dtype)
+        g.storages.append(ring_store)
+        ring.rebind(ring_store, 0, ring.C)
+        self._ring_pos = 0          # ring slot that holds the map of the frame before the next batch
         self.c_rec = g.tensor((T, self.h, self.w, 4), name='chunk_records')
         self.c_temp = g.tensor((T, self.h, self.w, 4), name='chunk_temp') if emit_debug else None
         self.c_nis = g.tensor((T, self.h, self.w, 3), name='chunk_nis') if emit_debug else None
@@ -146,10 +165,10 @@ class KFNetEngine(object):
         fb = self.H * self.W * 3
         _lib.check(self.lib.kfn_memcpy_d2d(self.images.ptr, dev_prev_frame.data_ptr(), fb, stream), 'prime')
         tower_ops = [op for op in self.net.frame_ops if op in self.net.feat_tower.ops]
-        self.graph.run(stream, tower_ops, active=(1, self.B))   # one frame only
         ring = self.net.temp_feat_maps
-        self.handover.src = ring.batch(1, 1)
-        self.handover.launch(self.lib, stream)
+        ring.slide(0)
+        self.graph.run(stream, tower_ops, active=(1, self.B))   # one frame only -> ring slot 1
+        self._ring_pos = 1
 
     def heavy(self, dev_frames, T=None, dst0=0):
         """State-independent phase for frames [0,T) of `dev_frames` -> chunk scan buffers
@@ -158,11 +177,25 @@ class KFNetEngine(object):
         if dst0 + T > self.max_chunk:
             raise ValueError('chunk of %d frames (at slot %d) exceeds max_chunk=%d' % (T, dst0, self.max_chunk))
         stream = self._stream()
+        lib = self.lib
         ring = self.net.temp_feat_maps
         hw = self.hw
+        per_map = hw * ring.C
+        if self._ring_pos != 0:
+            # once per chunk: the map of the frame before this chunk (the last slot written, or prime()'s) -> slot 0
+            ring.slide(0)
+            _lib.check(lib.kfn_memcpy_d2d(ring.ptr, ring.ptr + self._ring_pos * per_map * 4, per_map * 4, stream), 'ring hand-over')
+            self._ring_pos = 0
         for s0 in range(0, T, self.B):
             cnt = min(self.B, T - s0)
+            d0 = dst0 + s0
             self._set_batch_images(dev_frames, s0, cnt, stream)
+            fixed = self.use_graph            # hipGraph replay: the captured pointers cannot move
+            slot = self.max_chunk if fixed else d0
+            self.meas.slide(slot * hw * 4)
+            self.flow.slide(slot * hw * 2)
+            self.sigma_t.slide(slot * hw)
+            ring.slide(0 if fixed else self._ring_pos * per_map)
             if self.use_graph and cnt == self.B:
                 self._replay_heavy_graph()
             elif self.two_streams:
@@ -176,13 +209,13 @@ class KFNetEngine(object):
                 main.wait_event(self.ev_side)
             else:
                 self.graph.run(stream, self.heavy_ops, active=(cnt, self.B))   # partial batches cost their share
-            lib = self.lib
-            d0 = dst0 + s0
-            _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + d0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
-            _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + d0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')
-            _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + d0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
-            self.handover.src = ring.batch(cnt, 1)
-            self.handover.launch(lib, stream)
+            if fixed:
+                _lib.check(lib.kfn_memcpy_d2d(self.c_flow.ptr + d0 * hw * 8, self.flow.ptr, cnt * hw * 8, stream), 'cp flow')
+                _lib.check(lib.kfn_memcpy_d2d(self.c_sigma.ptr + d0 * hw * 4, self.sigma_t.ptr, cnt * hw * 4, stream), 'cp sig')
+                _lib.check(lib.kfn_memcpy_d2d(self.c_meas.ptr + d0 * hw * 16, self.meas.ptr, cnt * hw * 16, stream), 'cp meas')
+                _lib.check(lib.kfn_memcpy_d2d(ring.ptr, ring.ptr + cnt * per_map * 4, per_map * 4, stream), 'ring hand-over')
+            else:
+                self._ring_pos += cnt
 
     def _launch_heavy_full(self, stream_ptr, main):
         """Full-batch heavy phase on (main, side) streams; used directly and under capture."""

@@ -83,6 +83,7 @@ class Tensor(object):
             self.storage = Storage(n * h * w * c, dtype)
             self._ld = c
             self._off = 0
+            self._slot = 0      # element offset of the tensor inside its buffer (slide(): a window that moves per batch)
             graph.storages.append(self.storage)
 
     # -- TF-flavoured introspection ----------------------------------------------------
@@ -113,7 +114,7 @@ class Tensor(object):
     def elem_off(self):
         """Element offset of this view's batch window from the start of the root buffer."""
         if self.base is None:
-            return 0
+            return self._slot
         _, h, w, _ = self.base.shape
         return self.base.elem_off + self.rel_batch * h * w * self.base.ld
 
@@ -132,6 +133,16 @@ class Tensor(object):
         self.storage = storage
         self._off = ch_off
         self._ld = ld
+
+    def slide(self, elems):
+        """Move this root tensor to element offset `elems` of its buffer: the launches that write / read it and every
+        view of it follow at their next launch (pointers are taken at launch time).  The engine slides a [B,...] output
+        along a [T,...] chunk buffer so that a batch's results land where the scan reads them (no copy)."""
+        assert self.base is None
+        n, h, w, _ = self.shape
+        if elems < 0 or elems + n * h * w * self._ld > self.storage.numel:
+            raise ValueError('slide(%d) leaves the buffer of tensor %r' % (elems, self.name))
+        self._slot = int(elems)
 
     def channels(self, start, count, name=None):
         """tf.slice on the channel axis as a zero-copy view."""
@@ -339,6 +350,28 @@ def pack_winograd_s2_kernel_b(w):
     nc, _, cp, _ = u.shape
     v = u.reshape(nc, 8, 2, cp, 4, 2)                   # [chunk][pair][f][n][k][s]
     return np.ascontiguousarray(v.transpose(0, 1, 3, 4, 2, 5).reshape(nc, 8, cp, 16))
+
+
+def pack_winograd_s2_kernel_c(w):
+    """TF HWIO [3,3,Cin,Cout] -> the 36 weight fragments [Cin/16][36][cout_pad][16] of the F(4,2) form of kfn_conv2d_winograd_s2
+    (kfn_conv_desc.wino_form = KFN_WINO_FORM_S2_F42, csrc/kfn_wino_s2c.hip: the four stride-1 polyphase filters on 4x4 output
+    tiles).  With G = [[1/2,0],[1/2,1/2],[1/6,-1/6],[1/6,1/3],[0,1]] (F(4,2), points {0,1,-1,2,inf}): fragments 0-24 =
+    (G g00 G^T)[xi][nu] of the 2x2 taps g00[a][b] = w[2a][2b]; 25-29 = G (w[0][1], w[2][1]) (the (even,odd) phase, transformed
+    along y); 30-34 = G (w[1][0], w[1][2]) ((odd,even), along x); 35 = w[1][1].  Transformed in fp64, rounded once to fp32.  Lane
+    (channel n, k) of a 16x16x4 B operand reads 16 contiguous bytes per (super-step, fragment): input channels 4k .. 4k+3."""
+    w = np.asarray(w, np.float64)
+    kh, kw, ci, co = w.shape
+    assert kh == 3 and kw == 3 and ci % 16 == 0
+    G = np.array([[0.5, 0.0], [0.5, 0.5], [1.0 / 6, -1.0 / 6], [1.0 / 6, 1.0 / 3], [0.0, 1.0]], np.float64)
+    u = np.zeros((36, ci, co), np.float64)
+    u[0:25] = np.einsum('xa,abio,nb->xnio', G, w[0::2, 0::2], G).reshape(25, ci, co)
+    u[25:30] = np.einsum('xa,aio->xio', G, w[0::2, 1])
+    u[30:35] = np.einsum('nb,bio->nio', G, w[1, 0::2])
+    u[35] = w[1, 1]
+    cp = -(-co // 32) * 32
+    out = np.zeros((36, cp, ci), np.float32)
+    out[:, :co, :] = u.transpose(0, 2, 1).astype(np.float32)
+    return np.ascontiguousarray(out.reshape(36, cp, ci // 16, 16).transpose(2, 0, 1, 3))
 
 
 def as_f16(pack):
@@ -1232,6 +1265,58 @@ class MemcpyOp(Op):
         assert self.src.ld == c and self.dst.ld == c and self.dst.shape == self.src.shape
         rc = lib.kfn_memcpy_d2d(self.dst.ptr, self.src.ptr, n * h * w * c * 4, stream)
         _lib.check(rc, 'kfn_memcpy_d2d')
+
+
+class ApplyTransformOp(Op):
+    """KFNet/util.py:12-40 as its own launch (kfn_apply_transform): y = (T [x;1])[0:3].  `transform`: host 4x4 or [B,4,4]."""
+
+    def __init__(self, x, y, transform):
+        self.name = 'apply_transform'
+        self.x, self.y = x, y
+        T = np.ascontiguousarray(np.asarray(transform, dtype=np.float32))
+        if T.shape not in ((4, 4), (x.shape[0], 4, 4)):
+            raise ValueError('ApplyTransform: transform must be 4x4 or Bx4x4, got %s' % (T.shape,))
+        self.transform = T
+        self._dev = None
+
+    def launch(self, lib, stream):
+        import torch
+        if self._dev is None:
+            self._dev = torch.from_numpy(self.transform.reshape(-1)).to(self.x.graph.device)
+        n, h, w, _ = self.x.shape
+        rc = lib.kfn_apply_transform(self.x.ptr, self.x.ld, self._dev.data_ptr(), int(self.transform.ndim == 3),
+                                     _scaled(n, self.x.graph), h, w, self.y.ptr, self.y.ld, stream)
+        _lib.check(rc, 'kfn_apply_transform')
+
+
+class PixelMapOp(Op):
+    """KFNet/util.py:42-63 (kfn_pixel_map): y[b,i,j] = (j, i), optionally normalised by the intrinsics."""
+
+    def __init__(self, y, normalize=False, u=0.0, v=0.0, focal_x=1.0, focal_y=1.0):
+        self.name = 'pixel_map'
+        self.y = y
+        self.normalize = bool(normalize)
+        self.u, self.v, self.fx, self.fy = float(u), float(v), float(focal_x), float(focal_y)
+
+    def launch(self, lib, stream):
+        n, h, w, _ = self.y.shape
+        rc = lib.kfn_pixel_map(self.y.ptr, self.y.ld, n, h, w, int(self.normalize), self.u, self.v, self.fx, self.fy, stream)
+        _lib.check(rc, 'kfn_pixel_map')
+
+
+class BilinearSamplerOp(Op):
+    """tools/util.py:3-94 (kfn_bilinear_sampler): imgs [B,Hs,Ws,C] sampled at coords [B,Ht,Wt,2] (x, y)."""
+
+    def __init__(self, imgs, coords, y):
+        self.name = 'bilinear_sampler'
+        self.imgs, self.coords, self.y = imgs, coords, y
+
+    def launch(self, lib, stream):
+        b, hs, ws, c = self.imgs.shape
+        _, ht, wt, _ = self.coords.shape
+        rc = lib.kfn_bilinear_sampler(self.imgs.ptr, self.imgs.ld, _scaled(b, self.imgs.graph), hs, ws, c, self.coords.ptr,
+                                      self.coords.ld, ht, wt, self.y.ptr, self.y.ld, stream)
+        _lib.check(rc, 'kfn_bilinear_sampler')
 
 
 class KalmanScanOp(Op):

@@ -625,6 +625,9 @@ def test_bench_compact_line_fits_the_drivers_reader(tmp_path, capsys):
     side = json.load(open(args.detail))
     assert side['handoff']['error'].endswith('x' * 100) and side['sharding_cyclic']['tail_ms'] is None
     assert d2['detail_file'].endswith('detail.json')
+    # one entry point, called once (a duplicated `if __name__ == '__main__'` block ran the whole bench twice and printed two lines)
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert src.count("__name__ == '__main__'") == 1 and src.rstrip().endswith('main()')
 
 
 def test_f43_split_k_is_chosen_for_single_frames_only():

@@ -1,6 +1,8 @@
 """Known-answer tests for the CPU oracle, derived analytically from the cited reference
 code.  These are the only pins the oracle has: the reference cannot
 run here (no TensorFlow) and ships no golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -261,6 +263,76 @@ def test_polyphase_f22_stride2_identity():
                         if oy < H // 2 and ox < W // 2:
                             got[im, oy, ox] = y[di][dj]
     assert np.abs(got - ref).max() < 1e-5     # the fragments are stored in fp32
+
+
+def test_polyphase_f42_stride2_identity():
+    """The algebra behind the F(4,2) form of kfn_conv2d_winograd_s2 (csrc/kfn_wino_s2c.hip), on the CPU against the oracle's own
+    stride-2 convolution with the fragments kfnet_amd.graph.pack_winograd_s2_kernel_c produces: the four polyphase filters on
+    4x4 output tiles under F(4,2) -- B^T along two-tap axes, C (4 values -> accumulator indices {0,1,2,4}) along one-tap axes --
+    81 products into the 25 accumulators M[xi][nu], output Y = A^T M A, bias in M[1][1].  Positions / fragments / accumulators /
+    LDS order as in the kernel's tables."""
+    from kfnet_amd.graph import pack_winograd_s2_kernel_c
+    rng = np.random.default_rng(12)
+    AT = np.array([[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 0], [0, 1, -1, 8, 1]], np.float64)
+    BT = np.array([[2, -1, -2, 1, 0], [0, 2, 1, -1, 0], [0, -2, 3, -1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]], np.float64)
+    CT = np.array([[1, 0, -1, 0], [0, .5, .5, 0], [0, -.5, .5, 0], [0, -1, 0, 1]], np.float64)
+    IDX = [0, 1, 2, 4]
+    assert np.allclose(AT[:, IDX] @ CT, np.eye(4))          # C is the inverse of A^T restricted to the indices {0,1,2,4}
+    # the kernel's tables, rebuilt from their definition: round r = EE_r (5) EO_r (4) OE_r (4) OO_r (4, r < 4)
+    pos = []        # (slot, weight register, accumulator, fragment)
+    for r in range(5):
+        pos += [(r * 5 + nu, nu, r * 5 + nu, r * 5 + nu) for nu in range(5)]
+        pos += [(25 + r * 4 + j, 5, r * 5 + IDX[j], 25 + r) for j in range(4)]
+        pos += [(45 + i * 5 + r, 6, IDX[i] * 5 + r, 30 + r) for i in range(4)]
+        if r < 4:
+            pos += [(65 + r * 4 + j, 7, IDX[r] * 5 + IDX[j], 35) for j in range(4)]
+    assert len(pos) == 81 and sorted(p[0] for p in pos) == list(range(81))
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'kfnet_amd', 'csrc', 'kfn_wino_s2c.hip')).read()
+    def table(name):
+        m = re.search(r'constexpr int %s\[\w+\] = \{([^}]*)\}' % name, src)
+        return [int(v) for v in m.group(1).replace('\n', ' ').split(',')]
+    assert table('POS_BREG') == [p[1] for p in pos] and table('POS_ACC') == [p[2] for p in pos] and table('POS_FRAG') == [p[3] for p in pos]
+    rank = {p[0]: i for i, p in enumerate(pos)}
+    assert table('SLOT_IDX') == [rank[s] for s in range(81)]
+    for (n, H, W, ci, co) in [(2, 16, 24, 16, 5), (1, 8, 8, 32, 3)]:
+        x = rng.normal(size=(n, H, W, ci))
+        wt = rng.normal(size=(3, 3, ci, co)).astype(np.float32)
+        b = rng.normal(size=co)
+        ref = O.conv2d_same(x, wt.astype(np.float64), b, 2, False)
+        u = pack_winograd_s2_kernel_c(wt)                                  # [ci/16][36][cout_pad][16]
+        assert u.shape == (ci // 16, 36, 32, 16) and u.dtype == np.float32
+        U = u.transpose(1, 0, 3, 2).reshape(36, ci, u.shape[2])[:, :, :co].astype(np.float64)   # [frag][ci][co]
+        xp = np.pad(x, ((0, 0), (0, 1), (0, 1), (0, 0)))                   # zeros after the image
+        got = np.zeros_like(ref)
+        for im in range(n):
+            for ty in range(H // 8):
+                for tx in range(W // 8):
+                    d = xp[im, 8 * ty:8 * ty + 9, 8 * tx:8 * tx + 9]       # 9x9 patch
+                    slot = [None] * 81
+                    V = np.einsum('xm,mnc,yn->xyc', BT, d[0::2, 0::2], BT)
+                    for xi in range(5):
+                        for nu in range(5):
+                            slot[xi * 5 + nu] = V[xi, nu]
+                    V = np.einsum('xm,mjc,vj->xvc', BT, d[0::2, 1::2], CT)
+                    for xi in range(5):
+                        for j in range(4):
+                            slot[25 + xi * 4 + j] = V[xi, j]
+                    V = np.einsum('ui,inc,yn->uyc', CT, d[1::2, 0::2], BT)
+                    for i in range(4):
+                        for nu in range(5):
+                            slot[45 + i * 5 + nu] = V[i, nu]
+                    V = np.einsum('ui,ijc,vj->uvc', CT, d[1::2, 1::2], CT)
+                    for i in range(4):
+                        for j in range(4):
+                            slot[65 + i * 4 + j] = V[i, j]
+                    acc = [np.zeros(co) for _ in range(25)]
+                    acc[6] += b
+                    for (s, _, a, f) in pos:
+                        acc[a] += slot[s] @ U[f]
+                    M = np.stack(acc).reshape(5, 5, co)
+                    got[im, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = np.einsum('ix,xyo,jy->ijo', AT, M, AT)
+        assert np.abs(got - ref).max() < 2e-5     # the fragments are stored in fp32
 
 
 def test_window_fc_matrix_identity():
