@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _lib
 from ..graph import (Conv64RowsF16Op, ConvOp, CopyChannelsOp, FirstConvOp, pack_conv64_rows_kernel, Storage, Tensor, WinogradConvOp, WinogradFusedConvOp,
-                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_s2_kernel_b,
+                     WinogradS2ConvOp, WinogradF43ConvOp, WindowFcConvOp, as_f16, pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_s2_kernel_b, pack_winograd_s2_kernel_c,
                      as_f16x3, pack_bias, pack_conv_kernel, pack_deconv_kernel, pack_first_kernel,
                      pack_bias_x4, pack_window_fc_kernel, pack_winograd_fused_kernel, pack_winograd_kernel,
                      pack_winograd_s2_kernel, current_scope, pack_conv_kernel_chunked)
@@ -330,6 +330,12 @@ class Network(object):
         if (k == 3 and strides == 2 and smin and cin >= smin and filters >= 128
                 and WinogradS2ConvOp.supported(input.shape, cin, filters)
                 and g.winograd_lds_fits(2, cin, filters, _lib.WINO_FORM_S2_EIGHT_WAVE if e8 else 0)):
+            if (g.winograd_s2_f42 and WinogradS2ConvOp.f42_supported(input.shape, cin, filters)
+                    and WinogradS2ConvOp.f42_workgroups(y.shape) >= g.winograd_s2_f42_min_workgroups
+                    and g.winograd_lds_fits(2, cin, filters, _lib.WINO_FORM_S2_F42)):
+                kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel_c)
+                self._emit(WinogradS2ConvOp(name, input, y, kern, bias, relu, f42=True))
+                return y
             kern = g.variable(name + '/kernel', (k, k, cin, filters), pack_winograd_s2_kernel_b if e8 else pack_winograd_s2_kernel)
             ksplit = 1
             if e8 and g.winograd_s2_max_k_split > 1 and filters % 4 == 0:

@@ -802,8 +802,14 @@ class WinogradS2ConvOp(ConvOp):
 
     SS_US = 5.3      # one super-step of wino_s2b_kernel: 200 MFMAs of 32 cycles on each of two waves per SIMD
 
-    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32, eight_wave=False, k_split=1, workspace=None):
+    def __init__(self, name, x, y, kernel, bias, relu, operand_dtype=_lib.OPERAND_F32, eight_wave=False, k_split=1, workspace=None,
+                 f42=False):
         ConvOp.__init__(self, name, x, y, kernel, bias, 3, 3, 2, relu, operand_dtype=operand_dtype)
+        # wino_s2c_kernel: polyphase + F(4,2) on 4x4 output tiles, 81 instead of 100 products per 16 outputs (fp32; H, W multiples
+        # of 8; weights pack_winograd_s2_kernel_c).  Blocks of 16x16 output pixels: for launches that fill the chip several times.
+        self.f42 = bool(f42) and operand_dtype == _lib.OPERAND_F32
+        if self.f42:
+            eight_wave, k_split = False, 1
         self.k_split = int(k_split)      # > 1: kfn_conv2d_winograd_s2_splitk (eight-wave form, fp32) with a private workspace
         self.workspace = workspace
         # wino_s2b_kernel (two waves per SIMD on 16x16x4 MFMA tiles; fp32 operands; weights packed per pair of fragments,
@@ -812,7 +818,9 @@ class WinogradS2ConvOp(ConvOp):
 
     def desc(self):
         d = ConvOp.desc(self)
-        if self.eight_wave:
+        if self.f42:
+            d.wino_form = _lib.WINO_FORM_S2_F42
+        elif self.eight_wave:
             d.wino_form = _lib.WINO_FORM_S2_EIGHT_WAVE
         return d
 
@@ -821,7 +829,40 @@ class WinogradS2ConvOp(ConvOp):
         n, h, w, _ = x_shape
         return cin % 16 == 0 and h % 2 == 0 and w % 2 == 0 and (h // 2 + 1) // 2 >= 4
 
+    @staticmethod
+    def f42_supported(x_shape, cin, cout, ldy=None, y_ch_off=0):
+        """kfn::wino_s2c_supported's pointer-free conditions (csrc/kfn_wino_s2c.hip)."""
+        n, h, w, _ = x_shape
+        ldy = cout if ldy is None else ldy
+        return (cin % 16 == 0 and h % 8 == 0 and w % 8 == 0 and h >= 32 and cout % 4 == 0 and ldy % 4 == 0 and y_ch_off % 4 == 0)
+
+    @staticmethod
+    def f42_workgroups(y_shape):
+        """Blocks of 4 x 4 tiles of 4x4 OUTPUT pixels (batch rows packed) x column blocks of 128 output channels."""
+        n, ho, wo, cout = y_shape
+        th, tw = -(-ho // 4), -(-wo // 4)
+        return (-(-tw // 4)) * (-(-(n * th) // 4)) * (-(-cout // 128))
+
+    def resolve(self):
+        """After every concat has re-bound its producers: the F(4,2) form and the split-K form store 16 bytes at a time."""
+        y = self.y
+        if self.f42 and not self.f42_supported(self.x.shape, self.x.shape[3], y.shape[3], y.ld, y.ch_off):
+            if self.kernel.storage is not None:
+                raise _lib.KfnError('%s: output window (ld %d, channel offset %d) cannot take the F(4,2) stride-2 form and its weights '
+                                    'are already uploaded in that layout' % (self.name, y.ld, y.ch_off))
+            self.f42, self.eight_wave = False, True          # the F(2,2) eight-wave form has a dword-store path
+            self.kernel.pack = pack_winograd_s2_kernel_b
+        if self.k_split > 1 and (y.ld % 4 != 0 or y.ch_off % 4 != 0):
+            # (ADVICE r5) kfn_conv2d_winograd_s2_splitk needs a 16-byte aligned output with ldy % 4 == 0; the plain eight-wave
+            # launch takes the dword-store path instead
+            self.k_split = 1
+            if self.workspace is not None and self.workspace in self.x.graph.storages:
+                self.x.graph.storages.remove(self.workspace)
+            self.workspace = None
+
     def kernel_name(self, lib):
+        if self.f42:
+            return 'wino_s2c_kernel'
         if self.k_split > 1:
             return 'wino_s2b_kernel[split-K %d] + splitk_reduce_kernel' % self.k_split
         if self.eight_wave:
@@ -833,6 +874,10 @@ class WinogradS2ConvOp(ConvOp):
         8x4 tiles (batch rows packed), output channels padded to the workgroup's 128."""
         n, ho, wo, cout = self.y.shape
         n = _scaled(n, self.x.graph)
+        if self.f42:      # 81 products per 4x4-output tile and input channel, blocks of 4x4 tiles
+            th, tw = -(-ho // 4), -(-wo // 4)
+            tiles = (-(-tw // 4) * 4) * (-(-(n * th) // 4) * 4)
+            return 2.0 * 81 * tiles * (-(-cout // 128) * 128) * self.x.shape[3]
         th, tw = (ho + 1) // 2, (wo + 1) // 2
         tiles = (-(-tw // 8) * 8) * (-(-(n * th) // 4) * 4)
         return 2.0 * 25 * tiles * (-(-cout // 128) * 128) * self.x.shape[3]
@@ -841,6 +886,8 @@ class WinogradS2ConvOp(ConvOp):
         """Blocks of 8 x 4 tiles of 2x2 OUTPUT pixels (batch rows packed) x column blocks of 128 output channels."""
         n, ho, wo, cout = self.y.shape
         n = _scaled(n, self.x.graph)
+        if self.f42:
+            return self.f42_workgroups((n, ho, wo, cout))
         th, tw = (ho + 1) // 2, (wo + 1) // 2
         return (-(-tw // 8)) * (-(-(n * th) // 4)) * (-(-cout // 128)) * max(1, self.k_split)
 
@@ -1435,6 +1482,11 @@ class Graph(object):
         # ... and of the stride-2 polyphase kernel (wino_s2b_kernel; batch 32, same box: conv2a 4.65 -> 4.54 ms, conv3a 7.35 ->
         # 7.22, conv4a 7.19 -> 7.09)
         self.winograd_s2_eight_wave = True
+        # stride-2 layers through the polyphase + F(4,2) kernel (wino_s2c_kernel: 81 instead of 100 products per 16 outputs, 8-14 %
+        # faster per layer at the bench batch) when the launch has at least this many of its 16x16-pixel x 128-channel workgroups
+        # (4 rounds of 256 CUs); below that the F(2,2) kernel with its smaller blocks (and split-K) fills the chip better.  0 = never.
+        self.winograd_s2_f42 = True
+        self.winograd_s2_f42_min_workgroups = 1024
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM

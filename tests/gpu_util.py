@@ -79,12 +79,12 @@ def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, confi
       kind 'wino'  kfn_conv2d_winograd        (two kernels + workspace; F(2x2,3x3))
            'fused' kfn_conv2d_winograd_fused  (form 0 = the library's routing, 1 = KFN_WINO_FORM_ONE_WAVE)
            'f43'   kfn_conv2d_winograd_f43    (form 2 = four waves, 3 = eight waves)
-           's2'    kfn_conv2d_winograd_s2     (stride 2; form 0 = four waves, 4 = eight waves)
+           's2'    kfn_conv2d_winograd_s2     (stride 2; form 0 = four waves, 4 = eight waves, 5 = the F(4,2) form)
     Input and output live in wider buffers (ldx = Cin + ldx_pad filled with 9.0 behind Cin, ldy = Cout + ldy_pad); guard
     rows behind the output and the columns behind Cout must come back untouched.  Returns y [N,Ho,Wo,Cout] np fp32."""
     import torch
     from kfnet_amd.graph import (pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_fused_kernel,
-                                 pack_winograd_kernel, pack_winograd_s2_kernel, pack_winograd_s2_kernel_b)
+                                 pack_winograd_kernel, pack_winograd_s2_kernel, pack_winograd_s2_kernel_b, pack_winograd_s2_kernel_c)
     lib = _lib.load()
     n, h, w, ci = x.shape
     co = wt.shape[3]
@@ -116,7 +116,7 @@ def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, confi
         _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), stream()),
                    'kfn_conv2d_winograd_f43')
     elif kind == 's2':
-        du = dev((pack_winograd_s2_kernel_b if form == 4 else pack_winograd_s2_kernel)(wt))
+        du = dev({4: pack_winograd_s2_kernel_b, 5: pack_winograd_s2_kernel_c}.get(form, pack_winograd_s2_kernel)(wt))
         _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), bp, y.data_ptr(), stream()),
                    'kfn_conv2d_winograd_s2')
     else:

@@ -1095,6 +1095,64 @@ def test_winograd_s2_vs_oracle(case, relu, form):
     _check_err(err, x, wt, 'f22s2', 'wino s2 %s relu %d form %d' % (case, relu, form))
 
 
+# the F(4,2) form (wino_s2c_kernel, KFN_WINO_FORM_S2_F42): H, W multiples of 8, H >= 32; blocks straddling images (Th % 4 != 0),
+# ragged tile-block columns and channel tiles, many super-steps, SCoordNet's three layers at one frame
+S2C_CASES = [(1, 32, 32, 16, 128), (2, 40, 48, 32, 160), (1, 120, 160, 64, 128), (3, 32, 40, 48, 36), (5, 32, 32, 16, 8),
+             (2, 64, 80, 256, 256), (7, 40, 32, 32, 136), (1, 64, 96, 512, 128), (1, 120, 160, 512, 1024)]
+
+
+@pytest.mark.parametrize('relu', [1, 0])
+@pytest.mark.parametrize('case', S2C_CASES)
+def test_winograd_s2_f42_vs_oracle(case, relu):
+    """kfn_conv2d_winograd_s2 with wino_form = KFN_WINO_FORM_S2_F42 (polyphase + F(4,2) on 4x4 output tiles: 81 products into 25
+    accumulators per 16 outputs) == the oracle's stride-2 SAME convolution up to fp32 round-off (error class 'f42s2': a CPU
+    emulation of the fp32 evaluation measures 50-100 units of sqrt(1 + K/256) eps32 S, direct 25-35); strided output window,
+    guard rows untouched; kfn_winograd_s2_supported answers for the form."""
+    import torch
+    from tests.gpu_util import dev, stream, sync
+    from kfnet_amd import _lib
+    from kfnet_amd.graph import pack_winograd_s2_kernel_c
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    ho, wo = h // 2, w // 2
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 19)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    ldy = co + 8
+    d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ci, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
+                      stride=2, relu=relu, wino_form=_lib.WINO_FORM_S2_F42)
+    assert lib.kfn_winograd_s2_supported(C.byref(d)) == 1
+    GUARD = 64
+    y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
+    dx, du, db = dev(x), dev(pack_winograd_s2_kernel_c(wt)), dev(b)
+    _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d), dx.data_ptr(), du.data_ptr(), db.data_ptr(), y.data_ptr(), stream()), 'wino_s2c')
+    sync()
+    got = y.cpu().numpy()
+    assert np.all(got[:, co:] == -5.0) and np.all(got[n * ho * wo:] == -5.0)
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 2, bool(relu))
+    err = np.abs(got[:n * ho * wo, :co].reshape(ref.shape) - ref).max()
+    _check_err(err, x, wt, 'f42s2', 'wino s2c %s relu %d' % (case, relu))
+
+
+def test_winograd_s2_f42_refuses_what_it_cannot_take():
+    """H or W not a multiple of 8, H < 32, Cin % 16, Cout % 4, ldy % 4: not supported -> KFN_ERR_UNSUPPORTED with a message, nothing
+    launched (the graph routes such layers to the F(2,2) form)."""
+    import torch
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 16, device='cuda')
+    for kw_ in [dict(H=36, W=32), dict(H=32, W=36), dict(H=24, W=32), dict(Cin=24), dict(Cout=6), dict(ldy=130)]:
+        a = dict(N=1, H=32, W=32, Cin=16, ldx=16, Cout=8, cout_pad=32, ldy=8, kh=3, kw=3, stride=2, relu=0, wino_form=_lib.WINO_FORM_S2_F42)
+        a.update(kw_)
+        if 'Cin' in kw_:
+            a['ldx'] = kw_['Cin']
+        d = _lib.ConvDesc(**a)
+        assert lib.kfn_winograd_s2_supported(C.byref(d)) == 0, kw_
+        rc = lib.kfn_conv2d_winograd_s2(C.byref(d), buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == -3 and b'F(4,2)' in lib.kfn_last_error(), kw_
+
+
 @pytest.mark.parametrize('case', [(1, 16, 16, 16, 128), (2, 14, 18, 32, 160), (1, 120, 160, 64, 128), (2, 60, 80, 256, 256),
                                   (17, 14, 16, 32, 136)])
 def test_winograd_s2_fp16_operands(case):
@@ -1428,6 +1486,10 @@ BORDER_KERNELS = [
     ('s2', 0, (2, 14, 18, 32, 160), 2e-6),       # wino_s2_kernel: odd output sizes (7x9), pad (0,1)
     ('s2', 4, (2, 14, 18, 32, 160), 2e-6),       # wino_s2b_kernel
     ('s2', 4, (1, 30, 34, 48, 36), 2e-6),        # dword-store path (ldy = Cout + 8 with Cout % 4 == 0 still wide; ragged channels)
+    # wino_s2c_kernel (polyphase + F(4,2)): G holds sixths like F(4x4,3x3)'s, so U is rounded (a CPU emulation of the fp32
+    # evaluation on these inputs: 1.1e-5 / 0.6e-5 absolute).  Th = 5: the 4-row tile blocks straddle the two images; Tw = 6 ragged
+    ('s2', 5, (2, 40, 48, 32, 160), 4e-5),
+    ('s2', 5, (1, 32, 72, 48, 36), 4e-5),        # ragged channels (Cout = 36 of 128), Tw = 9
 ]
 
 

@@ -112,9 +112,32 @@ def test_default_routes_of_the_3x3_layers():
     for (ci, co, pp) in [(0, 0, 0), (13, 39, 35), (6, 17, 22), (9, 5, 7)]:
         assert ub[ci // 8, pp // 2, co, 4 * ((ci % 8) // 2) + 2 * (pp % 2) + ci % 2] == ua[ci // 8, pp, co, ci % 8]
     assert names['feat3'] == 'wino2_kernel'                  # 32 -> 32: one wave per 32 output channels
-    for n in ('conv2a', 'conv3a', 'conv4a', 'feat6'):
+    # stride 2: polyphase + F(4,2) (wino_s2c_kernel, round 6) where the launch has >= 1024 of its 16x16-pixel workgroups (batch 4:
+    # conv2a 2400, conv3a 1200), the F(2,2) eight-wave form below that (conv4a 600, feat6 75)
+    for n in ('conv2a', 'conv3a'):
+        assert names[n] == 'wino_s2c_kernel', (n, names[n])
+    for n in ('conv4a', 'feat6'):
         assert names[n] == 'wino_s2b_kernel', (n, names[n])      # the eight-wave form (Graph.winograd_s2_eight_wave)
-    gs, _ = _build(4, winograd_s2_eight_wave=False)
+    kc = [op for op in g.ops if op.name == 'conv3a'][0]
+    assert kc.kernel.pack.__name__ == 'pack_winograd_s2_kernel_c' and kc.desc().wino_form == 5 and kc.workgroups() == 1200
+    assert kc.mfma_flops() == 2.0 * 81 * (4 * 30 * 40) * 512 * 256           # 81 products per 4x4 tile and channel pair
+    def s2_layers(gr):      # SCoordNet's (the first of each name: OFlowNet has layers of the same names on its 8x8 windows)
+        first = {}
+        for op in gr.ops:
+            first.setdefault(op.name, op)
+        return [first[nm] for nm in ('conv2a', 'conv3a', 'conv4a')]
+    g20, _ = _build(20)
+    assert all(op.kernel_name(lib) == 'wino_s2c_kernel' for op in s2_layers(g20))
+    g1, _ = _build(1)
+    assert all(op.kernel_name(lib).startswith('wino_s2b_kernel') for op in s2_layers(g1))
+    gn, _ = _build(20, winograd_s2_f42=False)
+    assert all(op.kernel_name(lib) == 'wino_s2b_kernel' for op in s2_layers(gn))
+    # a concat that re-binds the output to a window the 16-byte stores cannot take: resolve() falls back to the F(2,2) form
+    kf = s2_layers(g20)[2]
+    kf.y._ld, kf.y._off = kf.y.shape[3] + 2, 2
+    kf.resolve()
+    assert kf.kernel_name(lib) == 'wino_s2b_kernel' and kf.kernel.pack.__name__ == 'pack_winograd_s2_kernel_b' and kf.desc().wino_form == 4
+    gs, _ = _build(4, winograd_s2_eight_wave=False, winograd_s2_f42=False)
     ks = [op for op in gs.ops if op.name == 'conv3a'][0]
     assert ks.kernel_name(lib) == 'wino_s2_kernel' and ks.kernel.pack.__name__ == 'pack_winograd_s2_kernel' and ks.desc().wino_form == 0
     from kfnet_amd.graph import pack_winograd_s2_kernel, pack_winograd_s2_kernel_b

@@ -19,12 +19,13 @@ ORDER = int(os.environ.get('MB_WINO_ORDER', '0'))   # kfn_conv_desc.wino_order: 
 N = int(os.environ.get('MB_BATCH', '16'))
 for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320, 256, 512), ('conv4a', 120, 160, 512, 1024)]:
     x = torch.randn(N * H * W * ci, device='cuda')
-    u = torch.randn(16 * co * ci, device='cuda') * 0.02
+    FORM = int(os.environ.get('MB_S2_FORM', '0'))       # 4 = the eight-wave form (wino_s2b_kernel), 5 = polyphase + F(4,2) (wino_s2c_kernel)
+    u = torch.randn((36 if FORM == 5 else 16) * co * ci, device='cuda') * 0.02
     w9 = torch.randn(co * 9 * ci, device='cuda') * 0.02
     y = torch.empty(N * (H // 2) * (W // 2) * co, device='cuda')
     F16 = os.environ.get('MB_F16', '') == '1'
     d = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, wino_order=ORDER,
-                      wino_form=int(os.environ.get('MB_S2_FORM', '0')))   # 4 = the eight-wave form (wino_s2b_kernel)
+                      wino_form=FORM)
     d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16, wino_order=ORDER)
     if F16:
         u = u.half(); w9 = w9.half()
@@ -32,5 +33,5 @@ for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320,
     t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d16 if F16 else d), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
     nominal = 2.0 * N * (H // 2) * (W // 2) * 9 * ci * co
     print('%-7s %3dx%3d C%4d->%4d: polyphase %.3f ms (%.1f TF executed, %.1f nominal) | direct %.3f ms (%.1f TF)'
-          % (name, H, W, ci, co, t_s2, nominal * 25 / 36 / t_s2 / 1e9, nominal / t_s2 / 1e9, t_dir, nominal / t_dir / 1e9), flush=True)
+          % (name, H, W, ci, co, t_s2, nominal * (81 / 144 if FORM == 5 else 25 / 36) / t_s2 / 1e9, nominal / t_s2 / 1e9, t_dir, nominal / t_dir / 1e9), flush=True)
     del x, u, y, w9
