@@ -219,14 +219,12 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   const int pk = pq8 >> 1, ph = pq8 & 1;
   const int v_st = (pk * 16 + (pt ^ (2 * pk))) * 4 + 2 * ph;                                 // floats inside a slot
   const int n_super = p.Cin / SS_CH;
-  const int s_last = n_super - 1;
 
   // ---- CONSUMER: lane (tile row r of the A operand / channel n0 + r of the B operand, k) ----
   const int rl = lane & 15, kl = lane >> 4;
   const int v_rd = (kl * 16 + (rl ^ (2 * kl))) * 4;                                        // floats inside a slot
   const unsigned voff_b = (unsigned)(((n0 + rl) * 16 + kl * 4) * 4);
   const unsigned b_step = (unsigned)p.cout_pad * 64u;                                       // bytes between fragments
-  const int q_last = n_super * NFRAG - 1;
   const int n = n0 + rl;
   const bool n_ok = n < p.Cout;
   const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
@@ -241,10 +239,11 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   f32x4 bq[8];         // weight fragments: 5 (even,even) columns, (even,odd), (odd,even), centre
   f32x4 vq[2][5];      // V fragments (4 k-steps): [group parity][position of the group]
 
-  auto b_load = [&](auto rc, int fq) __attribute__((always_inline)) {      // register r <- fragment index fq (over all super-steps)
+  // register r <- fragment index fq (over all super-steps).  No clamp: the prefetches of the last super-step run past the packed
+  // weights, where the buffer descriptor's range check returns zeros that nobody consumes.
+  auto b_load = [&](auto rc, int fq) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
-    const int qc = fq < q_last ? fq : q_last;
-    bq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)qc * b_step, 0));
+    bq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)fq * b_step, 0));
   };
 
   auto run = [&](auto part_c) __attribute__((always_inline)) {
@@ -257,8 +256,9 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
       constexpr int i = decltype(ic)::value;
       constexpr int m = i / PW, nn = i % PW;
       constexpr int u = 2 * m + ((PART == 2 || PART == 3) ? 1 : 0), v = 2 * nn + ((PART == 1 || PART == 3) ? 1 : 0);
-      const int sc = ss < s_last ? ss : s_last;
-      const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(sc * (SS_CH * 4));
+      // (no clamp on ss either: the gathers behind the last super-step read the pixel's next bytes -- inside the tensor or cut off by
+      // the descriptor -- into V slots that are never consumed)
+      const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(ss * (SS_CH * 4));
       pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, gbase[u == 8][v == 8], so, 0));
     };
     // the transform, one 1-D line per call (NLINE lines): first the lines along n (patch rows), then along m
