@@ -332,11 +332,6 @@ def _main_sharded(a, W, size, rank, world):
         if a.synthetic > 0:
             from ..synth import synthetic_sequence, synthetic_transform
             from ..dist import chunk_bounds, needs_state
-            lo, hi = chunk_bounds(a.synthetic, world, rank)
-            # every rank generates only the frames it needs (frame t depends on (seed, t) alone)
-            first = lo - (1 if (hi > lo and needs_state(lo, RESET_PERIOD)) else 0)
-            part = synthetic_sequence(hi - first, a.height, a.width, start=first)
-            frames = _ShiftedFrames(part, first, a.synthetic)
             transform = np.linalg.inv(synthetic_transform())
             if a.sharding == 'cyclic':
                 # (the generator is a function of (seed, frame index): every rank synthesises only what its blocks need)
@@ -346,6 +341,11 @@ def _main_sharded(a, W, size, rank, world):
                 torch.cuda.synchronize()
                 dist.barrier()
                 return 0
+            lo, hi = chunk_bounds(a.synthetic, world, rank)
+            # every rank generates only the frames it needs (frame t depends on (seed, t) alone)
+            first = lo - (1 if (hi > lo and needs_state(lo, RESET_PERIOD)) else 0)
+            part = synthetic_sequence(hi - first, a.height, a.width, start=first)
+            frames = _ShiftedFrames(part, first, a.synthetic)
             eval_sharded(None, transform, W, a.output_folder, rank, world, link, a.NIS, image_size=size,
                          batch=a.batch, frames=frames, sequence_length=RESET_PERIOD)
         else:

@@ -68,12 +68,6 @@ def _same_out(n, s):
     return -(-n // s)
 
 
-def _scaled_batch(n, graph):
-    """Frames a launch really processes (the graph's `active` share of the batch it was built for) -- at build time the
-    whole batch."""
-    return n
-
-
 def _off_path(name):
     def fn(self, *a, **k):
         raise NotImplementedError(
@@ -301,10 +295,10 @@ class Network(object):
         # F(2x2): conv5 80 workgroups 0.287 -> 0.238 ms, conv6 40: 0.151 -> 0.123, feat5 40: 0.031 -> 0.022; from 160
         # workgroups up F(4x4) is ahead: conv4b at batch 1 0.288 against 0.479; profiles/r04_wino4_microbench.log, r4z)
         e8 = bool(g.winograd_f43_eight_wave)
-        wgs = WinogradF43ConvOp.workgroups((_scaled_batch(n, g), h, w, cin), filters)
+        wgs = WinogradF43ConvOp.workgroups((n, h, w, cin), filters)
         ksplit = 1
         if e8 and g.winograd_f43_max_k_split > 1:
-            ksplit = WinogradF43ConvOp.best_k_split(wgs, cin, _scaled_batch(n, g) * h * w * filters * 4, g.winograd_f43_max_k_split)
+            ksplit = WinogradF43ConvOp.best_k_split(wgs, cin, n * h * w * filters * 4, g.winograd_f43_max_k_split)
         f43_fills = (not fused_ok or wgs * ksplit >= g.winograd_f43_min_workgroups)
         if (k == 3 and strides == 1 and g.winograd_fused and f43 and cin >= f43 and filters >= f43 and f43_fills
                 and WinogradF43ConvOp.supported(input.shape, cin, filters, input.ld, y.ld, y.ch_off)

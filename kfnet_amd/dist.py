@@ -246,7 +246,11 @@ def iter_cyclic(eng, frames_of, total_frames, block, rank, world, link=None, sta
         link = TorchLink(link)
     if block > eng.max_chunk:
         raise ValueError('block %d exceeds the engine\'s max_chunk %d' % (block, eng.max_chunk))
-    w = world if link is not None else 1
+    if world > 1 and link is None:
+        #  without a link the blocks of the other ranks would be skipped and no state handed over: silently wrong
+        # records.  A single process that wants the whole sequence passes world = 1.
+        raise ValueError('iter_cyclic: world = %d needs a state link (kfnet_amd.dist.make_link); pass world = 1 to run every block here' % world)
+    w = world
     for j, lo, hi in cyclic_blocks(total_frames, block, rank, w):
         n = hi - lo
         need = needs_state(lo, eng.reset_period)

@@ -275,18 +275,25 @@ class KFNetEngine(object):
         # stage every sequence's scan inputs at [s*T, (s+1)*T) of the chunk buffers
         for s in range(S):
             self.heavy(dev_seqs[s], T, dst0=s * T)
-        states = torch.zeros(S * hw * 4, device=self.device)
-        rec = torch.empty(S * T * hw * 4, device=self.device)
-        d = _lib.KalmanDesc(S=S, T=T, H=self.h, W=self.w, t0=0, reset_period=self.reset_period,
-                            min_uncertainty=self.net.min_uncertainty, nis_gate=self.nis_gate,
-                            has_transform=int(self.transform is not None))
-        if self.transform is not None:
-            for i, v in enumerate(np.asarray(self.transform, np.float32)[:3, :4].reshape(-1)):
-                d.transform[i] = float(v)
+        # scan buffers of this (S, T): allocated once and kept (no allocation inside a timed / captured region); the returned
+        # records are a view of the cached buffer, valid until the next call -- the contract of records() for process()
+        key = (S, T)
+        if getattr(self, '_seq_key', None) != key:
+            d = _lib.KalmanDesc(S=S, T=T, H=self.h, W=self.w, t0=0, reset_period=self.reset_period,
+                                min_uncertainty=self.net.min_uncertainty, nis_gate=self.nis_gate,
+                                has_transform=int(self.transform is not None))
+            if self.transform is not None:
+                for i, v in enumerate(np.asarray(self.transform, np.float32)[:3, :4].reshape(-1)):
+                    d.transform[i] = float(v)
+            import ctypes as C
+            need = C.c_size_t(0)
+            _lib.check(lib.kfn_kalman_scan_scratch_bytes(C.byref(d), C.byref(need)), 'kfn_kalman_scan_scratch_bytes')
+            self._seq_bufs = (d, torch.zeros(S * hw * 4, device=self.device), torch.empty(S * T * hw * 4, device=self.device),
+                              torch.empty((need.value + 3) // 4, device=self.device) if need.value else None)
+            self._seq_key = key
         import ctypes as C
-        need = C.c_size_t(0)
-        _lib.check(lib.kfn_kalman_scan_scratch_bytes(C.byref(d), C.byref(need)), 'kfn_kalman_scan_scratch_bytes')
-        scratch = torch.empty((need.value + 3) // 4, device=self.device) if need.value else None
+        d, states, rec, scratch = self._seq_bufs
+        _lib.check(lib.kfn_memset(states.data_ptr(), 0, S * hw * 16, stream), 'kfn_memset states')
         _lib.check(lib.kfn_kalman_scan(C.byref(d), self.c_flow.ptr, self.c_sigma.ptr, self.c_meas.ptr,
                                        states.data_ptr(), rec.data_ptr(), None, None,
                                        scratch.data_ptr() if scratch is not None else None, stream), 'kfn_kalman_scan')

@@ -269,6 +269,12 @@ class StreamedSequence(object):
         # where the consumer thread's wall time goes (seconds): waiting for the loader's next chunk, enqueueing a chunk's work,
         # waiting for a chunk's records; `consumer` (the caller's time between two yields) is the rest of the wall time
         st = self.stats = {'loader_wait': 0.0, 'enqueue': 0.0, 'records_wait': 0.0, 'chunks': 0, 'loader_wait_first': 0.0}
+        # a staging buffer of the loader must not be refilled while its upload is still in flight: with `depth` chunks in flight
+        # here the loader needs depth + 1 rotating buffers (ChunkLoader's docstring) -- checked, not assumed
+        ld = getattr(chunks, 'depth', None)
+        if ld is not None and int(ld) < self.depth + 1:
+            raise ValueError('StreamedSequence(depth=%d) needs a loader with at least %d staging buffers, got depth=%d: a buffer '
+                             'would be refilled while its host-to-device copy is still running' % (self.depth, self.depth + 1, int(ld)))
         it = iter(chunks)
         k = -1
         while True:

@@ -465,7 +465,7 @@ def test_config5_batch_independence_at_full_size():
 def test_records_are_reproducible_under_memory_load(cfg):
     """The whole path, fp32 (config 3's geometry) and fp16 (config 5's), run again and again while another stream keeps the
     memory system busy: every pass bit-identical to an unloaded one.  (What round 5's store hazard broke for config 5 --
-    DESIGN 3.1j -- checked end to end: two towers on two streams plus the copy stream, all kernels of the step.)"""
+    DESIGN 3.5 -- checked end to end: two towers on two streams plus the copy stream, all kernels of the step.)"""
     import torch
     from kfnet_amd.engine import KFNetEngine
     from kfnet_amd.synth import synthetic_sequence

@@ -697,7 +697,7 @@ def _side_stream_load(torch, side, big_a, big_b, copies=6):
 
 
 def test_conv3x3_c64_f16_is_reproducible_under_memory_load():
-    """Regression test of the 16-byte buffer-store hazard (kfn_common.h buffer_store_b128, DESIGN 3.1j): round 4's kernel sent,
+    """Regression test of the 16-byte buffer-store hazard (kfn_common.h buffer_store_b128, DESIGN 3.5): round 4's kernel sent,
     for one launch in seven of this shape while another stream loaded the memory system, the NEXT store's byte offset as the
     first dword of a few 16-byte pieces (the compiler reuses a store's dead data register at once; the store reads it late).
     40 launches beside 3 GB of copies each: all bit-identical to the first AND to an unloaded launch."""

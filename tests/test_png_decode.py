@@ -235,3 +235,57 @@ def test_mutated_files_never_crash_the_library(tmp_path):
     assert rc in (0, -1) and set(st) <= {_lib.PNG_OK, _lib.PNG_UNSUPPORTED, _lib.PNG_ERROR}
     assert st[0] == _lib.PNG_OK and np.array_equal(dst[0], decode_image(paths[0], (H, W)))
     assert list(st).count(_lib.PNG_ERROR) > 400          # most mutations are caught (bad inflate / sizes / chunks)
+
+
+def test_crc_and_chunk_order_are_checked(tmp_path):
+    """a damaged IHDR / PLTE / IDAT byte (CRC left as it was), a first chunk that is not IHDR and a second IHDR are
+    errors, as for libpng (the reference's tf.image.decode_png) and PIL; a damaged ANCILLARY chunk is not."""
+    from kfnet_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    rows = [_pack(rng.integers(0, 4, size=W), 2) for _ in range(H)]
+    pal = rng.integers(0, 256, size=12, dtype=np.uint8).tolist()
+    good = tmp_path / 'good.png'
+    _write_png(good, rows, 3, 2, [y % 5 for y in range(H)], pal, idat_pieces=2)
+    data = good.read_bytes()
+
+    def chunks(b):
+        out, pos = [], 8
+        while pos < len(b):
+            n = struct.unpack('>I', b[pos:pos + 4])[0]
+            out.append((b[pos + 4:pos + 8], pos, n))
+            pos += 12 + n
+        return out
+    at = {}
+    for t, pos, n in chunks(data):
+        at.setdefault(t, (pos, n))
+    cases = {}
+    for t in (b'IHDR', b'PLTE', b'IDAT', b'tEXt'):
+        pos, n = at[t]
+        b = bytearray(data)
+        b[pos + 8 + n - 1] ^= 0x01             # last body byte of the chunk, CRC untouched
+        cases[t.decode()] = bytes(b)
+    ih_pos, ih_n = at[b'IHDR']
+    ihdr = data[ih_pos:ih_pos + 12 + ih_n]
+    tx_pos, tx_n = at[b'tEXt']
+    text = data[tx_pos:tx_pos + 12 + tx_n]
+    cases['text_first'] = data[:8] + text + ihdr + data[tx_pos + 12 + tx_n:]
+    cases['two_ihdr'] = data[:8] + ihdr + ihdr + data[8 + len(ihdr):]
+    names = ['good'] + sorted(cases)
+    paths = [str(good)]
+    for k in names[1:]:
+        q = tmp_path / (k + '.png')
+        q.write_bytes(cases[k])
+        paths.append(str(q))
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(q) for q in paths])
+    st = (C.c_int * n)()
+    dst = np.zeros((n, H, W, 3), np.uint8)
+    lib.kfn_decode_png_rgb8(arr, n, H, W, dst.ctypes.data, st, 2)
+    got = dict(zip(names, list(st)))
+    assert got['good'] == _lib.PNG_OK and got['tEXt'] == _lib.PNG_OK
+    assert np.array_equal(dst[names.index('tEXt')], dst[0])
+    for k in ('IHDR', 'PLTE', 'IDAT', 'text_first', 'two_ihdr'):
+        assert got[k] == _lib.PNG_ERROR, (k, got[k])
+    assert b'CRC' in lib.kfn_last_error() or b'IHDR' in lib.kfn_last_error()
