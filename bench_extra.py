@@ -730,7 +730,7 @@ def measure_c5(args, device, T=None, min_seconds=None, with_parity=True):
                                 'oflow_*_kernel<true> = the window-resident OFlowNet launches with their convolutions on '
                                 'v_mfma_f32_16x16x16_f16; '
                                 'executed = algorithmic for all of them (no Winograd on this path: at fp16 rates the direct '
-                                'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- DESIGN 5d)'},
+                                'kernel is faster than the Winograd kernels, which are operand-bandwidth bound -- CHANGELOG round 3)'},
            'kernels_ms_per_batch': {k: {'launches': v[0], 'ms': round(v[2], 4),
                                         'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[1] else None}
                                     for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])[:8]},

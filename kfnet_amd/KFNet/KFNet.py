@@ -363,7 +363,7 @@ class KFNet():
             # (-0.4 ms per 16-frame batch).  f2 and f1 are then rounded separately and T - G is formed afterwards, so the
             # error is relative to |f| (unit-norm features: 2^-11) rather than to |f2 - f1|, and identical features no
             # longer cancel exactly (T uses fp16(sum of taps), G the per-tap fp16 weights); the flows of the two paths
-            # agree to 2.9e-3 px (config 5's tolerance test asserts < 0.05 px), DESIGN 5d.
+            # agree to 2.9e-3 px (config 5's tolerance test asserts < 0.05 px), DESIGN 4 (config 5).
             h16 = g.conv_operands == 'f16' and c % 32 == 0
             od = _lib.OPERAND_F16 if h16 else _lib.OPERAND_F32
             wg = g.derived_variable(conv0.kernel, 'cvol_G', as_f16(pack_cvol_g_kernel) if h16 else pack_cvol_g_kernel)

@@ -138,7 +138,7 @@ struct Wino4Args {
 
 #ifdef KFN_WINO4_PROF
 // (every lane stores the same value to the same address: a lane-0 branch would be divergent control flow, after which
-//  hipcc wraps the gathers' uniform descriptors in waterfall loops -- DESIGN 3.1d's measurement trap)
+//  hipcc wraps the gathers' uniform descriptors in waterfall loops -- the measurement trap of CHANGELOG round 2)
 #define KFN_STAMP4(i) (p.prof[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter())
 #ifndef KFN_W4_TL_KS
 #define KFN_W4_TL_KS 1      // the super-step whose 16-slot timeline is kept

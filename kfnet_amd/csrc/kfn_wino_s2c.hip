@@ -223,7 +223,10 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   // ---- CONSUMER: lane (tile row r of the A operand / channel n0 + r of the B operand, k) ----
   const int rl = lane & 15, kl = lane >> 4;
   const int v_rd = (kl * 16 + (rl ^ (2 * kl))) * 4;                                        // floats inside a slot
-  const unsigned voff_b = (unsigned)(((n0 + rl) * 16 + kl * 4) * 4);
+  // (channels past cout_pad -- a channel block of 128 that the packed weights fill only partly -- re-read the last packed channel:
+  //  their results are never stored, and no lane reaches beyond the last fragment)
+  const int nb = n0 + rl < p.cout_pad ? n0 + rl : p.cout_pad - 1;
+  const unsigned voff_b = (unsigned)((nb * 16 + kl * 4) * 4);
   const unsigned b_step = (unsigned)p.cout_pad * 64u;                                       // bytes between fragments
   const int n = n0 + rl;
   const bool n_ok = n < p.Cout;
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   f32x4 bq[8];         // weight fragments: 5 (even,even) columns, (even,odd), (odd,even), centre
   f32x4 vq[2][5];      // V fragments (4 k-steps): [group parity][position of the group]
 
-  // register r <- fragment index fq (over all super-steps).  No clamp: the prefetches of the last super-step run past the packed
-  // weights, where the buffer descriptor's range check returns zeros that nobody consumes.
+  // register r <- fragment index fq (over all super-steps).  The callers clamp the SUPER-STEP of a prefetch to the last one (once
+  // per super-step, scalar): the descriptor's range check covers the per-lane offset only, not the scalar one, so a prefetch
+  // past the last super-step must re-read valid memory (nobody consumes it).
   auto b_load = [&](auto rc, int fq) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     bq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)fq * b_step, 0));
@@ -256,8 +260,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
       constexpr int i = decltype(ic)::value;
       constexpr int m = i / PW, nn = i % PW;
       constexpr int u = 2 * m + ((PART == 2 || PART == 3) ? 1 : 0), v = 2 * nn + ((PART == 1 || PART == 3) ? 1 : 0);
-      // (no clamp on ss either: the gathers behind the last super-step read the pixel's next bytes -- inside the tensor or cut off by
-      // the descriptor -- into V slots that are never consumed)
+      // (ss is clamped by the caller, see b_load)
       const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(ss * (SS_CH * 4));
       pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, gbase[u == 8][v == 8], so, 0));
     };
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (KFN_S2C_LATE_GATHER) sfor<NPX>([&](auto ic) { p_gather(ic, 1); });
+    const int s_last = n_super - 1;
+    if constexpr (KFN_S2C_LATE_GATHER) sfor<NPX>([&](auto ic) { p_gather(ic, s_last < 1 ? s_last : 1); });
 
     // producer timetable inside a super-step (MFMA slots): gathers from slot 0 every GSTEP, transform lines from XSLOT every
     // XSTEP, [mid barrier at JMID], stores from SSLOT every SSTEP
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
     static_assert((KFN_S2C_LATE_GATHER || GSTEP * 25 <= XSLOT) && XSLOT + XSTEP * 10 <= JMID && SSLOT + 2 + SSTEP * 25 <= 4 * NPOS, "producer timetable");
     for (int ks = 0; ks < n_super; ++ks) {
       const int nxt = ks + 1;
+      const int ks1 = nxt < s_last ? nxt : s_last, ks2 = nxt + 1 < s_last ? nxt + 1 : s_last;      // clamped look-ahead super-steps
       const float* const rdD = smf + (NS + (ks & 1) * ND) * SLOT_F + v_rd;
       float* const stD = smf + (NS + (nxt & 1) * ND) * SLOT_F + v_st;
       // the first group: nothing of this super-step could be read before the barrier
@@ -341,11 +346,11 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
         // weights: the register's next fragment once this one has had its last k-step
         if constexpr (kst == 3 && frag_last_user(pp) && !(KFN_S2C_EXP & 16)) {
           constexpr int nf = next_frag(pp);
-          b_load(std::integral_constant<int, POS_BREG[pp]>{}, (ks + (nf >= 64 ? 1 : 0)) * NFRAG + (nf & 63));
+          b_load(std::integral_constant<int, POS_BREG[pp]>{}, (nf >= 64 ? ks1 : ks) * NFRAG + (nf & 63));
         }
-        if constexpr (!KFN_S2C_LATE_GATHER && j < NPX * GSTEP && j % GSTEP == 0 && !(KFN_S2C_EXP & 2)) p_gather(std::integral_constant<int, j / GSTEP>{}, nxt);
+        if constexpr (!KFN_S2C_LATE_GATHER && j < NPX * GSTEP && j % GSTEP == 0 && !(KFN_S2C_EXP & 2)) p_gather(std::integral_constant<int, j / GSTEP>{}, ks1);
         if constexpr (KFN_S2C_LATE_GATHER && j >= SSLOT + 2 && j < SSLOT + 2 + NPX * SSTEP && (j - SSLOT - 2) % SSTEP == 0 && !(KFN_S2C_EXP & 2))
-          p_gather(std::integral_constant<int, (j - SSLOT - 2) / SSTEP>{}, nxt + 1);
+          p_gather(std::integral_constant<int, (j - SSLOT - 2) / SSTEP>{}, ks2);
         if constexpr (j >= XSLOT && j < XSLOT + NLINE * XSTEP && (j - XSLOT) % XSTEP == 0 && !(KFN_S2C_EXP & 4)) p_line(std::integral_constant<int, (j - XSLOT) / XSTEP>{});
         if constexpr (j >= SSLOT && j < SSLOT + NPX * SSTEP && (j - SSLOT) % SSTEP == 0 && !(KFN_S2C_EXP & 8)) p_store(std::integral_constant<int, (j - SSLOT) / SSTEP>{}, stD);
         __builtin_amdgcn_sched_barrier(0);

@@ -37,7 +37,7 @@ python tools/pmc_traffic.py "$(finddb $OUT/k256FETCH_SIZE)" "$(finddb $OUT/k256W
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # the bench line below quotes these numbers (newest rNN file)
 i=0
 # (fourth group, round 5: the texture-addresser side -- TA_BUSY_avr = % of the kernel's time the address units are busy,
-#  vector-memory instructions issued, TA cycles stalled by the cache -- for the F(4x4,3x3) kernel's issue-rate analysis, DESIGN 3.1i)
+#  vector-memory instructions issued, TA cycles stalled by the cache -- for the F(4x4,3x3) kernel's issue-rate analysis, DESIGN 3.1)
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "TA_BUSY_avr SQ_INSTS_VMEM_RD TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
   i=$((i+1))
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $G -d $OUT/sq$i -- python $R/bench.py $SHORT > /dev/null 2> $OUT/sq$i.err )
