@@ -17,7 +17,10 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 ORDER = int(os.environ.get('MB_WINO_ORDER', '0'))   # kfn_conv_desc.wino_order: 0 default, 1 tile blocks fastest, 2 channel groups fastest
 N = int(os.environ.get('MB_BATCH', '16'))
-for (name, H, W, ci, co) in [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320, 256, 512), ('conv4a', 120, 160, 512, 1024)]:
+LAYERS = [('conv2a', 480, 640, 64, 256), ('conv3a', 240, 320, 256, 512), ('conv4a', 120, 160, 512, 1024)]
+if os.environ.get('MB_LAYERS'):      # e.g. MB_LAYERS='k64,480,640,64,256;k128,480,640,128,256': fixed cost per workgroup = the intercept over Cin
+    LAYERS = [(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4])) for f in (t.split(',') for t in os.environ['MB_LAYERS'].split(';'))]
+for (name, H, W, ci, co) in LAYERS:
     x = torch.randn(N * H * W * ci, device='cuda')
     FORM = int(os.environ.get('MB_S2_FORM', '0'))       # 4 = the eight-wave form (wino_s2b_kernel), 5 = polyphase + F(4,2) (wino_s2c_kernel)
     u = torch.randn((36 if FORM == 5 else 16) * co * ci, device='cuda') * 0.02
