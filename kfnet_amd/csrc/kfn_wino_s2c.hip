@@ -35,7 +35,7 @@
 #include <type_traits>
 
 // Timing-experiment builds (tools/mb/build_s2c.sh; results are WRONG on purpose): bit 0 no mid barrier, 1 no gathers, 2 no
-// transform, 3 no V stores, 4 no weight loads in the loop, 5 no V reads in the loop
+// transform, 3 no V stores, 4 no weight loads in the loop, 5 no V reads in the loop, 6 no output stores, 7 no epilogue at all
 #ifndef KFN_S2C_EXP
 #define KFN_S2C_EXP 0
 #endif
@@ -43,6 +43,16 @@
 // from there on): more than a super-step between a gather and the transform that consumes it.  0: gathered at the start of s+1.
 #ifndef KFN_S2C_LATE_GATHER
 #define KFN_S2C_LATE_GATHER 1
+#endif
+// 1: launches of at least two workgroups per CU run the persistent form (wino_s2c_pkernel, below); 0: one workgroup per tile block
+#ifndef KFN_S2C_PERSIST
+#define KFN_S2C_PERSIST 1
+#endif
+#ifndef KFN_S2C_PERSIST_MAX_SS
+#define KFN_S2C_PERSIST_MAX_SS 8          // ... of layers with at most this many super-steps (Cin <= 128)
+#endif
+#ifndef KFN_S2C_XSLOT_B
+#define KFN_S2C_XSLOT_B 24
 #endif
 
 namespace {
@@ -311,9 +321,6 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
 
     // producer timetable inside a super-step (MFMA slots): gathers from slot 0 every GSTEP, transform lines from XSLOT every
     // XSTEP, [mid barrier at JMID], stores from SSLOT every SSTEP
-#ifndef KFN_S2C_XSLOT_B
-#define KFN_S2C_XSLOT_B 24
-#endif
     // (the two waves of a SIMD -- w and w + 4: phases A+D, B+C -- run their transform bursts at different times)
     constexpr int GSTEP = 4, XSLOT = (KFN_S2C_LATE_GATHER && PART >= 2) ? KFN_S2C_XSLOT_B : 112, XSTEP = 4, SSLOT = JMID + 4 + (PART >= 2 ? 2 : 0), SSTEP = 4;
     static_assert((KFN_S2C_LATE_GATHER || GSTEP * 25 <= XSLOT) && XSLOT + XSTEP * 10 <= JMID && SSLOT + 2 + SSTEP * 25 <= 4 * NPOS, "producer timetable");
@@ -412,13 +419,301 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
     const int oy = 4 * ty + a;
     const bool row_ok = vr0 + trow < p.vrows && oy < p.Ho;        // uniform
     const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo) * pix_bytes);
-    kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
+    if (!(KFN_S2C_EXP & 64)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
   }
+}
+
+
+// =====================================================================================================================
+// PERSISTENT form (round 6, second half).  Measured on the kernel above (tools/mb_s2.py, MB_LAYERS with Cin = 64 .. 512 on conv2a's
+// shape): the time per workgroup is 9.8 us per super-step + an intercept of 18-24 us -- launch, the exposed first gathers and
+// transform, the epilogue with every CU of the chip storing at the same moment -- i.e. 30-40 % of conv2a (4 super-steps), 11 % of
+// conv3a, 5 % of conv4a.  Here a workgroup walks a SEQUENCE of tile blocks (its XCD's share, strided by the XCD's workgroups) and
+// the producers never stop: the gathers of super-step s + 2, the weight prefetches of s + 1 and the V stores of s + 1 simply run
+// on into the NEXT block's first super-steps (the V slots do not care which block they serve), so a block boundary costs the
+// consumers their output transform and stores -- through a small per-wave staging area BESIDE the V buffers (one tile column per
+// pass: 4.25 KiB per wave) -- and nothing else: no launch, no prologue, no barrier of its own.
+constexpr int PSTG = 4 * (16 * 16 + 16);                      // floats per wave: [4 tile rows][16 px + skew][16 ch]
+constexpr int LDS_P = LDS_V + 8 * PSTG * 4;                   // 156 672 B
+
+__global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  float* const smf = reinterpret_cast<float*>(smem_c);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // this workgroup's tiles: XCD x = blockIdx & 7 owns the tiles [xbase, xend) (as xcd_remap_c deals them); its workgroup j =
+  // blockIdx >> 3 takes xbase + j, + wpx, + 2 wpx, ... (wpx = workgroups of the grid on that XCD): at any moment the XCD's
+  // workgroups are on neighbouring tiles and, with n_group channel groups adjacent, mostly on the same weights
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int xcd = (int)blockIdx.x & 7;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xend = xbase + q8 + (xcd < r8 ? 1 : 0);
+  const int wpx = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+  int L = xbase + ((int)blockIdx.x >> 3);
+  if (L >= xend) return;                                       // (uniform; cannot happen with gridDim <= nwg)
+  const int per = p.tiles_m * p.n_group;
+  const int n_super = p.Cin / SS_CH;
+  const int s_last = n_super - 1;
+
+  struct Blk { int cb, vr0, img0, ty0, brk, tn; };
+  auto blk_of = [&](int tile) __attribute__((always_inline)) {
+    Blk b;
+    const int gset = tile / per, rem_ = tile - gset * per;
+    const int tm = rem_ / p.n_group;
+    b.tn = gset * p.n_group + (rem_ - tm * p.n_group);
+    b.cb = tm % p.bw;
+    b.vr0 = (tm / p.bw) * 4;
+    b.img0 = b.vr0 / p.Th;
+    b.ty0 = b.vr0 - b.img0 * p.Th;
+    b.brk = (p.Th - b.ty0 < 4) ? (p.Th - b.ty0) : 4;
+    return b;
+  };
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+  // ---- PRODUCER (see the kernel above): phase `part`, tile pt, channel pair pq8; its geometry follows the block being GATHERED ----
+  const int part = wave < 2 ? 0 : wave < 4 ? 1 : wave < 6 ? 3 : 2;
+  const int pt = 8 * (wave & 1) + (lane >> 3), pq8 = lane & 7;
+  const int ptr_ = pt >> 2, ptc = pt & 3;
+  unsigned gbase[2][2];
+  __amdgpu_buffer_rsrc_t rsA;
+  auto set_producer = [&](const Blk& b) __attribute__((always_inline)) {
+    const unsigned long long a_base = (unsigned long long)b.img0 * p.H * p.W * p.ldx * 4ull;
+    const unsigned long long a_rest = p.x_bytes - a_base;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
+                                            (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
+    const int img_rel = ptr_ < b.brk ? 0 : 1;
+    const int ty = ptr_ < b.brk ? b.ty0 + ptr_ : ptr_ - b.brk;
+    const int tx = b.cb * 4 + ptc;
+    const bool tile_ok = (b.vr0 + ptr_ < p.vrows) && tx < p.Tw;
+    const unsigned base = (unsigned)((((img_rel * p.H + 8 * ty) * p.W + 8 * tx) * p.ldx + pq8 * 2) * 4);
+    const bool r8_ = 8 * ty + 8 < p.H, c8_ = 8 * tx + 8 < p.W;
+    gbase[0][0] = tile_ok ? base : OOBV;
+    gbase[1][0] = tile_ok && r8_ ? base : OOBV;
+    gbase[0][1] = tile_ok && c8_ ? base : OOBV;
+    gbase[1][1] = tile_ok && r8_ && c8_ ? base : OOBV;
+  };
+  const unsigned row_b = (unsigned)(p.W * p.ldx * 4), pix_b = (unsigned)(p.ldx * 4);
+  const int pk = pq8 >> 1, ph = pq8 & 1;
+  const int v_st = (pk * 16 + (pt ^ (2 * pk))) * 4 + 2 * ph;
+
+  // ---- CONSUMER ----
+  const int rl = lane & 15, kl = lane >> 4;
+  const int v_rd = (kl * 16 + (rl ^ (2 * kl))) * 4;
+  const unsigned b_step = (unsigned)p.cout_pad * 64u;
+  auto voff_of = [&](int tn) __attribute__((always_inline)) {       // this lane's offset inside a weight fragment of channel group tn
+    const int nn = tn * NT + wave * 16 + rl;
+    const int nb = nn < p.cout_pad ? nn : p.cout_pad - 1;
+    return (unsigned)((nb * 16 + kl * 4) * 4);
+  };
+  f32x4 acc[NACC];
+  f32x2 pv[25];
+  f32x4 bq[8];
+  f32x4 vq[2][5];
+  auto acc_init = [&](int tn) __attribute__((always_inline)) {
+    const int n = tn * NT + wave * 16 + rl;
+    const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int g = 0; g < NACC; ++g) {
+      const float v0 = g == 6 ? bv : 0.f;
+      acc[g] = f32x4{v0, v0, v0, v0};
+    }
+  };
+  auto b_load = [&](auto rc, int fq, unsigned voff) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    bq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff, (unsigned)fq * b_step, 0));
+  };
+  auto p_gather = [&](auto part_c, auto ic, int ss) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value, i = decltype(ic)::value;
+    constexpr int PW = (PART == 0 || PART == 2) ? 5 : 4;
+    constexpr int m = i / PW, nn = i % PW;
+    constexpr int u = 2 * m + ((PART == 2 || PART == 3) ? 1 : 0), v = 2 * nn + ((PART == 1 || PART == 3) ? 1 : 0);
+    const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(ss * (SS_CH * 4));
+    pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, gbase[u == 8][v == 8], so, 0));
+  };
+  auto p_line = [&](auto part_c, auto lc) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value, l = decltype(lc)::value;
+    constexpr int PW = (PART == 0 || PART == 2) ? 5 : 4, PH = PART_NPX[PART] / PW;
+    if constexpr (l < PH) {
+      constexpr int m = l;
+      if constexpr (PW == 5) bt5(pv[m * 5], pv[m * 5 + 1], pv[m * 5 + 2], pv[m * 5 + 3], pv[m * 5 + 4]);
+      else ct4(pv[m * 4], pv[m * 4 + 1], pv[m * 4 + 2], pv[m * 4 + 3]);
+    } else {
+      constexpr int nn = l - PH;
+      if constexpr (PH == 5) bt5(pv[nn], pv[PW + nn], pv[2 * PW + nn], pv[3 * PW + nn], pv[4 * PW + nn]);
+      else ct4(pv[nn], pv[PW + nn], pv[2 * PW + nn], pv[3 * PW + nn]);
+    }
+  };
+  auto p_store = [&](auto part_c, auto ic, float* stD) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value, i = decltype(ic)::value;
+    constexpr int idx = SLOT_IDX[PART_SLOT0[PART] + i];
+    if constexpr (idx < NS) *reinterpret_cast<f32x2*>(smf + idx * SLOT_F + v_st) = pv[i];
+    else *reinterpret_cast<f32x2*>(stD + (idx - NS) * SLOT_F) = pv[i];
+  };
+  auto v_read = [&](auto pc, const float* rdD) __attribute__((always_inline)) {
+    constexpr int pp = decltype(pc)::value;
+    constexpr int g = group_of_pos(pp), k = pp - G_POS0[g];
+    if constexpr (pp < NS) vq[g & 1][k] = *reinterpret_cast<const f32x4*>(smf + pp * SLOT_F + v_rd);
+    else vq[g & 1][k] = *reinterpret_cast<const f32x4*>(rdD + (pp - NS) * SLOT_F);
+  };
+
+  // ---- state of the block loop (all uniform but the lane offsets) ----
+  Blk cur = blk_of(L), nxt_b = cur;
+  bool has_next = L + wpx < xend;
+  if (has_next) nxt_b = blk_of(L + wpx);
+  unsigned voff_b = voff_of(cur.tn), voff_n = voff_of(nxt_b.tn);
+  int gs = 0;                                      // super-steps done by this workgroup: parity of the double-buffered V region
+  set_producer(cur);
+  acc_init(cur.tn);
+
+  // ---- prologue of the FIRST block only ----
+  auto pro = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value;
+    constexpr int NPX = PART_NPX[PART];
+    constexpr int NLINE = NPX / ((PART == 0 || PART == 2) ? 5 : 4) + ((PART == 0 || PART == 2) ? 5 : 4);
+    sfor<NPX>([&](auto ic) { p_gather(part_c, ic, 0); });
+    sfor<8>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      constexpr int f0 = r < 5 ? r : r == 5 ? 25 : r == 6 ? 30 : 35;
+      b_load(rc, f0, voff_b);
+    });
+    sfor<NLINE>([&](auto lc) { p_line(part_c, lc); });
+    sfor<NPX>([&](auto ic) { p_store(part_c, ic, smf + NS * SLOT_F + v_st); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sfor<NPX>([&](auto ic) { p_gather(part_c, ic, 1); });          // (n_super >= 2 in this form)
+  };
+  // ---- the super-steps of ONE block; the producers' look-ahead runs on into the next block ----
+  auto kl_ = [&](auto part_c) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_c)::value;
+    constexpr int NPX = PART_NPX[PART];
+    constexpr int NLINE = NPX / ((PART == 0 || PART == 2) ? 5 : 4) + ((PART == 0 || PART == 2) ? 5 : 4);
+    constexpr int XSLOT = PART >= 2 ? KFN_S2C_XSLOT_B : 112, XSTEP = 4, SSLOT = JMID + 4 + (PART >= 2 ? 2 : 0), SSTEP = 4;
+    static_assert(XSLOT + XSTEP * 10 <= JMID && SSLOT + 2 + SSTEP * 25 <= 4 * NPOS, "producer timetable");
+    for (int ks = 0; ks < n_super; ++ks, ++gs) {
+      // look-ahead targets: the weights of the next super-step, the gathers of the one after -- of THIS block, of the NEXT block's
+      // first super-steps, or (last block) a harmless re-read of the last super-step
+      const bool w_wrap = ks + 1 >= n_super, g_wrap = ks + 2 >= n_super;
+      const int ss_w = !w_wrap ? ks + 1 : (has_next ? 0 : s_last);
+      const unsigned voff_w = (w_wrap && has_next) ? voff_n : voff_b;
+      if (ks == n_super - 2 && has_next) set_producer(nxt_b);      // every gather of this block has been issued
+      const int ss_g = !g_wrap ? ks + 2 : (has_next ? ks + 2 - n_super : s_last);
+      const float* const rdD = smf + (NS + (gs & 1) * ND) * SLOT_F + v_rd;
+      float* const stD = smf + (NS + ((gs + 1) & 1) * ND) * SLOT_F + v_st;
+      sfor<5>([&](auto kc) { v_read(kc, rdD); });
+      sfor<4 * NPOS>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int g = group_of_pos(j / 4);
+        constexpr int np = G_NPOS[g], j0 = 4 * G_POS0[g];
+        constexpr int kst = (j - j0) / np, k = (j - j0) % np;
+        constexpr int pp = G_POS0[g] + k;
+        if constexpr (j == JMID) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        acc[POS_ACC[pp]] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[g & 1][k][kst], bq[POS_BREG[pp]][kst], acc[POS_ACC[pp]], 0, 0, 0);
+        if constexpr (kst == 1 && g + 1 < NGROUP) {
+          constexpr int np1 = G_NPOS[g + 1];
+          if constexpr (k < np1) v_read(std::integral_constant<int, G_POS0[g + 1] + k>{}, rdD);
+          if constexpr (k == np - 1 && np1 > np) v_read(std::integral_constant<int, G_POS0[g + 1] + np>{}, rdD);
+        }
+        if constexpr (kst == 3 && frag_last_user(pp)) {
+          constexpr int nf = next_frag(pp);
+          if constexpr (nf >= 64) b_load(std::integral_constant<int, POS_BREG[pp]>{}, ss_w * NFRAG + (nf & 63), voff_w);
+          else b_load(std::integral_constant<int, POS_BREG[pp]>{}, ks * NFRAG + nf, voff_b);
+        }
+        if constexpr (j >= SSLOT + 2 && j < SSLOT + 2 + NPX * SSTEP && (j - SSLOT - 2) % SSTEP == 0)
+          p_gather(part_c, std::integral_constant<int, (j - SSLOT - 2) / SSTEP>{}, ss_g);
+        if constexpr (j >= XSLOT && j < XSLOT + NLINE * XSTEP && (j - XSLOT) % XSTEP == 0) p_line(part_c, std::integral_constant<int, (j - XSLOT) / XSTEP>{});
+        if constexpr (j >= SSLOT && j < SSLOT + NPX * SSTEP && (j - SSLOT) % SSTEP == 0) p_store(part_c, std::integral_constant<int, (j - SSLOT) / SSTEP>{}, stD);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+
+  const bool relu = p.relu != 0;
+  float* const stg = smf + LDS_V / 4 + wave * PSTG;
+  const int pix_bytes = p.ldy * 4;
+  auto at4 = [](float m0, float m1, float m2, float m3, float m4, float& y0, float& y1, float& y2, float& y3) __attribute__((always_inline)) {
+    const float s = m1 + m2, d = m1 - m2;
+    y0 = (m0 + s) + m3;
+    y1 = d + 2.0f * m3;
+    y2 = s + 4.0f * m3;
+    y3 = (d + 8.0f * m3) + m4;
+  };
+  // The whole walk -- prologue, block loop, epilogues -- sits INSIDE each phase's branch: with the block loop outside the four
+  // branches every patch / weight register live across a block boundary had to agree at the branch merges, and hipcc spilled 139
+  // VGPRs around them (scratch traffic inside the super-steps).  The epilogue's code is therefore instantiated four times (cold).
+  auto walk = [&](auto part_c) __attribute__((always_inline)) {
+  pro(part_c);
+  for (;;) {
+    kl_(part_c);
+
+    // ---- epilogue of block `cur`: Y = A^T M A per tile; lane (channel n0 + rl, k = kl), element e = tile (row kl, column e).
+    // One pass per tile COLUMN e through the wave's own staging area [4 tile rows][16 px (i, j)][16 ch]; store lane = (pixel, channel
+    // quad): one instruction writes 4 rows x 4 px x 64 bytes of one tile row. ----
+    {
+      const int n0 = cur.tn * NT + wave * 16;
+      const unsigned long long y_base = (unsigned long long)cur.img0 * p.Ho * p.Wo * p.ldy * 4ull;
+      const unsigned long long y_rest = p.y_bytes - y_base;
+      const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
+      const int spx = lane >> 2, nq = lane & 3;                  // store lane: pixel (i, j) = (spx >> 2, spx & 3) of a tile, channel quad
+      const bool q_ok = n0 + nq * 4 < p.Cout;
+      const unsigned voff_q = q_ok ? (unsigned)((((spx >> 2) * p.Wo + (spx & 3)) * p.ldy + n0 + nq * 4) * 4) : OOBV;
+#pragma unroll
+      for (int e = 0; e < ((KFN_S2C_EXP & 128) ? 0 : 4); ++e) {
+        float t[4][5];
+#pragma unroll
+        for (int nu = 0; nu < 5; ++nu)
+          at4(acc[nu][e], acc[5 + nu][e], acc[10 + nu][e], acc[15 + nu][e], acc[20 + nu][e], t[0][nu], t[1][nu], t[2][nu], t[3][nu]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float y0, y1, y2, y3;
+          at4(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], y0, y1, y2, y3);
+          float* const row = stg + kl * (16 * 16 + 16) + (i * 4) * 16 + rl;
+          row[0] = y0; row[16] = y1; row[32] = y2; row[48] = y3;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int tx = cur.cb * 4 + e;
+        const bool col_ok = tx < p.Tw;                           // (uniform)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + kk * (16 * 16 + 16) + spx * 16 + nq * 4);
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const int img_rel = kk < cur.brk ? 0 : 1;
+          const int ty = kk < cur.brk ? cur.ty0 + kk : kk - cur.brk;
+          const bool row_ok = col_ok && cur.vr0 + kk < p.vrows;  // (uniform; Ho is a multiple of 4: whole tiles)
+          const unsigned soff = (unsigned)(((img_rel * p.Ho + 4 * ty) * p.Wo + 4 * tx) * pix_bytes);
+          if (!(KFN_S2C_EXP & 64)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!has_next) break;
+    // ---- next block: the consumers' side follows the producers, who are already there ----
+    L += wpx;
+    cur = nxt_b;
+    voff_b = voff_n;
+    has_next = L + wpx < xend;
+    if (has_next) { nxt_b = blk_of(L + wpx); voff_n = voff_of(nxt_b.tn); }
+    acc_init(cur.tn);
+  }
+  };
+  if (part == 0) walk(std::integral_constant<int, 0>{});
+  else if (part == 1) walk(std::integral_constant<int, 1>{});
+  else if (part == 2) walk(std::integral_constant<int, 2>{});
+  else walk(std::integral_constant<int, 3>{});
 }
 
 }  // namespace
 
-int kfn::wino_s2c_lds_bytes() { return LDS_BYTES; }
+int kfn::wino_s2c_lds_bytes() { return KFN_S2C_PERSIST ? (LDS_P > LDS_BYTES ? LDS_P : LDS_BYTES) : LDS_BYTES; }
 
 // pointer-free routing check of the F(4,2) form (kfn_winograd_s2_supported answers it for wino_form = KFN_WINO_FORM_S2_F42)
 int kfn::wino_s2c_supported(const kfn_conv_desc* d) {
@@ -467,10 +762,33 @@ int kfn::launch_wino_s2c(const kfn_conv_desc* d, const float* x, const void* u_p
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((out_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)((long)NFRAG * d->cout_pad * d->Cin * 4L);
+  const long nwg = (long)a.tiles_m * a.tiles_n;
+#if KFN_S2C_PERSIST
+  // the persistent form: one workgroup per CU walking its share of the tile blocks (needs two super-steps of look-ahead inside a
+  // block; launches that do not even fill the chip once keep one workgroup per block)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  // MEASURED (batch 20, same box): conv2a (4 super-steps) 2.66 -> 2.53 ms, conv3a (16) 3.96 -> 3.95, conv4a (32) 3.80 -> 3.85 -- what a
+  // block costs beyond its super-steps is mostly the output stores (timing build without them: -8 % on conv2a in either form) and
+  // the consumers' epilogue, neither of which persistence removes, and hipcc's allocation of the block loop spills a few
+  // block-level registers whose reloads drain the prefetches in flight.  So: short-K layers only.
+  if (d->Cin / SS_CH >= 2 && d->Cin / SS_CH <= KFN_S2C_PERSIST_MAX_SS && nwg >= 2L * n_cu) {
+    static std::atomic<uint64_t> attr_done_p{0};
+    int rcp = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2c_pkernel), LDS_P, attr_done_p);
+    if (rcp != KFN_OK) return rcp;
+    hipLaunchKernelGGL(wino_s2c_pkernel, dim3((unsigned)n_cu), dim3(512), LDS_P, (hipStream_t)stream, a);
+    KFN_LAUNCH_CHECK("wino_s2c_pkernel");
+    return KFN_OK;
+  }
+#endif
   static std::atomic<uint64_t> attr_done{0};
   int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2c_kernel), LDS_BYTES, attr_done);
   if (rc != KFN_OK) return rc;
-  hipLaunchKernelGGL(wino_s2c_kernel, dim3((unsigned)((long)a.tiles_m * a.tiles_n)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wino_s2c_kernel, dim3((unsigned)nwg), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   KFN_LAUNCH_CHECK("wino_s2c_kernel");
   return KFN_OK;
 }

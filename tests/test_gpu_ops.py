@@ -1099,7 +1099,10 @@ def test_winograd_s2_vs_oracle(case, relu, form):
 # the F(4,2) form (wino_s2c_kernel, KFN_WINO_FORM_S2_F42): H, W multiples of 8, H >= 32; blocks straddling images (Th % 4 != 0),
 # ragged tile-block columns and channel tiles, many super-steps, SCoordNet's three layers at one frame
 S2C_CASES = [(1, 32, 32, 16, 128), (2, 40, 48, 32, 160), (1, 120, 160, 64, 128), (3, 32, 40, 48, 36), (5, 32, 32, 16, 8),
-             (2, 64, 80, 256, 256), (7, 40, 32, 32, 136), (1, 64, 96, 512, 128), (1, 120, 160, 512, 1024)]
+             (2, 64, 80, 256, 256), (7, 40, 32, 32, 136), (1, 64, 96, 512, 128), (1, 120, 160, 512, 1024),
+             # the PERSISTENT form (wino_s2c_pkernel: at least two workgroups per CU, 2 .. 8 super-steps): workgroups walking 2-3 tile
+             # blocks each, blocks straddling images (Th = 30), a ragged last round, channel groups that change along a walk
+             (8, 120, 160, 32, 512), (4, 240, 320, 64, 256), (10, 120, 160, 128, 384)]
 
 
 @pytest.mark.parametrize('relu', [1, 0])
