@@ -862,7 +862,9 @@ class WinogradS2ConvOp(ConvOp):
 
     def kernel_name(self, lib):
         if self.f42:
-            return 'wino_s2c_kernel'
+            # (the launcher's rule, csrc/kfn_wino_s2c.hip: the persistent form for 2 .. 8 super-steps and at least two workgroups per CU)
+            ss = self.x.shape[3] // 16
+            return 'wino_s2c_pkernel' if 2 <= ss <= 8 and self.workgroups() >= 2 * getattr(self.x.graph, 'cu_count', 256) else 'wino_s2c_kernel'
         if self.k_split > 1:
             return 'wino_s2b_kernel[split-K %d] + splitk_reduce_kernel' % self.k_split
         if self.eight_wave:
