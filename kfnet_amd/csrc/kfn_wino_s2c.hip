@@ -49,7 +49,7 @@
 #define KFN_S2C_PERSIST 1
 #endif
 #ifndef KFN_S2C_PERSIST_MAX_SS
-#define KFN_S2C_PERSIST_MAX_SS 8          // ... of layers with at most this many super-steps (Cin <= 128)
+#define KFN_S2C_PERSIST_MAX_SS 64         // ... of layers with at most this many super-steps
 #endif
 #ifndef KFN_S2C_XSLOT_B
 #define KFN_S2C_XSLOT_B 24
@@ -433,6 +433,15 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
 // on into the NEXT block's first super-steps (the V slots do not care which block they serve), so a block boundary costs the
 // consumers their output transform and stores -- through a small per-wave staging area BESIDE the V buffers (one tile column per
 // pass: 4.25 KiB per wave) -- and nothing else: no launch, no prologue, no barrier of its own.
+// This lane's index from the hardware, opaque to the optimiser: block-level code of the persistent kernel derives everything it
+// needs per lane from it on the spot.  (Hoisted out of the block loop those values do not fit beside the super-step's 248
+// registers; hipcc spills them, and every reload sits in the vector-memory queue BEHIND the gathers and weight prefetches that
+// are in flight across the block boundary -- waiting for it drains them.)
+__device__ __forceinline__ int lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 constexpr int PSTG = 4 * (16 * 16 + 16);                      // floats per wave: [4 tile rows][16 px + skew][16 ch]
 constexpr int LDS_P = LDS_V + 8 * PSTG * 4;                   // 156 672 B
 
@@ -478,6 +487,9 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
   unsigned gbase[2][2];
   __amdgpu_buffer_rsrc_t rsA;
   auto set_producer = [&](const Blk& b) __attribute__((always_inline)) {
+    const int lv = lane_now();
+    const int pt = 8 * (wave & 1) + (lv >> 3), pq8 = lv & 7;
+    const int ptr_ = pt >> 2, ptc = pt & 3;
     const unsigned long long a_base = (unsigned long long)b.img0 * p.H * p.W * p.ldx * 4ull;
     const unsigned long long a_rest = p.x_bytes - a_base;
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
@@ -502,6 +514,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
   const int v_rd = (kl * 16 + (rl ^ (2 * kl))) * 4;
   const unsigned b_step = (unsigned)p.cout_pad * 64u;
   auto voff_of = [&](int tn) __attribute__((always_inline)) {       // this lane's offset inside a weight fragment of channel group tn
+    const int lv = lane_now();
+    const int rl = lv & 15, kl = lv >> 4;
     const int nn = tn * NT + wave * 16 + rl;
     const int nb = nn < p.cout_pad ? nn : p.cout_pad - 1;
     return (unsigned)((nb * 16 + kl * 4) * 4);
@@ -511,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
   f32x4 bq[8];
   f32x4 vq[2][5];
   auto acc_init = [&](int tn) __attribute__((always_inline)) {
-    const int n = tn * NT + wave * 16 + rl;
+    const int n = tn * NT + wave * 16 + (lane_now() & 15);
     const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int g = 0; g < NACC; ++g) {
@@ -561,7 +575,6 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
   Blk cur = blk_of(L), nxt_b = cur;
   bool has_next = L + wpx < xend;
   if (has_next) nxt_b = blk_of(L + wpx);
-  unsigned voff_b = voff_of(cur.tn), voff_n = voff_of(nxt_b.tn);
   int gs = 0;                                      // super-steps done by this workgroup: parity of the double-buffered V region
   set_producer(cur);
   acc_init(cur.tn);
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     sfor<8>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       constexpr int f0 = r < 5 ? r : r == 5 ? 25 : r == 6 ? 30 : 35;
-      b_load(rc, f0, voff_b);
+      b_load(rc, f0, voff_of(cur.tn));
     });
     sfor<NLINE>([&](auto lc) { p_line(part_c, lc); });
     sfor<NPX>([&](auto ic) { p_store(part_c, ic, smf + NS * SLOT_F + v_st); });
@@ -596,7 +609,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
       // first super-steps, or (last block) a harmless re-read of the last super-step
       const bool w_wrap = ks + 1 >= n_super, g_wrap = ks + 2 >= n_super;
       const int ss_w = !w_wrap ? ks + 1 : (has_next ? 0 : s_last);
-      const unsigned voff_w = (w_wrap && has_next) ? voff_n : voff_b;
+      const unsigned voff_b = voff_of(cur.tn);
+      const unsigned voff_w = (w_wrap && has_next) ? voff_of(nxt_b.tn) : voff_b;
       if (ks == n_super - 2 && has_next) set_producer(nxt_b);      // every gather of this block has been issued
       const int ss_g = !g_wrap ? ks + 2 : (has_next ? ks + 2 - n_super : s_last);
       const float* const rdD = smf + (NS + (gs & 1) * ND) * SLOT_F + v_rd;
@@ -658,12 +672,14 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     // One pass per tile COLUMN e through the wave's own staging area [4 tile rows][16 px (i, j)][16 ch]; store lane = (pixel, channel
     // quad): one instruction writes 4 rows x 4 px x 64 bytes of one tile row. ----
     {
+      const int lv = lane_now();
+      const int rl = lv & 15, kl = lv >> 4;
       const int n0 = cur.tn * NT + wave * 16;
       const unsigned long long y_base = (unsigned long long)cur.img0 * p.Ho * p.Wo * p.ldy * 4ull;
       const unsigned long long y_rest = p.y_bytes - y_base;
       const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
-      const int spx = lane >> 2, nq = lane & 3;                  // store lane: pixel (i, j) = (spx >> 2, spx & 3) of a tile, channel quad
+      const int spx = lv >> 2, nq = lv & 3;                  // store lane: pixel (i, j) = (spx >> 2, spx & 3) of a tile, channel quad
       const bool q_ok = n0 + nq * 4 < p.Cout;
       const unsigned voff_q = q_ok ? (unsigned)((((spx >> 2) * p.Wo + (spx & 3)) * p.ldy + n0 + nq * 4) * 4) : OOBV;
 #pragma unroll
@@ -699,9 +715,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     // ---- next block: the consumers' side follows the producers, who are already there ----
     L += wpx;
     cur = nxt_b;
-    voff_b = voff_n;
     has_next = L + wpx < xend;
-    if (has_next) { nxt_b = blk_of(L + wpx); voff_n = voff_of(nxt_b.tn); }
+    if (has_next) nxt_b = blk_of(L + wpx);
     acc_init(cur.tn);
   }
   };
@@ -772,10 +787,10 @@ int kfn::launch_wino_s2c(const kfn_conv_desc* d, const float* x, const void* u_p
     hipDeviceProp_t prop;
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  // MEASURED (batch 20, same box): conv2a (4 super-steps) 2.66 -> 2.53 ms, conv3a (16) 3.96 -> 3.95, conv4a (32) 3.80 -> 3.85 -- what a
-  // block costs beyond its super-steps is mostly the output stores (timing build without them: -8 % on conv2a in either form) and
-  // the consumers' epilogue, neither of which persistence removes, and hipcc's allocation of the block loop spills a few
-  // block-level registers whose reloads drain the prefetches in flight.  So: short-K layers only.
+  // MEASURED (batch 20, same box, two runs each): conv2a (4 super-steps) 2.66 -> 2.53 ms, conv3a (16) 4.01 -> 3.93, conv4a (32) 3.81 ->
+  // 3.81.  What a block still costs beyond its super-steps (15 of conv2a's 54 us) is the issue of its 131 KB of output stores (a
+  // timing build without them: -8 % on conv2a in either form) and the consumers' epilogue, which persistence cannot hide.  (The
+  // first build spilled 31 block-level VGPRs whose reloads queued behind the prefetches in flight: lane_now().)
   if (d->Cin / SS_CH >= 2 && d->Cin / SS_CH <= KFN_S2C_PERSIST_MAX_SS && nwg >= 2L * n_cu) {
     static std::atomic<uint64_t> attr_done_p{0};
     int rcp = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino_s2c_pkernel), LDS_P, attr_done_p);
