@@ -149,8 +149,6 @@ typedef struct kfn_conv_desc {
 #define KFN_WINO_FORM_F43_FOUR_WAVE 2  /* kfn_conv2d_winograd_f43: wino4_kernel (four waves, 32x32x2 MFMA tiles) */
 #define KFN_WINO_FORM_F43_EIGHT_WAVE 3 /* kfn_conv2d_winograd_f43: wino4b_kernel (eight waves, 16x16x4 MFMA tiles) */
 #define KFN_WINO_FORM_S2_EIGHT_WAVE 4  /* kfn_conv2d_winograd_s2: wino_s2b_kernel (eight waves, 16x16x4 MFMA tiles; fp32 operands) */
-#define KFN_WINO_FORM_F43_PERSISTENT 6 /* kfn_conv2d_winograd_f43: wino4c_kernel, persistent workgroups of 16 tiles x 128 channels, every wave all 36
-                                        * positions (Cout >= 128, an even number of 16-channel super-steps; weights: pack_winograd_f43_kernel_c) */
 #define KFN_WINO_FORM_S2_F42 5         /* kfn_conv2d_winograd_s2: wino_s2c_kernel, polyphase + F(4,2) on 4x4 output tiles (81 instead of 100
                                         * products per 16 outputs; fp32, H and W multiples of 8; weights: pack_winograd_s2_kernel_c) */
 

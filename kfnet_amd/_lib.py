@@ -21,7 +21,6 @@ CFG_128x256 = 9
 CFG_256x64, CFG_256x256, CFG_256x256_W8 = 12, 13, 14
 WINO_FORM_F43_FOUR_WAVE, WINO_FORM_F43_EIGHT_WAVE = 2, 3   # kfn_conv_desc.wino_form for kfn_conv2d_winograd_f43
 WINO_FORM_S2_EIGHT_WAVE = 4                                # ... for kfn_conv2d_winograd_s2
-WINO_FORM_F43_PERSISTENT = 6                               # ... kfn_conv2d_winograd_f43's persistent form (wino4c_kernel)
 WINO_FORM_S2_F42 = 5                                       # ... its polyphase + F(4,2) form (wino_s2c_kernel)
 CFG_AUTO, CFG_160x128, CFG_128x128, CFG_128x64, CFG_128x32, CFG_64x64, CFG_256x32, CFG_192x64 = 0, 1, 2, 3, 4, 5, 6, 7
 

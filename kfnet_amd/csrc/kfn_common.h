@@ -94,9 +94,6 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // answers; each is defined beside the kernel it describes.  < 0: no such form in that file.
 int wino_f43_lds_bytes(int wino_form);     // kfn_wino4.hip: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE
 int wino_s2_lds_bytes(int wino_form, int operand_dtype);   // kfn_wino_s2.hip: AUTO (four waves) / KFN_WINO_FORM_S2_EIGHT_WAVE
-int wino4c_lds_bytes();                    // kfn_wino4c.hip: KFN_WINO_FORM_F43_PERSISTENT
-int wino4c_supported(const kfn_conv_desc* d);
-int launch_wino4c(const kfn_conv_desc* d, const float* x, const float* u_packed, const float* bias, float* y, void* stream);
 int wino_s2c_lds_bytes();                  // kfn_wino_s2c.hip: KFN_WINO_FORM_S2_F42
 int wino_s2c_supported(const kfn_conv_desc* d);   // (normalised descriptor)
 int launch_wino_s2c(const kfn_conv_desc* d, const float* x, const void* u_packed, const float* bias, float* y, void* stream);

@@ -1257,7 +1257,6 @@ unsigned long long* g_wino4_prof = nullptr;
 int kfn::wino_f43_lds_bytes(int wino_form) {
   if (wino_form == KFN_WINO_FORM_F43_FOUR_WAVE) return LDS_V;
   if (wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE) return B_LDS;
-  if (wino_form == KFN_WINO_FORM_F43_PERSISTENT) return kfn::wino4c_lds_bytes();
   return -1;
 }
 
@@ -1297,7 +1296,6 @@ extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
   if (2L * d->H * d->W * d->ldy * 4L >= (1L << 31)) return 0;            // ... of the output below 2 GiB
   if (36L * d->cout_pad * d->Cin * 4L >= (1L << 31)) return 0;           // the transformed kernel below 2 GiB
   if ((long)d->N * ((d->H + 3) / 4) >= (1L << 30)) return 0;
-  if (d->wino_form == KFN_WINO_FORM_F43_PERSISTENT) return kfn::wino4c_supported(d);
   return 1;
 }
 
@@ -1386,7 +1384,6 @@ extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, c
   Wino4Args a;
   int rc = wino4_setup(d, x, u4_packed, bias, y, d->ldy, "kfn_conv2d_winograd_f43", &a);
   if (rc != KFN_OK) return rc;
-  if (d->wino_form == KFN_WINO_FORM_F43_PERSISTENT) return kfn::launch_wino4c(d, x, u4_packed, bias, y, stream);   // kfn_wino4c.hip
   // kfn_conv_desc.wino_form: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE pick the kernel (A/B measurements); AUTO = the default below
   const bool eight = d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE ||
                      (d->wino_form != KFN_WINO_FORM_F43_FOUR_WAVE && KFN_W4_DEFAULT_EIGHT_WAVE);

@@ -317,17 +317,6 @@ def pack_winograd_f43_kernel_b(w):
     return np.ascontiguousarray(v.transpose(0, 1, 3, 4, 2, 5).reshape(nc, 18, cp, 16))
 
 
-def pack_winograd_f43_kernel_c(w):
-    """The same U for the PERSISTENT form of kfn_conv2d_winograd_f43 (kfn_conv_desc.wino_form = KFN_WINO_FORM_F43_PERSISTENT,
-    csrc/kfn_wino4c.hip): U4c [Cin/16][36 positions][cout_pad][16] -- lane (channel n, k) of a 16x16x4 B operand reads 16 contiguous
-    bytes per (super-step, position): input channels 4k .. 4k+3 of the super-step's 16."""
-    u = pack_winograd_f43_kernel(w)                     # [Cin/8][36][cp][8]
-    nc, _, cp, _ = u.shape
-    assert nc % 2 == 0
-    v = u.reshape(nc // 2, 2, 36, cp, 8)                # [super-step][chunk][pos][n][c8]
-    return np.ascontiguousarray(v.transpose(0, 2, 3, 1, 4).reshape(nc // 2, 36, cp, 16))
-
-
 def pack_winograd_s2_kernel(w):
     """TF HWIO [3,3,Cin,Cout] -> the 16 weight fragments [Cin/8][16][cout_pad][8] of kfn_conv2d_winograd_s2
     (3x3 stride-2 conv as four stride-1 polyphase filters under F(2,2), csrc/kfn_wino_s2.hip): with
