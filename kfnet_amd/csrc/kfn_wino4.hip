@@ -722,7 +722,9 @@ static_assert(18 % NBB == 0 && 36 % NVB == 0 && NBB <= WPOS / 2 && NVB <= WPOS, 
 #endif
 static_assert(36 * KFN_W4B_GSTEP <= KFN_W4B_XSLOT && KFN_W4B_XSLOT < KFN_W4B_SSLOT && KFN_W4B_SSLOT + 36 <= CPS * SPC,
               "producer schedule (eight-wave form)");
-// timing experiments only (wrong results on purpose): bit 0 no transform, 1 no patch loads, 2 no V stores, 3 no B loads in the loop
+// timing experiments only (wrong results on purpose): bit 0 no transform, 1 no patch loads, 2 no V stores, 3 no B loads in the loop,
+// 4 no output stores (round 6: 4.5 of a workgroup's 16 us of fixed cost; delaying the first round's workgroups by up to 31 x 0.25 / 1 us so
+// that the rounds do not store at the same moment changed nothing: the cost is per CU, not a chip-wide burst)
 #ifndef KFN_W4B_DBG
 #define KFN_W4B_DBG 0
 #endif
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
       const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
       const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
       const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
-      kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);
+      if (!(KFN_W4B_DBG & 16)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);   // (bit 4: no output stores)
     }
   }
 }
