@@ -41,8 +41,10 @@ extern "C" {
 /* 5 (round 4): kfn_conv_desc starts with `struct_size` (the struct had grown at its end -- weights_path -- without a
  * version bump); kfn_comm_rank asks RCCL; kfn_kalman_scan_ex no longer allocates.  A host checks
  * kfn_abi_version() == KFN_ABI_VERSION once after loading the library.
- * 6 (round 5): split-K Winograd entry points, kfn_winograd_lds_bytes.  7 (round 5): kfn_decode_png_rgb8. */
-#define KFN_ABI_VERSION 8
+ * 6 (round 5): split-K Winograd entry points, kfn_winograd_lds_bytes.  7 (round 5): kfn_decode_png_rgb8.
+ * 8 (round 6): KFN_WINO_FORM_S2_F42, kfn_apply_transform / kfn_pixel_map / kfn_bilinear_sampler.
+ * 9 (round 6): kfn_conv_desc.x_layout / y_layout (KFN_LAYOUT_C16). */
+#define KFN_ABI_VERSION 9
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -123,6 +125,10 @@ typedef struct kfn_conv_desc {
   int32_t weights_path;  /* fp16 activations in AND out only: KFN_WEIGHTS_AUTO / _VIA_REGISTERS (global -> registers ->
                           * ds_write) / _LDS_DMA (global -> LDS directly, `buffer_load ... lds`, three weight buffers) /
                           * KFN_OPERANDS_LDS_DMA (the activation tile too) */
+  int32_t x_layout;      /* KFN_LAYOUT_NHWC (0) / KFN_LAYOUT_C16: memory layout of the input activations (ABI 9) */
+  int32_t y_layout;      /* ... of the output.  Only kfn_conv2d_winograd_f43 (eight-wave form) and kfn_conv2d_winograd_s2
+                          * (F(4,2) form) take KFN_LAYOUT_C16; every other entry point refuses a non-zero layout
+                          * (KFN_ERR_UNSUPPORTED) instead of reading the buffer as NHWC. */
 } kfn_conv_desc;
 /* kfn_conv_desc d = KFN_CONV_DESC_INIT;  -- zero everything, set struct_size */
 #define KFN_CONV_DESC_INIT {(int32_t)sizeof(kfn_conv_desc)}
@@ -134,6 +140,14 @@ typedef struct kfn_conv_desc {
 
 #define KFN_ACT_F32 0
 #define KFN_ACT_F16 1
+
+/* Activation layouts.  NHWC: element (n, h, w, c) at ((n*H + h)*W + w)*ld + c -- the layout of the reference's tensors and the
+ * default everywhere.  C16 ("channel-blocked"): per image [C/16][H][W][16], element at n*H*W*C + (((c/16)*H + h)*W + w)*16
+ * + c%16 -- needs C % 16 == 0 and a dense tensor (ld == C).  The image stride is the same, so batch windows of a tensor are
+ * layout-agnostic.  The Winograd kernels read 16 input channels of a patch per step: in C16 a 6-pixel patch row is 384
+ * contiguous bytes instead of six 64-byte pieces of six different lines (measured: the F(4x4,3x3) kernel -7 %). */
+#define KFN_LAYOUT_NHWC 0
+#define KFN_LAYOUT_C16 1
 
 /* Order in which the Winograd kernels' workgroups walk (tile block, channel group): with the tile blocks
  * fastest every resident workgroup of an XCD streams the same weight slice and the input crosses the

@@ -10,11 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
 ACT_F32, ACT_F16 = 0, 1
+LAYOUT_NHWC, LAYOUT_C16 = 0, 1                            # kfn_conv_desc.x_layout / y_layout (KFN_LAYOUT_*)
 PNG_OK, PNG_UNSUPPORTED, PNG_ERROR = 0, 1, 2
 WINO_ORDER_AUTO, WINO_ORDER_M_FAST, WINO_ORDER_N_FAST = 0, 1, 2
 CFG_128x256 = 9
@@ -36,7 +37,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'struct_size', 'N', 'H', 'W', 'Cin', 'ldx', 'Cout', 'cout_pad', 'ldy', 'kh', 'kw', 'stride',
         'transposed', 'relu', 'epilogue', 'config', 'operand_dtype', 'wino_order', 'wino_form',
-        'x_dtype', 'y_dtype', 'k_step', 'weights_path')]
+        'x_dtype', 'y_dtype', 'k_step', 'weights_path', 'x_layout', 'y_layout')]
 
     def __init__(self, *args, **kw):
         super(ConvDesc, self).__init__(*args, **kw)

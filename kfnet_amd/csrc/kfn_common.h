@@ -106,7 +106,7 @@ constexpr int WINO2_LDS_BYTES = 2 * 16384;          // wino2_kernel's two raw-pa
 // kfn_conv_desc crosses the ABI by pointer and grows at its end; `struct_size` (first member) says how many bytes the
 // CALLER's object has.  Every entry point works on a full-size copy whose missing tail is zero (= AUTO / fp32
 // defaults) and never touches the caller's memory beyond struct_size.
-inline int conv_desc_in(const kfn_conv_desc* in, kfn_conv_desc* out, const char* who) {
+inline int conv_desc_in(const kfn_conv_desc* in, kfn_conv_desc* out, const char* who, bool layouts_ok = false) {
   if (in == nullptr) return fail(KFN_ERR_ARG, "%s: null descriptor", who);
   const int32_t sz = in->struct_size;
   const int32_t min_sz = (int32_t)(offsetof(kfn_conv_desc, config) + sizeof(int32_t));   // the first-round struct
@@ -118,6 +118,11 @@ inline int conv_desc_in(const kfn_conv_desc* in, kfn_conv_desc* out, const char*
   std::memset(out, 0, sizeof(*out));
   std::memcpy(out, in, (size_t)sz);
   out->struct_size = (int32_t)sizeof(kfn_conv_desc);
+  if ((unsigned)out->x_layout > KFN_LAYOUT_C16 || (unsigned)out->y_layout > KFN_LAYOUT_C16)
+    return fail(KFN_ERR_ARG, "%s: unknown activation layout (x_layout %d, y_layout %d)", who, out->x_layout, out->y_layout);
+  if (!layouts_ok && (out->x_layout != KFN_LAYOUT_NHWC || out->y_layout != KFN_LAYOUT_NHWC))
+    return fail(KFN_ERR_UNSUPPORTED, "%s reads and writes NHWC only (x_layout %d, y_layout %d): the channel-blocked layout exists "
+                "for kfn_conv2d_winograd_f43 (eight-wave form) and kfn_conv2d_winograd_s2 (F(4,2) form)", who, out->x_layout, out->y_layout);
   return KFN_OK;
 }
 // (the declaration shadows the caller's pointer with the normalised copy)
@@ -125,6 +130,14 @@ inline int conv_desc_in(const kfn_conv_desc* in, kfn_conv_desc* out, const char*
   kfn_conv_desc d##_full;                                          \
   {                                                                \
     int _rc = ::kfn::conv_desc_in(d, &d##_full, who);              \
+    if (_rc != KFN_OK) return _rc;                                 \
+  }                                                                \
+  d = &d##_full
+// ... for the entry points that take KFN_LAYOUT_C16 activations
+#define KFN_CONV_DESC_IN_LAYOUTS(d, who)                           \
+  kfn_conv_desc d##_full;                                          \
+  {                                                                \
+    int _rc = ::kfn::conv_desc_in(d, &d##_full, who, true);        \
     if (_rc != KFN_OK) return _rc;                                 \
   }                                                                \
   d = &d##_full

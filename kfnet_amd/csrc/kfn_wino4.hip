@@ -126,6 +126,11 @@ struct Wino4Args {
   unsigned long long x_bytes;
   unsigned long long y_bytes;
   unsigned u_bytes;
+  // wino4b_kernel only -- byte strides of the activation layouts (kfn_conv_desc.x_layout / y_layout): element (n, h, w, c) lies at
+  // n * img + (h * W + w) * pix + (c >> 4) * cb + (c & 15) * 4.  NHWC: pix = ld * 4, cb = 64; KFN_LAYOUT_C16 (per image
+  // [C/16][H][W][16]): pix = 64, cb = H * W * 64.  The image stride is the same in both.
+  unsigned x_pix, x_cb, x_img;
+  unsigned y_pix, y_cb, y_img;
   // split-K (wino4b_kernel only; kfn_conv2d_winograd_f43_splitk): the grid is k_split copies of the tile grid, copy s
   // accumulates super-steps [s * ss_per_split, (s + 1) * ss_per_split) and writes its RAW partial sums (no bias, no ReLU)
   // into plane s of the workspace (y / ldy / y_bytes describe ONE plane, y_split_bytes the distance between planes)
@@ -867,9 +872,9 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   const int img0 = vr0 / p.Th;
   const int ty0 = vr0 - img0 * p.Th;
   const int brk = (p.Th - ty0 < BH4) ? (p.Th - ty0) : BH4;
-  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_base = (unsigned long long)img0 * p.x_img;
   const unsigned long long a_rest = p.x_bytes - a_base;
-  const unsigned long long two_img = 2ull * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long two_img = 2ull * p.x_img;
   const __amdgpu_buffer_rsrc_t rsU =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u4), 0, p.u_bytes, 0x00020000);
 
@@ -898,21 +903,21 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     for (int r = 0; r < 3; ++r) {
       const int yy = 4 * ty - 1 + 3 * rh + r;
       roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
-                    ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(cp * 8) : ROW_POISON;
+                    ? (unsigned)img_rel * p.x_img + (unsigned)(yy * p.W) * p.x_pix + (unsigned)(cp * 8) : ROW_POISON;
     }
 #else
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int yy = 4 * ty - 1 + r;
       roff[r] = (row_tile_ok && (unsigned)yy < (unsigned)p.H)
-                    ? (unsigned)((img_rel * p.H + yy) * p.W) * (unsigned)(p.ldx * 4) + (unsigned)(c16 * 4) : ROW_POISON;
+                    ? (unsigned)img_rel * p.x_img + (unsigned)(yy * p.W) * p.x_pix + (unsigned)(c16 * 4) : ROW_POISON;
     }
 #endif
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int xx = 4 * tx - 1 + c;
       cok[c] = (tx < p.Tw) && ((unsigned)xx < (unsigned)p.W);
-      coff[c] = cok[c] ? (unsigned)(xx * p.ldx * 4) : 0u;
+      coff[c] = cok[c] ? (unsigned)xx * p.x_pix : 0u;
     }
   }
   const int x_records = (int)(a_rest < two_img ? a_rest : two_img);
@@ -967,9 +972,9 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0, cok[c] ? x_records : 0, 0x00020000);
 #if KFN_W4B_PAIR
-    pq[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), 0));
+    pq[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, roff[r], coff[c] + (unsigned)(ks0 + sc) * p.x_cb, 0));
 #else
-    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)((ks0 + sc) * 64), KFN_W4B_PATCH_AUX));
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[r], coff[c] + (unsigned)(ks0 + sc) * p.x_cb, KFN_W4B_PATCH_AUX));
 #if KFN_W4B_PACKED
     KFN_PP_IN(pp, r, c) = v;
 #else
@@ -1202,7 +1207,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   // the image leaves: iteration `it` = tiles 2 it, 2 it + 1 (wave >> 2), pixel row i = wave & 3, column j = lane >> 4, channel quad lane & 15
   {
     const bool relu = p.relu != 0;
-    const unsigned long long y_base = (unsigned long long)img0 * p.H * p.W * p.ldy * 4ull;
+    const unsigned long long y_base = (unsigned long long)img0 * p.y_img;
     const unsigned long long y_rest = p.y_bytes - y_base;
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.y) + y_base + (unsigned long long)split * p.y_split_bytes, 0,
@@ -1212,8 +1217,8 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
     const bool q_ok = nq < p.Cout;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && q_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + nq);
-    const unsigned voff = (unsigned)((j * p.ldy + nq) * 4);
-    const int pix_bytes = p.ldy * 4;
+    const unsigned voff = (unsigned)j * p.y_pix + (unsigned)(nq >> 4) * p.y_cb + (unsigned)((nq & 15) * 4);
+    const unsigned pix_bytes = p.y_pix;
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int t = 2 * it + tsel;
@@ -1227,7 +1232,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
       const int oy = 4 * ty + pi;
       const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
       const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
-      const unsigned soff = (unsigned)(((img_rel * p.H + oy) * p.W + 4 * tx) * pix_bytes);
+      const unsigned soff = (unsigned)img_rel * p.y_img + (unsigned)(oy * p.W + 4 * tx) * pix_bytes;
       if (!(KFN_W4B_DBG & 16)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);   // (bit 4: no output stores)
     }
   }
@@ -1268,7 +1273,7 @@ int kfn::wino_f43_lds_bytes(int wino_form) {
 // failing in the first launch.  No device access.
 extern "C" int kfn_winograd_lds_bytes(const kfn_conv_desc* d, int* bytes) {
   KFN_REQUIRE(d && bytes, "kfn_winograd_lds_bytes: null argument");
-  KFN_CONV_DESC_IN(d, "kfn_winograd_lds_bytes");
+  KFN_CONV_DESC_IN_LAYOUTS(d, "kfn_winograd_lds_bytes");
   KFN_REQUIRE(d->kh == 3 && d->kw == 3 && (d->stride == 1 || d->stride == 2) && !d->transposed,
               "kfn_winograd_lds_bytes: the Winograd kernels take 3x3 stride-1 / stride-2 convolutions only");
   int b;
@@ -1284,9 +1289,14 @@ extern "C" int kfn_winograd_lds_bytes(const kfn_conv_desc* d, int* bytes) {
 // that does not need the pointers: what remains there is the 16-byte alignment of y / u4_packed / bias and 8-byte of x.)
 extern "C" int kfn_winograd_f43_supported(const kfn_conv_desc* d) {
   kfn_conv_desc d_full;
-  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_f43_supported") != KFN_OK) return 0;
+  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_f43_supported", true) != KFN_OK) return 0;
   d = &d_full;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->transposed) return 0;
+  if (d->x_layout != KFN_LAYOUT_NHWC || d->y_layout != KFN_LAYOUT_NHWC) {       // channel-blocked: the eight-wave kernel, dense tensors
+    if (d->wino_form == KFN_WINO_FORM_F43_FOUR_WAVE || (d->wino_form == 0 && !KFN_W4_DEFAULT_EIGHT_WAVE)) return 0;
+    if (d->x_layout == KFN_LAYOUT_C16 && d->ldx != d->Cin) return 0;
+    if (d->y_layout == KFN_LAYOUT_C16 && (d->Cout % 16 != 0 || d->ldy != d->Cout)) return 0;
+  }
   if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32 || d->operand_dtype != KFN_OPERAND_F32) return 0;
   if (d->Cin <= 0 || d->Cin % 16 != 0) return 0;
   if ((d->H + 3) / 4 < BH4) return 0;               // an 8-row tile block may straddle at most two images
@@ -1358,6 +1368,13 @@ int wino4_setup(const kfn_conv_desc* d, const float* x, const float* u4_packed, 
   // the B ring prefetches whole 1 KiB fragments of 32 output channels: the last column block of a 32-but-not-64-multiple
   // cout_pad reads 32 channels past the matrix -- the range check returns zeros for them (their accumulators are never stored)
   a.u_bytes = (unsigned)(36L * d->cout_pad * d->Cin * 4L);
+  const bool xb = d->x_layout == KFN_LAYOUT_C16, yb = d->y_layout == KFN_LAYOUT_C16;
+  if (xb && d->ldx != d->Cin)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: a KFN_LAYOUT_C16 input is dense (ldx=%d, Cin=%d)", who, d->ldx, d->Cin);
+  if (yb && (d->Cout % 16 != 0 || ldy != d->Cout))
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "%s: a KFN_LAYOUT_C16 output is dense and Cout %% 16 == 0 (ldy=%d, Cout=%d)", who, ldy, d->Cout);
+  a.x_img = (unsigned)img_b; a.x_pix = xb ? 64u : (unsigned)d->ldx * 4u; a.x_cb = xb ? (unsigned)(d->H * d->W) * 64u : 64u;
+  a.y_img = (unsigned)out_b; a.y_pix = yb ? 64u : (unsigned)ldy * 4u; a.y_cb = yb ? (unsigned)(d->H * d->W) * 64u : 64u;
   a.k_split = 1;
   a.ss_per_split = d->Cin / (8 * CPS);
   a.y_split_bytes = 0;
@@ -1382,13 +1399,15 @@ int wino4b_launch(const Wino4Args& a, hipStream_t stream) {
 extern "C" int kfn_conv2d_winograd_f43(const kfn_conv_desc* d, const float* x, const float* u4_packed, const float* bias,
                                        float* y, void* stream) {
   KFN_REQUIRE(d && x && u4_packed && y, "kfn_conv2d_winograd_f43: null argument");
-  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_f43");
+  KFN_CONV_DESC_IN_LAYOUTS(d, "kfn_conv2d_winograd_f43");
   Wino4Args a;
   int rc = wino4_setup(d, x, u4_packed, bias, y, d->ldy, "kfn_conv2d_winograd_f43", &a);
   if (rc != KFN_OK) return rc;
   // kfn_conv_desc.wino_form: KFN_WINO_FORM_F43_FOUR_WAVE / _EIGHT_WAVE pick the kernel (A/B measurements); AUTO = the default below
   const bool eight = d->wino_form == KFN_WINO_FORM_F43_EIGHT_WAVE ||
                      (d->wino_form != KFN_WINO_FORM_F43_FOUR_WAVE && KFN_W4_DEFAULT_EIGHT_WAVE);
+  if (!eight && (d->x_layout != KFN_LAYOUT_NHWC || d->y_layout != KFN_LAYOUT_NHWC))
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_f43: the four-wave form reads and writes NHWC only");
   if (eight) return wino4b_launch(a, (hipStream_t)stream);
   static std::atomic<uint64_t> attr_done{0};
   rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(wino4_kernel), LDS_V, attr_done);

@@ -706,7 +706,8 @@ int kfn::wino_s2_lds_bytes(int wino_form, int operand_dtype) {
 
 extern "C" int kfn_winograd_s2_supported(const kfn_conv_desc* d) {
   kfn_conv_desc d_full;
-  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_s2_supported") != KFN_OK) return 0;
+  if (!d || kfn::conv_desc_in(d, &d_full, "kfn_winograd_s2_supported", true) != KFN_OK) return 0;
+  if ((d_full.x_layout != KFN_LAYOUT_NHWC || d_full.y_layout != KFN_LAYOUT_NHWC) && d_full.wino_form != KFN_WINO_FORM_S2_F42) return 0;
   d = &d_full;
   if (d->wino_form == KFN_WINO_FORM_S2_F42) return kfn::wino_s2c_supported(d);
   if (d->x_dtype != KFN_ACT_F32 || d->y_dtype != KFN_ACT_F32) return 0;
@@ -818,8 +819,10 @@ int s2_launch(const kfn_conv_desc* d, const float* x, const void* u2_packed, con
 extern "C" int kfn_conv2d_winograd_s2(const kfn_conv_desc* d, const float* x, const void* u2_packed, const float* bias,
                                       float* y, void* stream) {
   KFN_REQUIRE(d && x && u2_packed && y, "kfn_conv2d_winograd_s2: null argument");
-  KFN_CONV_DESC_IN(d, "kfn_conv2d_winograd_s2");
+  KFN_CONV_DESC_IN_LAYOUTS(d, "kfn_conv2d_winograd_s2");
   if (d->wino_form == KFN_WINO_FORM_S2_F42) return kfn::launch_wino_s2c(d, x, u2_packed, bias, y, stream);   // kfn_wino_s2c.hip
+  if (d->x_layout != KFN_LAYOUT_NHWC || d->y_layout != KFN_LAYOUT_NHWC)
+    return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2: only the F(4,2) form (KFN_WINO_FORM_S2_F42) takes KFN_LAYOUT_C16 activations");
   return s2_launch(d, x, u2_packed, bias, y, d->ldy, d->relu, 1, stream);
 }
 

@@ -130,6 +130,10 @@ struct S2cArgs {
   int n_group;
   unsigned long long x_bytes, y_bytes;
   unsigned u_bytes;
+  // byte strides of the activation layouts (kfn_conv_desc.x_layout / y_layout): element (n, h, w, c) at n * img + (h * W + w) * pix +
+  // (c >> 4) * cb + (c & 15) * 4 -- NHWC: pix = ld * 4, cb = 64; KFN_LAYOUT_C16: pix = 64, cb = H * W * 64
+  unsigned x_pix, x_cb, x_img;
+  unsigned y_pix, y_cb, y_img;
 };
 
 template <int I, int N, class F>
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   const int img0 = vr0 / p.Th;
   const int ty0 = vr0 - img0 * p.Th;
   const int brk = (p.Th - ty0 < 4) ? (p.Th - ty0) : 4;        // tile rows >= brk belong to image img0 + 1
-  const unsigned long long a_base = (unsigned long long)img0 * p.H * p.W * p.ldx * 4ull;
+  const unsigned long long a_base = (unsigned long long)img0 * p.x_img;
   const unsigned long long a_rest = p.x_bytes - a_base;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
@@ -214,14 +218,14 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
     const int ty = ptr_ < brk ? ty0 + ptr_ : ptr_ - brk;
     const int tx = cb * 4 + ptc;
     const bool tile_ok = (vr0 + ptr_ < p.vrows) && tx < p.Tw;
-    const unsigned base = (unsigned)((((img_rel * p.H + 8 * ty) * p.W + 8 * tx) * p.ldx + pq8 * 2) * 4);
+    const unsigned base = (unsigned)img_rel * p.x_img + (unsigned)(8 * ty * p.W + 8 * tx) * p.x_pix + (unsigned)(pq8 * 8);
     const bool r8 = 8 * ty + 8 < p.H, c8 = 8 * tx + 8 < p.W;
     gbase[0][0] = tile_ok ? base : OOBV;
     gbase[1][0] = tile_ok && r8 ? base : OOBV;
     gbase[0][1] = tile_ok && c8 ? base : OOBV;
     gbase[1][1] = tile_ok && r8 && c8 ? base : OOBV;
   }
-  const unsigned row_b = (unsigned)(p.W * p.ldx * 4), pix_b = (unsigned)(p.ldx * 4);
+  const unsigned row_b = (unsigned)p.W * p.x_pix, pix_b = p.x_pix;
   // slot layout [4 k][16 rows][4 k-steps] floats: channel 2 pq8 + e = 4 k + s, k = pq8 >> 1, s = 2 (pq8 & 1) + e; tile t is stored
   // in row t ^ 2k.  Reads: ds_read_b128 at (lane's k, row) -- per hardware lane group 16 lanes on 256 different bytes of a 256-byte
   // window (MI355X_MICROARCH.md, LDS: 4 x 16 lanes, 64 banks).  Stores: ds_write_b64 is served in groups of 16 CONTIGUOUS lanes (two
@@ -253,8 +257,9 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   f32x4 vq[2][5];      // V fragments (4 k-steps): [group parity][position of the group]
 
   // register r <- fragment index fq (over all super-steps).  The callers clamp the SUPER-STEP of a prefetch to the last one (once
-  // per super-step, scalar): the descriptor's range check covers the per-lane offset only, not the scalar one, so a prefetch
-  // past the last super-step must re-read valid memory (nobody consumes it).
+  // per super-step, scalar): a prefetch past the last super-step re-reads valid memory (nobody consumes it).  (Not needed for
+  // safety: on gfx950 the range check of a raw descriptor counts voffset + soffset -- tools/mb/srd_probe.hip -- so the unclamped
+  // prefetch would come back as zeros; it was written before that was measured and costs two scalar instructions per super-step.)
   auto b_load = [&](auto rc, int fq) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     bq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, voff_b, (unsigned)fq * b_step, 0));
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
       constexpr int m = i / PW, nn = i % PW;
       constexpr int u = 2 * m + ((PART == 2 || PART == 3) ? 1 : 0), v = 2 * nn + ((PART == 1 || PART == 3) ? 1 : 0);
       // (ss is clamped by the caller, see b_load)
-      const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(ss * (SS_CH * 4));
+      const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)ss * p.x_cb;
       pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, gbase[u == 8][v == 8], so, 0));
     };
     // the transform, one 1-D line per call (NLINE lines): first the lines along n (patch rows), then along m
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   // (tile row kl, tile column e).  Per wave an output image [4 tile rows][4 rows][16 px][16 ch] (+64 B skew per tile row: the four
   // k groups of a store hit different banks), then 16-byte stores of 64-byte runs. ----
   const bool relu = p.relu != 0;
-  const unsigned long long y_base = (unsigned long long)img0 * p.Ho * p.Wo * p.ldy * 4ull;
+  const unsigned long long y_base = (unsigned long long)img0 * p.y_img;
   const unsigned long long y_rest = p.y_bytes - y_base;
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
   const int ox = lane >> 2, nq = lane & 3;             // store lane: block pixel column ox, channel quad nq
   const int ox0 = 16 * cb;
   const bool q_ok = n0 + nq * 4 < p.Cout && ox0 + ox < p.Wo;
-  const unsigned voff_q = q_ok ? (unsigned)(((ox0 + ox) * p.ldy + n0 + nq * 4) * 4) : OOBV;
-  const int pix_bytes = p.ldy * 4;
+  const unsigned voff_q = q_ok ? (unsigned)(ox0 + ox) * p.y_pix + (unsigned)(n0 >> 4) * p.y_cb + (unsigned)(nq * 16) : OOBV;   // (n0 is a multiple of 16)
+  const unsigned pix_bytes = p.y_pix;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int trow = i >> 2, a = i & 3;
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_kernel(S2cArgs p) {
     const int ty = trow < brk ? ty0 + trow : trow - brk;
     const int oy = 4 * ty + a;
     const bool row_ok = vr0 + trow < p.vrows && oy < p.Ho;        // uniform
-    const unsigned soff = (unsigned)(((img_rel * p.Ho + oy) * p.Wo) * pix_bytes);
+    const unsigned soff = (unsigned)img_rel * p.y_img + (unsigned)(oy * p.Wo) * pix_bytes;
     if (!(KFN_S2C_EXP & 64)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
   }
 }
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     const int lv = lane_now();
     const int pt = 8 * (wave & 1) + (lv >> 3), pq8 = lv & 7;
     const int ptr_ = pt >> 2, ptc = pt & 3;
-    const unsigned long long a_base = (unsigned long long)b.img0 * p.H * p.W * p.ldx * 4ull;
+    const unsigned long long a_base = (unsigned long long)b.img0 * p.x_img;
     const unsigned long long a_rest = p.x_bytes - a_base;
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + a_base, 0,
                                             (int)(a_rest < 0x7fffffffull ? a_rest : 0x7fffffffull), 0x00020000);
@@ -498,14 +503,14 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     const int ty = ptr_ < b.brk ? b.ty0 + ptr_ : ptr_ - b.brk;
     const int tx = b.cb * 4 + ptc;
     const bool tile_ok = (b.vr0 + ptr_ < p.vrows) && tx < p.Tw;
-    const unsigned base = (unsigned)((((img_rel * p.H + 8 * ty) * p.W + 8 * tx) * p.ldx + pq8 * 2) * 4);
+    const unsigned base = (unsigned)img_rel * p.x_img + (unsigned)(8 * ty * p.W + 8 * tx) * p.x_pix + (unsigned)(pq8 * 8);
     const bool r8_ = 8 * ty + 8 < p.H, c8_ = 8 * tx + 8 < p.W;
     gbase[0][0] = tile_ok ? base : OOBV;
     gbase[1][0] = tile_ok && r8_ ? base : OOBV;
     gbase[0][1] = tile_ok && c8_ ? base : OOBV;
     gbase[1][1] = tile_ok && r8_ && c8_ ? base : OOBV;
   };
-  const unsigned row_b = (unsigned)(p.W * p.ldx * 4), pix_b = (unsigned)(p.ldx * 4);
+  const unsigned row_b = (unsigned)p.W * p.x_pix, pix_b = p.x_pix;
   const int pk = pq8 >> 1, ph = pq8 & 1;
   const int v_st = (pk * 16 + (pt ^ (2 * pk))) * 4 + 2 * ph;
 
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
     constexpr int PW = (PART == 0 || PART == 2) ? 5 : 4;
     constexpr int m = i / PW, nn = i % PW;
     constexpr int u = 2 * m + ((PART == 2 || PART == 3) ? 1 : 0), v = 2 * nn + ((PART == 1 || PART == 3) ? 1 : 0);
-    const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)(ss * (SS_CH * 4));
+    const unsigned so = (unsigned)u * row_b + (unsigned)v * pix_b + (unsigned)ss * p.x_cb;
     pv[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, gbase[u == 8][v == 8], so, 0));
   };
   auto p_line = [&](auto part_c, auto lc) __attribute__((always_inline)) {
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
 
   const bool relu = p.relu != 0;
   float* const stg = smf + LDS_V / 4 + wave * PSTG;
-  const int pix_bytes = p.ldy * 4;
+  const unsigned pix_bytes = p.y_pix;
   auto at4 = [](float m0, float m1, float m2, float m3, float m4, float& y0, float& y1, float& y2, float& y3) __attribute__((always_inline)) {
     const float s = m1 + m2, d = m1 - m2;
     y0 = (m0 + s) + m3;
@@ -675,13 +680,13 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
       const int lv = lane_now();
       const int rl = lv & 15, kl = lv >> 4;
       const int n0 = cur.tn * NT + wave * 16;
-      const unsigned long long y_base = (unsigned long long)cur.img0 * p.Ho * p.Wo * p.ldy * 4ull;
+      const unsigned long long y_base = (unsigned long long)cur.img0 * p.y_img;
       const unsigned long long y_rest = p.y_bytes - y_base;
       const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<char*>(p.y) + y_base, 0, (int)(y_rest < 0x7fffffffull ? y_rest : 0x7fffffffull), 0x00020000);
       const int spx = lv >> 2, nq = lv & 3;                  // store lane: pixel (i, j) = (spx >> 2, spx & 3) of a tile, channel quad
       const bool q_ok = n0 + nq * 4 < p.Cout;
-      const unsigned voff_q = q_ok ? (unsigned)((((spx >> 2) * p.Wo + (spx & 3)) * p.ldy + n0 + nq * 4) * 4) : OOBV;
+      const unsigned voff_q = q_ok ? (unsigned)((spx >> 2) * p.Wo + (spx & 3)) * p.y_pix + (unsigned)(n0 >> 4) * p.y_cb + (unsigned)(nq * 16) : OOBV;
 #pragma unroll
       for (int e = 0; e < ((KFN_S2C_EXP & 128) ? 0 : 4); ++e) {
         float t[4][5];
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void wino_s2c_pkernel(S2cArgs p) {
           const int img_rel = kk < cur.brk ? 0 : 1;
           const int ty = kk < cur.brk ? cur.ty0 + kk : kk - cur.brk;
           const bool row_ok = col_ok && cur.vr0 + kk < p.vrows;  // (uniform; Ho is a multiple of 4: whole tiles)
-          const unsigned soff = (unsigned)(((img_rel * p.Ho + 4 * ty) * p.Wo + 4 * tx) * pix_bytes);
+          const unsigned soff = (unsigned)img_rel * p.y_img + (unsigned)(4 * ty * p.Wo + 4 * tx) * pix_bytes;
           if (!(KFN_S2C_EXP & 64)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, row_ok ? voff_q : OOBV, soff);
         }
         __builtin_amdgcn_wave_barrier();
@@ -738,13 +743,16 @@ int kfn::wino_s2c_supported(const kfn_conv_desc* d) {
   if (d->H / 8 < 4) return 0;                                                 // a 4-row tile block straddles at most two images
   if (d->Cin <= 0 || d->Cin % SS_CH != 0 || d->cout_pad % 32 != 0) return 0;
   if (d->Cout % 4 != 0 || d->ldy % 4 != 0 || d->ldx % 2 != 0) return 0;      // 16-byte stores, 8-byte gathers
+  if (d->x_layout == KFN_LAYOUT_C16 && d->ldx != d->Cin) return 0;            // channel-blocked tensors are dense
+  if (d->y_layout == KFN_LAYOUT_C16 && (d->Cout % 16 != 0 || d->ldy != d->Cout)) return 0;
   return 1;
 }
 
 int kfn::launch_wino_s2c(const kfn_conv_desc* d, const float* x, const void* u_packed, const float* bias, float* y, void* stream) {
   if (!wino_s2c_supported(d))
     return kfn::fail(KFN_ERR_UNSUPPORTED, "kfn_conv2d_winograd_s2 (F(4,2) form): needs fp32, 3x3 stride 2, H and W multiples of 8 with H >= 32, "
-                     "Cin %% 16 == 0, Cout %% 4 == 0, ldy %% 4 == 0 (got H=%d W=%d Cin=%d Cout=%d ldy=%d)", d->H, d->W, d->Cin, d->Cout, d->ldy);
+                     "Cin %% 16 == 0, Cout %% 4 == 0, ldy %% 4 == 0, KFN_LAYOUT_C16 tensors dense with C %% 16 == 0 (got H=%d W=%d Cin=%d ldx=%d Cout=%d ldy=%d, "
+                     "x_layout %d, y_layout %d)", d->H, d->W, d->Cin, d->ldx, d->Cout, d->ldy, d->x_layout, d->y_layout);
   KFN_REQUIRE(d->N > 0 && d->ldx >= d->Cin && d->ldy >= d->Cout && d->cout_pad >= d->Cout, "kfn_conv2d_winograd_s2 (F(4,2) form): bad strides / channel counts");
   KFN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u_packed) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
               "kfn_conv2d_winograd_s2 (F(4,2) form): buffers must be 16-byte aligned");
@@ -777,6 +785,9 @@ int kfn::launch_wino_s2c(const kfn_conv_desc* d, const float* x, const void* u_p
   a.x_bytes = (unsigned long long)(((in_pix - 1) * d->ldx + d->Cin) * 4L);
   a.y_bytes = (unsigned long long)(((out_pix - 1) * d->ldy + d->Cout) * 4L);
   a.u_bytes = (unsigned)((long)NFRAG * d->cout_pad * d->Cin * 4L);
+  const bool xb = d->x_layout == KFN_LAYOUT_C16, yb = d->y_layout == KFN_LAYOUT_C16;
+  a.x_img = (unsigned)img_b; a.x_pix = xb ? 64u : (unsigned)d->ldx * 4u; a.x_cb = xb ? (unsigned)(d->H * d->W) * 64u : 64u;
+  a.y_img = (unsigned)out_b; a.y_pix = yb ? 64u : (unsigned)d->ldy * 4u; a.y_cb = yb ? (unsigned)(a.Ho * a.Wo) * 64u : 64u;
   const long nwg = (long)a.tiles_m * a.tiles_n;
 #if KFN_S2C_PERSIST
   // the persistent form: one workgroup per CU walking its share of the tile blocks (needs two super-steps of look-ahead inside a

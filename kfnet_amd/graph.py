@@ -67,7 +67,12 @@ class Storage(object):
 class Tensor(object):
     """NHWC tensor handle: a channel window [ch_off, ch_off+C) of a buffer whose pixel
     stride is `ld` elements.  `base` makes this a view that follows its parent when the
-    parent is re-bound into a concat buffer."""
+    parent is re-bound into a concat buffer.
+
+    `layout`: 'nhwc' (every tensor a caller sees) or 'c16' -- per image [C/16][H][W][16] (include/kfnet_hip.h,
+    KFN_LAYOUT_C16), given by Graph.assign_layouts to dense intermediate tensors whose producer and consumers are all
+    Winograd launches that take it.  numpy() / upload() speak NHWC for both; channel views and concat windows of a c16
+    tensor do not exist (they raise)."""
 
     def __init__(self, graph, shape, dtype='f32', name=None, base=None, rel_off=0, rel_batch=0):
         self.graph = graph
@@ -84,6 +89,7 @@ class Tensor(object):
             self._ld = c
             self._off = 0
             self._slot = 0      # element offset of the tensor inside its buffer (slide(): a window that moves per batch)
+            self._layout = 'nhwc'
             graph.storages.append(self.storage)
 
     # -- TF-flavoured introspection ----------------------------------------------------
@@ -101,6 +107,19 @@ class Tensor(object):
     @property
     def ld(self):
         return self.base.ld if self.base is not None else self._ld
+
+    @property
+    def layout(self):
+        return self.base.layout if self.base is not None else self._layout
+
+    def set_layout(self, layout):
+        """Root tensors only, before any data is in the buffer (Graph.assign_layouts)."""
+        if layout not in ('nhwc', 'c16'):
+            raise ValueError('unknown layout %r' % (layout,))
+        if layout == 'c16' and not (self.is_whole() and self.shape[3] % 16 == 0 and self.dtype == 'f32' and not self.external):
+            raise ValueError('tensor %r cannot be channel-blocked: it must be a dense fp32 tensor the graph owns with C %% 16 == 0'
+                             % self.name)
+        self._layout = layout
 
     @property
     def ch_off(self):
@@ -128,6 +147,8 @@ class Tensor(object):
     def rebind(self, storage, ch_off, ld):
         """Move this tensor's data into a window of a wider buffer (concat)."""
         assert self.base is None
+        if self._layout != 'nhwc':
+            raise ValueError('tensor %r is channel-blocked: it cannot become a window of a concat buffer' % self.name)
         if self.storage in self.graph.storages:
             self.graph.storages.remove(self.storage)
         self.storage = storage
@@ -148,6 +169,8 @@ class Tensor(object):
         """tf.slice on the channel axis as a zero-copy view."""
         n, h, w, c = self.shape
         assert 0 <= start and start + count <= c
+        if self.layout != 'nhwc':
+            raise ValueError('tensor %r is channel-blocked: no channel views' % self.name)
         return Tensor(self.graph, (n, h, w, count), self.dtype, name, base=self, rel_off=start)
 
     def batch(self, start, count, name=None):
@@ -165,6 +188,9 @@ class Tensor(object):
             raise _lib.KfnError('tensor %r is not allocated' % self.name)
         torch.cuda.synchronize()
         flat = buf.cpu().numpy()
+        if self.layout == 'c16':        # per image [C/16][H][W][16] -> NHWC
+            blk = flat[self.elem_off:self.elem_off + n * h * w * c].reshape(n, c // 16, h, w, 16)
+            return np.ascontiguousarray(blk.transpose(0, 2, 3, 1, 4)).reshape(n, h, w, c)
         off, ld = self.ch_off + self.elem_off, self.ld
         idx = off + np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :]
         return flat[idx].reshape(n, h, w, c)
@@ -177,6 +203,8 @@ class Tensor(object):
         if arr.dtype != want:
             raise TypeError('tensor %r wants %s, got %s' % (self.name, want, arr.dtype))
         assert self.ld == c and self.ch_off == 0, 'upload needs a channel-dense tensor'
+        if self.layout == 'c16':
+            arr = np.ascontiguousarray(arr.reshape(n, h, w, c // 16, 16).transpose(0, 3, 1, 2, 4))
         dst = self.root_storage.buf[self.elem_off:self.elem_off + arr.size]
         dst.copy_(torch.from_numpy(arr.reshape(-1)), non_blocking=False)
 
@@ -465,8 +493,14 @@ class ConvOp(Op):
                           epilogue=self.epilogue, config=self.config, operand_dtype=self.operand_dtype,
                           x_dtype=_lib.ACT_F16 if self.x.dtype == 'f16' else _lib.ACT_F32,
                           y_dtype=_lib.ACT_F16 if self.y.dtype == 'f16' else _lib.ACT_F32, k_step=self.k_step,
-                          weights_path=int(getattr(self.x.graph, 'conv_weights_path', 0)))
+                          weights_path=int(getattr(self.x.graph, 'conv_weights_path', 0)),
+                          x_layout=_lib.LAYOUT_C16 if self.x.layout == 'c16' else _lib.LAYOUT_NHWC,
+                          y_layout=_lib.LAYOUT_C16 if self.y.layout == 'c16' else _lib.LAYOUT_NHWC)
         return d
+
+    def takes_c16(self):
+        """Can this op's launch read AND write KFN_LAYOUT_C16 activations?  (Graph.assign_layouts; only two kernels can.)"""
+        return False
 
     def flops(self):
         """Nominal dense FLOPs (zero-padding taps counted)."""
@@ -679,6 +713,9 @@ class WinogradF43ConvOp(ConvOp):
         d.wino_form = _lib.WINO_FORM_F43_EIGHT_WAVE if self.eight_wave else _lib.WINO_FORM_F43_FOUR_WAVE
         return d
 
+    def takes_c16(self):
+        return type(self) is WinogradF43ConvOp and self.eight_wave and self.k_split <= 1
+
     @staticmethod
     def supported(x_shape, cin, cout, ldx=None, ldy=None, y_ch_off=0):
         """Mirror of kfn_winograd_f43_supported (+ the launcher's 16-byte alignment of y, which for a tensor is "pixel
@@ -823,6 +860,9 @@ class WinogradS2ConvOp(ConvOp):
         elif self.eight_wave:
             d.wino_form = _lib.WINO_FORM_S2_EIGHT_WAVE
         return d
+
+    def takes_c16(self):
+        return type(self) is WinogradS2ConvOp and self.f42
 
     @staticmethod
     def supported(x_shape, cin, cout):
@@ -1489,6 +1529,10 @@ class Graph(object):
         # (4 rounds of 256 CUs); below that the F(2,2) kernel with its smaller blocks (and split-K) fills the chip better.  0 = never.
         self.winograd_s2_f42 = True
         self.winograd_s2_f42_min_workgroups = 1024
+        # dense intermediate tensors between two launches of wino4b_kernel / wino_s2c_kernel live channel-blocked (KFN_LAYOUT_C16:
+        # per image [C/16][H][W][16]) -- a Winograd super-step's 16 input channels of a patch row are then contiguous (measured at
+        # batch 20: the F(4x4,3x3) kernel -6 ... -10 % per layer).  False = NHWC everywhere.
+        self.activation_layout_c16 = True
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
         # polyphase F(2,2) kernel (kfn_conv2d_winograd_s2); 0 = always the direct implicit GEMM
@@ -1568,9 +1612,59 @@ class Graph(object):
         for op in self.ops:          # routing decisions that depend on the final buffer bindings
             if hasattr(op, 'resolve'):
                 op.resolve()
+        self.assign_layouts()
         for s in self.storages:
             s.allocate(self.device)
         return self
+
+    @staticmethod
+    def _tensor_refs(op):
+        """Every Tensor an op holds, as (attribute name, tensor) -- through lists / tuples / dicts too."""
+        def walk(name, v, depth=0):
+            if isinstance(v, Tensor):
+                yield name, v
+            elif isinstance(v, (list, tuple)) and depth < 3:
+                for e in v:
+                    for r in walk(name, e, depth + 1):
+                        yield r
+            elif isinstance(v, dict) and depth < 3:
+                for e in v.values():
+                    for r in walk(name, e, depth + 1):
+                        yield r
+        for name, v in vars(op).items():
+            for r in walk(name, v):
+                yield r
+
+    def assign_layouts(self):
+        """Channel-blocked layout for the tensors that only Winograd launches touch (after resolve(): the routes are final).
+        A tensor qualifies when it is a dense fp32 root tensor of the graph with C % 16 == 0, EVERY reference any op holds is
+        the tensor itself (no views), exactly one op writes it (as .y) and all others read it as .x, and all of them launch a
+        kernel that takes KFN_LAYOUT_C16.  Anything else -- inputs, outputs, concat members, tensors the cost volume, the
+        heads or the engine's copies read -- stays NHWC.  Returns the names of the blocked tensors."""
+        if not self.activation_layout_c16:
+            return []
+        refs = {}
+        for op in self.ops:
+            for attr, t in self._tensor_refs(op):
+                root = t
+                while root.base is not None:
+                    root = root.base
+                refs.setdefault(id(root), (root, []))[1].append((op, attr, t))
+        blocked = []
+        for root, uses in refs.values():
+            if root.external or not root.is_whole() or root.dtype != 'f32' or root.shape[3] % 16 != 0 or root._slot != 0:
+                continue
+            if any(t is not root for _, _, t in uses):
+                continue
+            writers = [op for op, attr, _ in uses if attr == 'y']
+            readers = [op for op, attr, _ in uses if attr == 'x']
+            if len(writers) != 1 or not readers or len(writers) + len(readers) != len(uses):
+                continue
+            if not all(isinstance(op, ConvOp) and op.takes_c16() for op in writers + readers):
+                continue
+            root.set_layout('c16')
+            blocked.append(root.name)
+        return blocked
 
     def load_weights(self, W, strict=True):
         """RestoreFromScope analogue (KFNet/train.py:317-321): W is {tf_name: ndarray}."""

@@ -74,14 +74,16 @@ def run_conv(x, w, b, stride=1, relu=False, transposed=False, epilogue=0, config
     return out
 
 
-def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, config=0):
+def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, config=0, x_layout='nhwc', y_layout='nhwc'):
     """One launch of a minimal-filtering entry point on x [N,H,W,Cin] fp32 with the TF-layout 3x3 kernel wt:
       kind 'wino'  kfn_conv2d_winograd        (two kernels + workspace; F(2x2,3x3))
            'fused' kfn_conv2d_winograd_fused  (form 0 = the library's routing, 1 = KFN_WINO_FORM_ONE_WAVE)
            'f43'   kfn_conv2d_winograd_f43    (form 2 = four waves, 3 = eight waves)
            's2'    kfn_conv2d_winograd_s2     (stride 2; form 0 = four waves, 4 = eight waves, 5 = the F(4,2) form)
     Input and output live in wider buffers (ldx = Cin + ldx_pad filled with 9.0 behind Cin, ldy = Cout + ldy_pad); guard
-    rows behind the output and the columns behind Cout must come back untouched.  Returns y [N,Ho,Wo,Cout] np fp32."""
+    rows behind the output and the columns behind Cout must come back untouched.  x_layout / y_layout 'c16': that tensor is handed
+    over / comes back channel-blocked (KFN_LAYOUT_C16, per image [C/16][H][W][16]; dense, so its pad is dropped); the conversion
+    from / to NHWC happens here on the host.  Returns y [N,Ho,Wo,Cout] np fp32."""
     import torch
     from kfnet_amd.graph import (pack_winograd_f43_kernel, pack_winograd_f43_kernel_b, pack_winograd_fused_kernel,
                                  pack_winograd_kernel, pack_winograd_s2_kernel, pack_winograd_s2_kernel_b, pack_winograd_s2_kernel_c)
@@ -90,11 +92,19 @@ def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, confi
     co = wt.shape[3]
     stride = 2 if kind == 's2' else 1
     ho, wo = -(-h // stride), -(-w // stride)
+    if x_layout == 'c16':
+        ldx_pad = 0
+    if y_layout == 'c16':
+        ldy_pad = 0
     ldx, ldy = ci + ldx_pad, co + ldy_pad
     d = _lib.ConvDesc(N=n, H=h, W=w, Cin=ci, ldx=ldx, Cout=co, cout_pad=-(-co // 32) * 32, ldy=ldy, kh=3, kw=3,
-                      stride=stride, relu=int(relu), wino_form=form, config=config)
-    xb = np.full((n * h * w, ldx), 9.0, dtype=np.float32)
-    xb[:, :ci] = x.reshape(-1, ci)
+                      stride=stride, relu=int(relu), wino_form=form, config=config,
+                      x_layout=_lib.LAYOUT_C16 if x_layout == 'c16' else 0, y_layout=_lib.LAYOUT_C16 if y_layout == 'c16' else 0)
+    if x_layout == 'c16':
+        xb = np.ascontiguousarray(x.reshape(n, h, w, ci // 16, 16).transpose(0, 3, 1, 2, 4)).reshape(n * h * w, ci)
+    else:
+        xb = np.full((n * h * w, ldx), 9.0, dtype=np.float32)
+        xb[:, :ci] = x.reshape(-1, ci)
     GUARD = 64
     y = torch.full((n * ho * wo + GUARD, ldy), -5.0, device='cuda')
     dx = dev(xb)
@@ -125,4 +135,6 @@ def run_winograd(kind, x, wt, b, relu=False, form=0, ldx_pad=0, ldy_pad=8, confi
     got = y.cpu().numpy()
     assert np.all(got[n * ho * wo:] == -5.0), '%s wrote past the last output pixel' % kind
     assert np.all(got[:, co:] == -5.0), '%s wrote outside its channel window' % kind
+    if y_layout == 'c16':
+        return np.ascontiguousarray(got[:n * ho * wo].reshape(n, co // 16, ho, wo, 16).transpose(0, 2, 3, 1, 4)).reshape(n, ho, wo, co)
     return got[:n * ho * wo, :co].reshape(n, ho, wo, co)

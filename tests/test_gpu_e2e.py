@@ -113,6 +113,32 @@ def test_nis_gate_and_odd_grid():
 #  against the committed fp64-oracle records of tests/golden/kfnet_full.npz instead of recomputing them)
 
 
+def test_channel_blocked_activations_change_nothing_but_addresses():
+    """Graph.activation_layout_c16 (round 6): at batch 8 every tensor from conv1b's output to conv5's lives channel-blocked
+    (KFN_LAYOUT_C16) between the Winograd launches -- the records of an 8-frame 480x640 sequence are BIT-IDENTICAL to the all-NHWC
+    graph's (same products in the same order; only addresses move), an intermediate tensor read back through Tensor.numpy() is the
+    same NHWC array in both, and a small graph (64x96, where neither Winograd form is routed) blocks nothing."""
+    from kfnet_amd.engine import KFNetEngine
+    from kfnet_amd.synth import synthetic_sequence
+    from kfnet_amd.weights import synthetic_weights
+    W = synthetic_weights(11)
+    imgs = synthetic_sequence(8, 480, 640, seed=4)
+    outs, mids = [], []
+    for c16 in (True, False):
+        eng = KFNetEngine(W, image_size=(480, 640), batch=8, reset_period=500, max_chunk=8, graph_options=dict(activation_layout_c16=c16))
+        sc = eng.net.scoordnet
+        blocked = sorted(n for n in ('conv1a', 'conv1b', 'conv2a', 'conv2b', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5', 'conv6')
+                         if sc.get_output_by_name(n).layout == 'c16')
+        assert blocked == (['conv1b', 'conv2a', 'conv2b', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5'] if c16 else []), blocked
+        outs.append(eng.process(eng.upload_frames(imgs)).cpu().numpy().copy())
+        mids.append(sc.get_output_by_name('conv3a').numpy().copy())
+        del eng
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(mids[0], mids[1]) and np.abs(mids[0]).max() > 0
+    small = KFNetEngine(W, image_size=(64, 96), batch=2, reset_period=500, max_chunk=4)
+    assert all(t.layout == 'nhwc' for t in small.net.scoordnet.layers.values() if hasattr(t, 'layout'))
+
+
 def test_chunked_equals_single_pass():
     """Processing a sequence as two chunks with state/feature hand-over (what two ranks do)
     is bit-identical to one pass."""

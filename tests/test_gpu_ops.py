@@ -1139,6 +1139,66 @@ def test_winograd_s2_f42_vs_oracle(case, relu):
     _check_err(err, x, wt, 'f42s2', 'wino s2c %s relu %d' % (case, relu))
 
 
+# channel-blocked activations (KFN_LAYOUT_C16, round 6): (kind, form, N, H, W, Cin, Cout) -- whole and ragged blocks, blocks straddling
+# images, one and many super-steps, the persistent stride-2 form, Cout of 16 / several channel groups
+C16_CASES = [('f43', 3, 2, 32, 16, 16, 64), ('f43', 3, 3, 60, 80, 32, 64), ('f43', 3, 5, 36, 20, 16, 96), ('f43', 3, 3, 29, 35, 32, 112),
+             ('f43', 3, 9, 32, 16, 512, 64), ('f43', 3, 2, 60, 80, 256, 128), ('f43', 3, 1, 29, 12, 32, 16),
+             ('s2', 5, 1, 32, 32, 16, 128), ('s2', 5, 2, 40, 48, 32, 160), ('s2', 5, 3, 32, 40, 48, 48), ('s2', 5, 7, 40, 32, 32, 144),
+             ('s2', 5, 1, 64, 96, 512, 128), ('s2', 5, 8, 120, 160, 32, 512), ('s2', 5, 10, 120, 160, 128, 384)]
+
+
+@pytest.mark.parametrize('layouts', [('c16', 'c16'), ('c16', 'nhwc'), ('nhwc', 'c16')])
+@pytest.mark.parametrize('case', C16_CASES)
+def test_winograd_channel_blocked_layout(case, layouts):
+    """kfn_conv_desc.x_layout / y_layout = KFN_LAYOUT_C16 (per image [C/16][H][W][16]) on the two kernels that take it -- wino4b_kernel
+    and wino_s2c_kernel / wino_s2c_pkernel: blocked in, blocked out, and each mixed with NHWC (the ends of SCoordNet's blocked chain:
+    conv1b reads NHWC, conv6 writes NHWC).  The layout only moves addresses: every combination must be BIT-IDENTICAL to the NHWC
+    launch of the same operands (same products, same order), which the tests above hold to the oracle; the oracle is compared too."""
+    from tests.gpu_util import run_winograd
+    kind, form, n, h, w, ci, co = case
+    rng = np.random.default_rng(n * 1000 + h * 10 + ci + 61)
+    x = np.maximum(rng.normal(size=(n, h, w, ci)), 0).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    base = run_winograd(kind, x, wt, b, relu=True, form=form)
+    got = run_winograd(kind, x, wt, b, relu=True, form=form, x_layout=layouts[0], y_layout=layouts[1])
+    assert np.array_equal(got, base), 'layouts %s: max |diff| %g' % (layouts, np.abs(got - base).max())
+    ref = O.conv2d_same(x.astype(np.float64), wt, b, 2 if kind == 's2' else 1, True)
+    _check_err(np.abs(got - ref).max(), x, wt, 'f42s2' if kind == 's2' else 'f43', 'c16 %s %s' % (case, layouts))
+
+
+def test_channel_blocked_layout_is_refused_where_no_kernel_reads_it():
+    """Every entry point but the two above answers KFN_ERR_UNSUPPORTED for a non-zero layout (instead of reading the buffer as NHWC);
+    the two refuse blocked tensors that are not dense / whose channel count is not a multiple of 16; unknown layout values are
+    KFN_ERR_ARG.  Nothing is launched."""
+    import torch
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 18, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    p = buf.data_ptr()
+    ok = dict(N=1, H=32, W=32, Cin=32, ldx=32, Cout=64, cout_pad=64, ldy=64, kh=3, kw=3, stride=1)
+    blk = dict(x_layout=_lib.LAYOUT_C16, y_layout=_lib.LAYOUT_C16)
+    d = _lib.ConvDesc(**dict(ok, **blk))
+    assert lib.kfn_conv2d_nhwc(C.byref(d), p, p, None, p, st) == -3 and b'NHWC only' in lib.kfn_last_error()
+    assert lib.kfn_conv2d_winograd_fused(C.byref(d), p, p, None, p, st) == -3
+    assert lib.kfn_conv2d_winograd_f43(C.byref(_lib.ConvDesc(**dict(ok, wino_form=2, **blk))), p, p, None, p, st) == -3     # four-wave form
+    assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**dict(ok, wino_form=2, **blk)))) == 0
+    assert lib.kfn_winograd_f43_supported(C.byref(_lib.ConvDesc(**dict(ok, wino_form=3, **blk)))) == 1
+    assert lib.kfn_conv2d_winograd_f43_splitk(C.byref(_lib.ConvDesc(**dict(ok, wino_form=3, **blk))), p, p, None, p, p, 2, st) == -3
+    s2 = dict(ok, stride=2)
+    assert lib.kfn_conv2d_winograd_s2(C.byref(_lib.ConvDesc(**dict(s2, wino_form=4, **blk))), p, p, None, p, st) == -3
+    assert lib.kfn_winograd_s2_supported(C.byref(_lib.ConvDesc(**dict(s2, wino_form=4, **blk)))) == 0
+    assert lib.kfn_winograd_s2_supported(C.byref(_lib.ConvDesc(**dict(s2, wino_form=5, **blk)))) == 1
+    for form, fn, sup in ((3, lib.kfn_conv2d_winograd_f43, lib.kfn_winograd_f43_supported), (5, lib.kfn_conv2d_winograd_s2, lib.kfn_winograd_s2_supported)):
+        base = dict(ok, stride=1 if form == 3 else 2, wino_form=form)
+        for bad in (dict(ldx=40, x_layout=1), dict(ldy=72, y_layout=1), dict(Cout=40, cout_pad=64, ldy=40, y_layout=1)):
+            dd = _lib.ConvDesc(**dict(base, **bad))
+            assert sup(C.byref(dd)) == 0, (form, bad)
+            assert fn(C.byref(dd), p, p, None, p, st) == -3, (form, bad)
+        assert fn(C.byref(_lib.ConvDesc(**dict(base, x_layout=2))), p, p, None, p, st) == -1
+
+
 def test_winograd_s2_f42_refuses_what_it_cannot_take():
     """H or W not a multiple of 8, H < 32, Cin % 16, Cout % 4, ldy % 4: not supported -> KFN_ERR_UNSUPPORTED with a message, nothing
     launched (the graph routes such layers to the F(2,2) form)."""

@@ -44,6 +44,57 @@ def test_library_exports_every_declared_symbol():
     assert lib.kfn_abi_version() == _lib.ABI_VERSION
 
 
+def test_assign_layouts_blocks_only_what_winograd_launches_own():
+    """Graph.assign_layouts (KFN_LAYOUT_C16, round 6): at the bench batch SCoordNet's tensors from conv1b's output to conv5's lie
+    between two launches of wino4b_kernel / wino_s2c_kernel and become channel-blocked; conv1a (written by the first-layer kernel) and
+    conv6 (read by the 1x1 conv7) stay NHWC, and so does everything at batch 1, where the stride-2 layers take the F(2,2) kernel.  A
+    tensor somebody else also reads, a concat member and a view disqualify; blocked tensors refuse channel views and re-binding."""
+    def blocked(g):
+        for op in g.ops:
+            if hasattr(op, 'resolve'):
+                op.resolve()
+        return sorted(g.assign_layouts())
+    chain = ['conv1b', 'conv2a', 'conv2b', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5']
+    g20, net20 = _build(20)
+    assert blocked(g20) == chain
+    sc = net20.scoordnet
+    assert sc.get_output_by_name('conv1a').layout == 'nhwc' and sc.get_output_by_name('conv6').layout == 'nhwc'
+    first = {}
+    for op in g20.ops:
+        first.setdefault(op.name, op)
+    d = first['conv2a'].desc()
+    assert (d.x_layout, d.y_layout) == (1, 1)
+    d = first['conv1b'].desc()
+    assert (d.x_layout, d.y_layout) == (0, 1)           # reads the first-layer kernel's NHWC output
+    d = first['conv6'].desc()
+    assert (d.x_layout, d.y_layout) == (1, 0)           # writes NHWC for the 1x1 conv7
+    assert first['conv7'].desc().x_layout == 0
+    t = sc.get_output_by_name('conv3b')
+    with pytest.raises(ValueError):
+        t.channels(0, 16)
+    with pytest.raises(ValueError):
+        t.rebind(t.storage, 0, t.shape[3] + 16)
+    assert t.batch(1, 2).layout == 'c16'                # batch windows: the image stride is the layout's too
+    assert blocked(_build(4)[0]) == ['conv1b', 'conv2a', 'conv2b', 'conv3a', 'conv4b', 'conv5']     # conv4a takes the F(2,2) kernel there
+    assert blocked(_build(1)[0]) == []
+    assert blocked(_build(20, activation_layout_c16=False)[0]) == []
+    # a second reader that is not such a launch (here: the same tensor also handed to a copy-like op) keeps the tensor NHWC
+    g, net = _build(20)
+    class Peek(object):
+        name = 'peek'
+        def __init__(self, t):
+            self.src = t
+    g.ops.append(Peek(net.scoordnet.get_output_by_name('conv2b')))
+    assert blocked(g) == [n for n in chain if n != 'conv2b']
+    # ... and a reader through a batch VIEW
+    g, net = _build(20)
+    first = {}
+    for op in g.ops:
+        first.setdefault(op.name, op)
+    first['conv3b'].x = first['conv3b'].x.batch(0, 20)
+    assert blocked(g) == [n for n in chain if n != 'conv3a']
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():

@@ -32,7 +32,10 @@ for (name, H, W, ci, co) in LAYERS:
     d16 = _lib.ConvDesc(N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, cout_pad=co, ldy=co, kh=3, kw=3, stride=2, relu=1, operand_dtype=_lib.OPERAND_F16, wino_order=ORDER)
     if F16:
         u = u.half(); w9 = w9.half()
+    lay = os.environ.get('MB_LAYOUT', '00')       # 'xy' digits, 1 = KFN_LAYOUT_C16 (form 5 only; timing -- the buffers hold noise either way)
+    d.x_layout, d.y_layout = int(lay[0]), int(lay[1])
     t_s2 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_s2(C.byref(d16 if F16 else d), x.data_ptr(), u.data_ptr(), None, y.data_ptr(), st), 's2'))
+    d.x_layout, d.y_layout = 0, 0
     t_dir = timeit(lambda: _lib.check(lib.kfn_conv2d_nhwc(C.byref(d16 if F16 else d), x.data_ptr(), w9.data_ptr(), None, y.data_ptr(), st), 'c'))
     nominal = 2.0 * N * (H // 2) * (W // 2) * 9 * ci * co
     print('%-7s %3dx%3d C%4d->%4d: polyphase %.3f ms (%.1f TF executed, %.1f nominal) | direct %.3f ms (%.1f TF)'

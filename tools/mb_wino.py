@@ -27,7 +27,7 @@ FUSED_ONLY = os.environ.get('MB_FUSED_ONLY', '') == '1'
 for (name, H, W, ci, co) in LAYERS:
     if ONLY and name not in ONLY.split(','):
         continue
-    x = torch.randn(N * H * W * ci, device='cuda')
+    x = torch.randn(N * H * W * ci + (1 << 22), device='cuda')      # (+16 MiB: the plane-stride experiments read past the tensor)
     u = torch.randn(16 * co * ci, device='cuda') * 0.02
     y = torch.empty(N * H * W * co + 4, device='cuda')
     YOFF = 4 * int(os.environ.get('MB_Y_MISALIGN', '0'))   # 1: y 4 bytes off a 16-byte boundary -> the kernels' dword-store epilogue
@@ -57,7 +57,11 @@ for (name, H, W, ci, co) in LAYERS:
     f43 = ''
     if os.environ.get('MB_F43', '1') == '1' and not F16 and lib.kfn_winograd_f43_supported(C.byref(dd)) == 1:
         u4 = torch.randn(36 * co * ci, device='cuda') * 0.02
+        # MB_LAYOUT: 'xy' digits, 1 = KFN_LAYOUT_C16 (channel-blocked input / output; timing only -- the buffers hold noise either way)
+        lay = os.environ.get('MB_LAYOUT', '00')
+        dd.x_layout, dd.y_layout = int(lay[0]), int(lay[1])
         t4 = timeit(lambda: _lib.check(lib.kfn_conv2d_winograd_f43(C.byref(dd), x.data_ptr(), u4.data_ptr(), None, y.data_ptr(), st), 'w4'))
+        dd.x_layout, dd.y_layout = 0, 0
         M4 = N * (-(-H // 4)) * (-(-W // 4))
         f43 = ' | F(4x4,3x3) %.3f ms (%.1f TF exec, %.2fx the F(2x2,3x3) kernel)' % (t4, 2.0 * 36 * M4 * ci * co / t4 / 1e9, t_fused / t4)
         del u4
