@@ -1652,6 +1652,7 @@ class Graph(object):
                 refs.setdefault(id(root), (root, []))[1].append((op, attr, t))
         blocked = []
         for root, uses in refs.values():
+            root._layout = 'nhwc'          # (idempotent: a graph that grew since the last call is judged afresh)
             if root.external or not root.is_whole() or root.dtype != 'f32' or root.shape[3] % 16 != 0 or root._slot != 0:
                 continue
             if any(t is not root for _, _, t in uses):
