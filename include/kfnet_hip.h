@@ -43,8 +43,8 @@ extern "C" {
  * kfn_abi_version() == KFN_ABI_VERSION once after loading the library.
  * 6 (round 5): split-K Winograd entry points, kfn_winograd_lds_bytes.  7 (round 5): kfn_decode_png_rgb8.
  * 8 (round 6): KFN_WINO_FORM_S2_F42, kfn_apply_transform / kfn_pixel_map / kfn_bilinear_sampler.
- * 9 (round 6): kfn_conv_desc.x_layout / y_layout (KFN_LAYOUT_C16). */
-#define KFN_ABI_VERSION 9
+ * 9 (round 6): kfn_conv_desc.x_layout / y_layout (KFN_LAYOUT_C16).  10 (round 6): kfn_kalman_arith_probe. */
+#define KFN_ABI_VERSION 10
 
 const char* kfn_last_error(void);
 int kfn_abi_version(void);
@@ -489,6 +489,12 @@ int kfn_kalman_fuse(const float* pred, const float* meas, float* out, float* opt
 /* KFNet.GetKFCoord2 (KFNet/KFNet.py:487-502; not on eval.py's path): the same fusion with the posterior variance in
  * the symmetric form (1-K)^2 P^- + K^2 R.  pred / meas / out packed [P,4] = (x, y, z, sigma) as for kfn_kalman_fuse. */
 int kfn_kalman_fuse2(const float* pred, const float* meas, float* out, long P, void* stream);
+
+/* Self-check of the arithmetic inside kfn_kalman_scan (ABI 10): the scan computes its two square roots and two quotients per pixel
+ * with the refinement steps of the IEEE forms but without their denormal pre-scaling (csrc/kfn_kalman.hip, sqrt_rn_normal /
+ * div_rn_normal: the scan is VALU-bound).  out [n,4] = (lean sqrt(a), sqrtf(a), lean a / b, a / b): the pairs must be equal bit
+ * for bit for normal-range operands, and for zero / infinity / NaN as IEEE defines them. */
+int kfn_kalman_arith_probe(const float* a, const float* b, float* out, long n, void* stream);
 
 /* ---- the graph-level helpers of the reference as stand-alone launches ----------------------------------------
  * On eval.py's path they are fused into the scan (kfn_kalman_scan: warp, fuse, transform in one kernel); these entry

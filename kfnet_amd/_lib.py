@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libkfnet_hip.so')
 
 KFN_OK = 0
-ABI_VERSION = 9
+ABI_VERSION = 10
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_L2NORM, EPI_EXP_CH3, EPI_EXP_1E2 = 0, 1, 2, 3
 OPERAND_F32, OPERAND_F16, OPERAND_F16X3 = 0, 1, 2
@@ -108,6 +108,7 @@ SYMBOLS = {
     'kfn_kalman_scan_ex': (_i, [C.POINTER(KalmanDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'kfn_eval_metrics': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp]),
     'kfn_kalman_fuse': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
+    'kfn_kalman_arith_probe': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_kalman_fuse2': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'kfn_copy_channels': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'kfn_apply_transform': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -77,7 +77,51 @@ __device__ __forceinline__ void st_stream(V* p, const V& v) {
 // exists (p < HW); invalid lanes compute on a clamped duplicate and store nothing.
 // (x, y) = the pixel's grid position (p = y W + x); rec_out != nullptr: the record is handed back instead of stored
 // (the scan kernel stores it through a buffer descriptor with scalar frame / slot offsets).
-template <bool NT = false, bool DBG = true>
+// sqrt and quotient, CORRECTLY ROUNDED like sqrtf / '/' at -ffp-contract=off, for operands in the normal range: the refinement steps
+// hipcc emits for the IEEE forms (v_sqrt + the two one-ulp neighbours tested by their residuals; v_rcp + two Newton steps on the
+// reciprocal and the quotient + the final residual fma) WITHOUT the denormal pre-scaling around them (v_div_scale x 2 / v_div_fmas;
+// the 2^32 scaling, its undo and the zero / infinity class test of the root): 9 + 10 instead of 16 + 12 instructions and none of
+// the VCC hazards' s_nops.  The scan is VALU-bound (154 instructions per pixel, profiles/r06_kalman_scan_pmc.json); variances and
+// sigmas of this model lie in [1e-10, 1e4].  Bit-identical to the IEEE forms there (tools/mb/kalman_mb: every variant against
+// the IEEE build; tests/test_gpu_ops.py::test_kalman_lean_arithmetic_is_correctly_rounded); zero, infinity and NaN come out as
+// IEEE's (v_div_fixup stays; sqrt(0) = 0); operands below 2^-96 may differ in the last place.
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+  const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+  const float rd = __builtin_fmaf(-sd, s, x);
+  const float ru = __builtin_fmaf(-su, s, x);
+  float r = rd <= 0.f ? sd : s;
+  r = ru > 0.f ? su : r;
+  return r;
+}
+__device__ __forceinline__ float div_rn_normal(float a, float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float nb = -b;
+  const float f0 = __builtin_fmaf(nb, r0, 1.0f);
+  const float f1 = __builtin_fmaf(f0, r0, r0);
+  const float m = a * f1;
+  const float f2 = __builtin_fmaf(nb, m, a);
+  const float f3 = __builtin_fmaf(f2, f1, m);
+  const float f4 = __builtin_fmaf(nb, f3, a);
+  const float q = __builtin_fmaf(f4, f1, f3);
+  return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+#ifndef KFN_KALMAN_LEAN
+#define KFN_KALMAN_LEAN 1
+#endif
+template <bool LEAN>
+__device__ __forceinline__ float k_sqrt(float x) {
+  if constexpr (LEAN) return sqrt_rn_normal(x);
+  else return sqrtf(x);
+}
+template <bool LEAN>
+__device__ __forceinline__ float k_div(float a, float b) {
+  if constexpr (LEAN) return div_rn_normal(a, b);
+  else return a / b;
+}
+
+template <bool NT = false, bool DBG = true, bool LEAN = (KFN_KALMAN_LEAN != 0)>
 __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4* st, const PixIn& in, int p, int x, int y,
                                             size_t off, bool reset, int W, float xmax, float ymax,
                                             float eps2, bool want_nis, bool valid = true, f32x4* rec_out = nullptr) {
@@ -121,26 +165,26 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
     // variance propagation (KFNet.py:393-401)
     const float last_var = fmaxf(g.w * g.w, eps2);
     const float trans_var = fmaxf(in.st * in.st, eps2);
-    const float temp_unc = sqrtf(trans_var + last_var);
+    const float temp_unc = k_sqrt<LEAN>(trans_var + last_var);
     // BuildKFCoord (KFNet.py:148-162) -- note last_variance = square(sqrt(.))
     const float lv = temp_unc * temp_unc;
     const float mv = z.w * z.w;
-    const float K = lv / (lv + mv);
+    const float K = k_div<LEAN>(lv, lv + mv);
     const float om = fmaxf(1.0f - K, 0.0f);
     f32x4 kf;
     kf.x = om * g.x + K * z.x;
     kf.y = om * g.y + K * z.y;
     kf.z = om * g.z + K * z.z;
-    kf.w = sqrtf(om * lv);
+    kf.w = k_sqrt<LEAN>(om * lv);
     nv = kf;
     outv = kf;  // eval.py:103-104: the raw KF state (nv) is what is fed back
     if (a.opt_kf && valid) a.opt_kf[off + p] = kf;
     if (want_nis) {
       // GetNIS (KFNet.py:164-184)
-      const float iu = sqrtf(temp_unc * temp_unc + z.w * z.w);
+      const float iu = k_sqrt<LEAN>(temp_unc * temp_unc + z.w * z.w);
       const float iv = iu * iu;
       const float d0 = z.x - g.x, d1 = z.y - g.y, d2 = z.z - g.z;
-      const float n0 = (d0 * d0) / iv, n1 = (d1 * d1) / iv, n2 = (d2 * d2) / iv;
+      const float n0 = k_div<LEAN>(d0 * d0, iv), n1 = k_div<LEAN>(d1 * d1, iv), n2 = k_div<LEAN>(d2 * d2, iv);
       if (a.d.nis_gate > 0.f && ((n0 + n1) + n2) > a.d.nis_gate) {
         // eval.py:87-92: gated OUTPUT takes the measurement coords, keeps KF sigma
         outv.x = z.x; outv.y = z.y; outv.z = z.z;
@@ -171,7 +215,7 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
   } else {
     r.x = outv.x; r.y = outv.y; r.z = outv.z;
   }
-  r.w = 1.0f / outv.w;
+  r.w = k_div<LEAN>(1.0f, outv.w);
   if (rec_out != nullptr) *rec_out = r;
   else if (valid) st_stream<NT>(a.rec + off + p, r);
   return nv;
@@ -193,7 +237,7 @@ __device__ __forceinline__ f32x4 fuse_pixel(const KalmanArgs& a_in, const f32x4*
 // so the production 60x80 form stays as measured in the profiles.  false = buffer descriptors with scalar frame / slot
 // offsets (below): no per-slot registers, which is what lets the single-buffer forms of the larger grids run without spills
 // (68x120, S = 256: 0.720 against 0.43 for rounds 1-4's form).
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false>
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false, bool LEAN = (KFN_KALMAN_LEAN != 0)>
 __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   static_assert(D >= 1 && D <= PPT && PPT % D == 0, "ring slots are compile-time constants");
   extern __shared__ __attribute__((aligned(16))) float smem_k[];
@@ -212,11 +256,11 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
   // of frame t sits at  voffset = tid * size  (per thread)  +  soffset = (t HW + k KT) * size  (wave-uniform: scalar
   // registers and scalar arithmetic).  The per-pixel 64-bit pointers of the first version cost eight loop-invariant VGPRs
   // per slot (the compiler hoists them out of the frame loop): 56-224 spilled registers in the single-buffer forms.  The
-  // hardware range-checks voffset (NOT the scalar offset) against num_records: a thread whose slot lies past the grid
+  // hardware range-checks voffset + soffset against num_records (tools/mb/srd_probe.hip): a thread whose slot lies past the grid
   // (tid + k KT >= HW) gets a voffset beyond every sequence -- its loads return zeros, its stores are dropped -- so every
   // load and store is unconditional, the number of vector-memory operations between a load and its use is a compile-time
   // constant and the s_waitcnt in front of the use leaves the younger loads in flight.  (The look-ahead's frame index is
-  // clamped to T - 1: the scalar offset is not range-checked.  T HW 16 < 2^31 -- checked by the launcher -- keeps the
+  // clamped to T - 1: it re-reads the last frame instead of zeros.  T HW 16 < 2^31 -- checked by the launcher -- keeps the
   // poison 0x08000000 elements beyond num_records for all three element sizes.)
   const size_t seq_px = (size_t)s * T * HW;
   const unsigned aux = NT ? 2u : 0u;          // the non-temporal bit: streamed once, not re-read by this launch
@@ -290,9 +334,9 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel(KalmanArgs a) {
       if constexpr (PTR) {
         const int pc = min(tid + k * KT, HW - 1);
         const int yc = pc / W, xc = pc - yc * W;
-        nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], pc, xc, yc, off, reset, W, xmax, ymax, eps2, want_nis, valid);
+        nv = fuse_pixel<NT, DBG, LEAN>(a, st, ring[k % D], pc, xc, yc, off, reset, W, xmax, ymax, eps2, want_nis, valid);
       } else {
-        nv = fuse_pixel<NT, DBG>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
+        nv = fuse_pixel<NT, DBG, LEAN>(a, st, ring[k % D], p, xk, yk, off, reset, W, xmax, ymax, eps2, want_nis, valid, &rec);
         kfn::buffer_store_b128<NT ? 2 : 0>(rec, rsR, slot_index(tv, k) * 16u,
                                            (unsigned)(t * HW + k * KT) * 16u);               // (threads past the grid: dropped)
       }
@@ -444,10 +488,10 @@ __global__ __launch_bounds__(256) void kalman_fuse2_kernel(const f32x4* __restri
 #define KFN_FUSE_NT 1
 #endif
 
-template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false>
+template <int KT, int PPT, bool DBL, int D, bool NT, bool DBG, bool PTR = false, bool LEAN = (KFN_KALMAN_LEAN != 0)>
 int launch_scan_dbg(const KalmanArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)a.d.H * a.d.W * sizeof(f32x4) * (DBL ? 2 : 1);
-  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG, PTR>;
+  auto kern = kalman_scan_kernel<KT, PPT, DBL, D, NT, DBG, PTR, LEAN>;
   static std::atomic<uint64_t> attr_done{0};   // per instantiation: bit per device
   {
     int rc = kfn::set_max_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done);
@@ -465,6 +509,21 @@ template <int KT, int PPT, bool DBL, int D, bool NT, int KT_DBG = KT, int PPT_DB
 int launch_scan(const KalmanArgs& a, hipStream_t stream) {
   if (a.opt_temp || a.opt_nis || a.opt_kf) return launch_scan_dbg<KT_DBG, PPT_DBG, DBL, DD, NT, true, false>(a, stream);
   return launch_scan_dbg<KT, PPT, DBL, D, NT, false, /*PTR=*/DBL>(a, stream);
+}
+
+// self-check of the scan's sqrt / quotient (kfn_kalman_arith_probe): out[4 i .. 4 i + 3] = sqrt_rn_normal(a), sqrtf(a),
+// div_rn_normal(a, b), a / b
+__global__ __launch_bounds__(256) void kalman_arith_probe_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 f32x4* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i], y = b[i];
+  f32x4 r;
+  r.x = sqrt_rn_normal(x);
+  r.y = sqrtf(x);
+  r.z = div_rn_normal(x, y);
+  r.w = x / y;
+  out[i] = r;
 }
 
 }  // namespace
@@ -571,5 +630,14 @@ extern "C" int kfn_kalman_fuse2(const float* pred, const float* meas, float* out
                      reinterpret_cast<const f32x4*>(pred), reinterpret_cast<const f32x4*>(meas),
                      reinterpret_cast<f32x4*>(out), P);
   KFN_LAUNCH_CHECK("kalman_fuse2_kernel");
+  return KFN_OK;
+}
+
+extern "C" int kfn_kalman_arith_probe(const float* a, const float* b, float* out, long n, void* stream) {
+  KFN_REQUIRE(a && b && out && n > 0 && (n + 255) / 256 < (1L << 31), "kfn_kalman_arith_probe: bad argument");
+  KFN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "kfn_kalman_arith_probe: out must be 16-byte aligned");
+  hipLaunchKernelGGL(kalman_arith_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     reinterpret_cast<f32x4*>(out), n);
+  KFN_LAUNCH_CHECK("kalman_arith_probe_kernel");
   return KFN_OK;
 }

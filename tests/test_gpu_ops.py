@@ -338,6 +338,47 @@ def test_kalman_scan_is_reproducible_under_memory_load(grid):
     assert not bad, 'launches %s differ from the unloaded one' % bad
 
 
+def test_kalman_lean_arithmetic_is_correctly_rounded():
+    """The scan's square root and quotient (csrc/kfn_kalman.hip: sqrt_rn_normal / div_rn_normal -- the IEEE refinement steps without
+    the denormal pre-scaling, because the scan is VALU-bound) against sqrtf and '/' of the same build at -ffp-contract=off, through
+    kfn_kalman_arith_probe: BIT-IDENTICAL on 2^24 random bit patterns with exponents in [-90, 90] (both signs for the quotient), on
+    this model's own range ([1e-10, 1e4]) and on the specials 0, inf and NaN; numpy's correctly rounded sqrt / divide agree too."""
+    import torch
+    from kfnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2024)
+    n = 1 << 24
+    def rand_normal(size, signed):
+        e = rng.integers(127 - 90, 127 + 90, size=size, dtype=np.uint32)
+        m = rng.integers(0, 1 << 23, size=size, dtype=np.uint32)
+        sgn = rng.integers(0, 2, size=size, dtype=np.uint32) if signed else np.zeros(size, np.uint32)
+        return ((sgn << 31) | (e << 23) | m).view(np.float32)
+    a = rand_normal(n, False)
+    b = rand_normal(n, True)
+    # exponents of a / b kept inside the normal range (the lean quotient's contract)
+    keep = np.abs(np.log2(a.astype(np.float64)) - np.log2(np.abs(b).astype(np.float64))) < 100
+    a, b = a[keep], b[keep]
+    model = rng.uniform(1e-10, 1e4, size=1 << 20).astype(np.float32)
+    a = np.concatenate([a, model, model[::-1].copy(), np.float32([0.0, 0.0, np.inf, 1.0, np.nan, 1.0, 4.0, 0.0])])
+    b = np.concatenate([b, model[::-1].copy(), np.float32(1.0) + model, np.float32([1.0, 0.0, 2.0, np.inf, 1.0, np.nan, 0.0, -3.0])])
+    n = a.size
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.zeros(n * 4, device='cuda')
+    _lib.check(lib.kfn_kalman_arith_probe(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream), 'probe')
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(n, 4)
+    bits = o.view(np.uint32)
+    nan_s = np.isnan(o[:, 0]) & np.isnan(o[:, 1])
+    nan_q = np.isnan(o[:, 2]) & np.isnan(o[:, 3])
+    assert np.all((bits[:, 0] == bits[:, 1]) | nan_s), 'lean sqrt differs from sqrtf in %d places' % int(np.sum((bits[:, 0] != bits[:, 1]) & ~nan_s))
+    assert np.all((bits[:, 2] == bits[:, 3]) | nan_q), 'lean quotient differs from / in %d places' % int(np.sum((bits[:, 2] != bits[:, 3]) & ~nan_q))
+    with np.errstate(all='ignore'):
+        ref_s, ref_q = np.sqrt(a), a / b
+    ok = np.isfinite(ref_q) & (np.abs(ref_q) >= np.finfo(np.float32).tiny) | (ref_q == 0) | np.isinf(ref_q)
+    assert np.array_equal(o[~np.isnan(ref_s), 0], ref_s[~np.isnan(ref_s)])
+    assert np.array_equal(o[ok, 2], ref_q[ok])
+
+
 def test_kalman_fuse2_symmetric_variance():
     """kfn_kalman_fuse2 = KFNet.GetKFCoord2's fusion (KFNet/KFNet.py:487-502): bit exact vs the fp32 numpy oracle;
     KAT: equal noise -> K = 1/2, mean of the two, sigma / sqrt(2); its sigma equals BuildKFCoord's up to round-off."""

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(KT) void kalman_scan_kernel_r4(KalmanArgs a) {
     for (int k = 0; k < PPT; ++k) {
       const int p = tid + k * KT;
       if (p < HW) {
-        const f32x4 nv = fuse_pixel<false, true>(a, st, cur[k], p, p % W, p / W, off, reset, W, xmax, ymax, eps2, want_nis);
+        const f32x4 nv = fuse_pixel<false, true, false>(a, st, cur[k], p, p % W, p / W, off, reset, W, xmax, ymax, eps2, want_nis);
         if (DBL) st_new[p] = nv; else newst[DBL ? 0 : k] = nv;
       }
       // keep the unrolled pixels sequential: interleaving them only multiplies live
@@ -149,13 +149,15 @@ int main(int argc, char** argv) {
 
   std::vector<Variant> vs;
   if (HW * 32 <= 160 * 1024) {
-    vs.push_back({"r4: 768x7 burst prefetch (rounds 1-4)", launch_scan_r4<768, 7, true, true>});
+    vs.push_back({"r4: 768x7 burst prefetch (rounds 1-4), IEEE sqrt / div", launch_scan_r4<768, 7, true, true>});
     vs.push_back({"768x7  D=7 nt (rolling)", launch_scan_dbg<768, 7, true, 7, true, false>});
     vs.push_back({"768x7  D=1 plain (~ rounds 1-4 without the burst prefetch)", launch_scan_dbg<768, 7, true, 1, false, false>});
     vs.push_back({"768x7  D=7 plain", launch_scan_dbg<768, 7, true, 7, false, false>});
-    vs.push_back({"1024x5 D=5 nt, descriptors", launch_scan_dbg<1024, 5, true, 5, true, false>});
+    vs.push_back({"1024x5 D=5 nt, descriptors, IEEE", launch_scan_dbg<1024, 5, true, 5, true, false, false, false>});
     vs.push_back({"1024x5 D=5 plain", launch_scan_dbg<1024, 5, true, 5, false, false>});
-    vs.push_back({"1024x5 D=5 nt, POINTER addressing (default)", launch_scan_dbg<1024, 5, true, 5, true, false, true>});
+    vs.push_back({"1024x5 D=5 nt, POINTER addressing, IEEE sqrt / div", launch_scan_dbg<1024, 5, true, 5, true, false, true, false>});
+    vs.push_back({"1024x5 D=5 nt, POINTER addressing, lean (default)", launch_scan_dbg<1024, 5, true, 5, true, false, true, true>});
+    vs.push_back({"1024x5 D=5 nt, descriptors, lean", launch_scan_dbg<1024, 5, true, 5, true, false, false, true>});
     vs.push_back({"768x7  D=7 nt, pointer addressing", launch_scan_dbg<768, 7, true, 7, true, false, true>});
     vs.push_back({"1024x5 D=1 nt", launch_scan_dbg<1024, 5, true, 1, true, false>});
     vs.push_back({"512x10 D=10 nt", launch_scan_dbg<512, 10, true, 10, true, false>});
