@@ -145,7 +145,7 @@ typedef struct kfn_conv_desc {
  * default everywhere.  C16 ("channel-blocked"): per image [C/16][H][W][16], element at n*H*W*C + (((c/16)*H + h)*W + w)*16
  * + c%16 -- needs C % 16 == 0 and a dense tensor (ld == C).  The image stride is the same, so batch windows of a tensor are
  * layout-agnostic.  The Winograd kernels read 16 input channels of a patch per step: in C16 a 6-pixel patch row is 384
- * contiguous bytes instead of six 64-byte pieces of six different lines (measured: the F(4x4,3x3) kernel -7 %). */
+ * contiguous bytes instead of six 64-byte pieces of six different lines (measured: the F(4x4,3x3) kernel -2 ... -3 %). */
 #define KFN_LAYOUT_NHWC 0
 #define KFN_LAYOUT_C16 1
 

@@ -1531,7 +1531,7 @@ class Graph(object):
         self.winograd_s2_f42_min_workgroups = 1024
         # dense intermediate tensors between two launches of wino4b_kernel / wino_s2c_kernel live channel-blocked (KFN_LAYOUT_C16:
         # per image [C/16][H][W][16]) -- a Winograd super-step's 16 input channels of a patch row are then contiguous (measured at
-        # batch 20: the F(4x4,3x3) kernel -6 ... -10 % per layer).  False = NHWC everywhere.
+        # batch 20: the F(4x4,3x3) kernel -2 ... -3 % per layer).  False = NHWC everywhere.
         self.activation_layout_c16 = True
         self.winograd_fused_max_channels = 1024
         # 3x3 stride-2 layers of even-sized images with at least this many input / 128 output channels take the
