@@ -103,7 +103,7 @@ def pipeline_io_bytes(eng):
     return total
 
 
-def kalman_roofline(device, S=256, T=64, H=60, W=80):
+def kalman_roofline(device, S=256, T=64, H=60, W=80, flow='random'):
     """Batched persistent scan: S sequences x T frames per launch,
     76 B/px algorithmic traffic (44 read + 32 written)."""
     import ctypes as C
@@ -112,7 +112,12 @@ def kalman_roofline(device, S=256, T=64, H=60, W=80):
     lib = _lib.load()
     hw = H * W
     g = torch.Generator(device=device).manual_seed(0)     # generated in HBM: 1.5 G values at T = 256
-    flow = torch.randn(S * T * hw * 2, generator=g, device=device) * 1.5
+    flow_kind = flow
+    flow = torch.randn(S * T * hw * 2, generator=g, device=device) * 1.5      # 'random': every pixel warps from its own random neighbour
+    if flow_kind == 'smooth':      # (tools/kalman_roofline.py --smooth-flow: one displacement per frame + 0.05 px of noise -- what a camera
+        #  motion looks like; neighbouring lanes then gather neighbouring pixels and the LDS reads are conflict-free)
+        per_frame = torch.randn(S * T, 1, 2, generator=g, device=device) * 1.5
+        flow = (per_frame + flow.view(S * T, hw, 2) * (0.05 / 1.5)).reshape(-1).contiguous()
     sig = torch.rand(S * T * hw, generator=g, device=device) * 0.05 + 0.001
     meas = torch.randn(S * T * hw * 4, generator=g, device=device)
     meas[3::4] = meas[3::4].abs() * 0.3 + 0.05

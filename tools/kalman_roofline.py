@@ -21,7 +21,9 @@ if __name__ == '__main__':
     T = int(sys.argv[sys.argv.index('--T') + 1]) if '--T' in sys.argv else 64
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    out = {'scan': bench.kalman_roofline(dev, T=T)}
+    # `--smooth-flow`: a per-frame displacement + 0.05 px of noise instead of an independent random neighbour per pixel (a side
+    # measurement: bench.py's `roofline_kalman` keeps the random field, the worst case for the LDS gather)
+    out = {'scan': bench.kalman_roofline(dev, T=T, flow='smooth' if '--smooth-flow' in sys.argv else 'random')}
     if T == 64:
         out['fuse'] = bench.kalman_fuse_roofline(dev)
     print(json.dumps(out))
