@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
   // the image leaves: iteration `it` = tiles 2 it, 2 it + 1 (wave >> 2), pixel row i = wave & 3, column j = lane >> 4, channel quad lane & 15
   {
     const bool relu = p.relu != 0;
-    const unsigned long long y_base = (unsigned long long)img0 * p.y_img;
+    const unsigned long long y_base = (KFN_W4B_DBG & 64) ? 0ull : (unsigned long long)img0 * p.y_img;
     const unsigned long long y_rest = p.y_bytes - y_base;
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.y) + y_base + (unsigned long long)split * p.y_split_bytes, 0,
@@ -1232,8 +1232,11 @@ __global__ __launch_bounds__(512, 1) void wino4b_kernel(Wino4Args p) {
       const int oy = 4 * ty + pi;
       const bool row_ok = (vr0 + tr < p.vrows) && (tx < p.Tw) && (oy < p.H);     // uniform
       const bool ok = row_ok && q_ok && (4 * tx + j < p.W);
-      const unsigned soff = (unsigned)img_rel * p.y_img + (unsigned)(oy * p.W + 4 * tx) * pix_bytes;
-      if (!(KFN_W4B_DBG & 16)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);   // (bit 4: no output stores)
+      unsigned soff = (unsigned)img_rel * p.y_img + (unsigned)(oy * p.W + 4 * tx) * pix_bytes;
+      if (KFN_W4B_DBG & 64) soff = (unsigned)((4 * tr + pi) * p.W + 4 * tcc + 16 * (blockIdx.x & 255)) * pix_bytes;
+      // (timing bits: 4 no output stores; 5 only every other one; 6 every workgroup of a CU-sized group writes the same 131 KB)
+      if ((KFN_W4B_DBG & 32) && (it & 1)) continue;
+      if (!(KFN_W4B_DBG & 16)) kfn::buffer_store_b128<KFN_NT_STORE_AUX>(v, rsY, ok ? voff : ROW_POISON, row_ok ? soff : 0u);
     }
   }
 }
